@@ -1,0 +1,181 @@
+/*
+ * stereo_recon_hip.h -- C-ABI of libstereo_recon_hip.so: the MI355X (gfx950) dense
+ * matching-cost / support-weight aggregation / winner-take-all path of
+ * StereoReconstruction, i.e. what the reference computes inside
+ *   TwoViewStereo::computeCostVolumes / crossCheck   (stereo/twoviewstereo.cpp:233-502, 596-672)
+ *   MultiViewStereo::computeInitialEstimate / crossCheck (stereo/multiviewstereo.cpp:524-662, 666-729)
+ * and the helpers they call.
+ *
+ * Plain C: opaque context, POD structs, caller-owned buffers, integer status
+ * codes, no exceptions, no torch / Qt / Eigen types.  A Qt adapter (or the
+ * Qt-free C++ classes in stereoreconstruction_amd/host/) sits on top and keeps
+ * the reference's TwoViewStereo / MultiViewStereo class API; INTEGRATION.md shows
+ * the binding.  All arithmetic on the path is IEEE double, evaluated in the
+ * reference's operation order with FMA contraction off.
+ *
+ * Every entry point returns SRH_OK (0) or a negative SRH_E_* code;
+ * srh_last_error() returns a human-readable message for the calling thread.
+ */
+#ifndef STEREO_RECON_HIP_H
+#define STEREO_RECON_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRH_ABI_VERSION 1
+
+enum {
+	SRH_OK = 0,
+	SRH_E_INVALID = -1,    /* bad argument (NULL, size mismatch, slot out of range ...) */
+	SRH_E_DEVICE = -2,     /* HIP runtime error (message has the hipError string) */
+	SRH_E_NO_DEVICE = -3,  /* no usable GPU: the library has NO CPU fallback */
+	SRH_E_CANCELLED = -4,  /* cancel flag observed between launches */
+	SRH_E_UNSUPPORTED = -5
+};
+
+enum { SRH_WEIGHT_ADAPTIVE = 0, SRH_WEIGHT_GEODESIC = 1 };
+enum { SRH_MAX_VIEWS = 64 };
+
+/* Snapshot of a reference `Camera` (project/camera.hpp:168-185): the adapter
+ * copies these at TwoViewStereo construction / MultiViewStereo::initialize so the
+ * GUI may keep mutating its Camera objects (races).
+ * 3x3 matrices are row-major. */
+typedef struct srh_camera {
+	double K[9], Kinv[9], R[9], Rinv[9];
+	double t[3], C[3];
+	double dist[5];          /* k1,k2,p1,p2,k3 -- LensDistortions order (project.cpp:143-147) */
+	int32_t is_distorted;    /* Camera::isDistorted() */
+	int32_t is_refractive;   /* Camera::isRefractive() */
+	double plane_normal[3];  /* Camera::plane().normal(), camera-local, unit */
+	double plane_dist;       /* Camera::plane().distance() */
+	double refr_index;       /* Camera::refractiveIndex() */
+	double pdir[3];          /* Camera::principleRay().direction() */
+} srh_camera;
+
+/* Every constant the reference hard-codes on this path, with its default
+ * (twoviewstereo.cpp:64-80, multiviewstereo.cpp:90-102, adaptiveweight.cpp:26,
+ * geodesicweight.cpp:33-41) plus the run-time arguments of
+ * TwoViewStereo::TwoViewStereo / MultiViewStereo::initialize. */
+typedef struct srh_params {
+	double  min_depth, max_depth;
+	int32_t num_depth_levels;
+	int32_t window_radius;        /* TwoView 5, MVS 2 */
+	double  image_scale;          /* images handed over are ALREADY scaled by this */
+	int32_t weight_kind;          /* SRH_WEIGHT_* ; reference default geodesic */
+	int32_t geodesic_iters;       /* 3 */
+	double  geodesic_sigma;       /* 50 */
+	double  geodesic_init;        /* 1e6 */
+	double  adaptive_color_sigma; /* 10 */
+	double  weight_cutoff;        /* 1e-10 */
+	double  bad_ret;              /* 1000 */
+	double  max_color_diff;       /* 120 */
+	double  second_best_factor;   /* 0.95 */
+	double  wta_margin;           /* 1e-10 */
+	double  inconsistency_thresh; /* 1 */
+	double  peak_threshold;       /* 0.95 */
+	double  cross_check_threshold;
+	double  neighbour_min_dot;    /* 0.2 */
+	int32_t top_k;                /* 9 */
+	int32_t num_neighbours;       /* 3 */
+} srh_params;
+
+/* Counters of the last run on a context (for N_eval reporting). */
+typedef struct srh_stats {
+	int64_t n_pixels;        /* reference pixels with mask == WHITE */
+	int64_t n_eval;          /* cost evaluations the reference would have performed */
+	int64_t n_eval_device;   /* cost evaluations actually performed on the device */
+	int32_t used_dense_path; /* 1 if the row-aligned dense kernel ran */
+	int32_t reserved;
+} srh_stats;
+
+typedef struct srh_context srh_context;
+
+/* Progress / cancellation hooks = Task::progressUpdate / stageUpdate / isCancelled
+ * (gui/task.hpp:57-105).  `cancel` is polled between kernel launches. */
+typedef void (*srh_progress_fn)(int step, const char *stage, void *user);
+
+/* ---- library ---- */
+int         srh_abi_version(void);
+const char *srh_last_error(void);
+int         srh_device_count(int *count);
+
+/* ---- parameters and cameras (host-side math only) ---- */
+void srh_params_twoview_defaults(srh_params *p);   /* twoviewstereo.cpp:64-80 */
+void srh_params_mvs_defaults(srh_params *p);       /* multiviewstereo.cpp:90-102 */
+/* Camera::set(K,R,t) + setLensDistortion + setPlane/setRefractiveIndex
+ * (project/camera.cpp:225-240, 302-344).  dist / plane_normal may be NULL. */
+int  srh_camera_from_krt(const double K[9], const double R[9], const double t[3],
+                         const double dist[5],
+                         const double plane_normal[3], double plane_dist, double refr_index,
+                         srh_camera *out);
+/* MultiViewStereo::runTask neighbour selection (multiviewstereo.cpp:335-360):
+ * neigh[v*p->num_neighbours + k], count[v]. */
+int  srh_mvs_neighbours(int nviews, const srh_camera *cams, const srh_params *p,
+                        int32_t *neigh, int32_t *count);
+
+/* ---- context ---- */
+int  srh_create(int device_ordinal, srh_context **out);
+void srh_destroy(srh_context *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+int  srh_set_stream(srh_context *ctx, void *hip_stream);
+int  srh_set_hooks(srh_context *ctx, const volatile int *cancel, srh_progress_fn progress, void *user);
+int  srh_synchronize(srh_context *ctx);
+
+/* ---- views: what VectorImage::fromQImage + the mask test hold (util/vectorimage.cpp:48-64) ----
+ * rgba: w*h*4 bytes R,G,B,A of the ALREADY SCALED image; mask: w*h bytes,
+ * 1 <=> mask.pixel(x,y)==WHITE, NULL = all WHITE.  Host pointers; copied. */
+int  srh_view_upload(srh_context *ctx, int slot, int w, int h,
+                     const uint8_t *rgba, const uint8_t *mask, const srh_camera *cam);
+int  srh_view_size(srh_context *ctx, int slot, int *w, int *h);
+/* The context keeps one depth map (w*h doubles) per view slot in device memory. */
+int  srh_view_depth_download(srh_context *ctx, int slot, double *host_out);
+int  srh_view_depth_upload(srh_context *ctx, int slot, const double *host_in);
+int  srh_view_depth_device_ptr(srh_context *ctx, int slot, void **dev_ptr);
+
+/* ---- TwoViewStereo ----
+ * One pass of computeCostVolumes (twoviewstereo.cpp:260-333 with ref=left,
+ * :431-501 with ref=right): depth map of `ref_slot` against `oth_slot`, rows
+ * [y0,y1) (y1<=0: all).  Asynchronous on the context stream; result stays in the
+ * slot's device depth map. */
+int  srh_twoview_wta(srh_context *ctx, int ref_slot, int oth_slot, const srh_params *p,
+                     int y0, int y1);
+/* crossCheck (twoviewstereo.cpp:596-672): left pass, then right pass reading the
+ * filtered left map; in place on the two slots' depth maps. */
+int  srh_twoview_cross_check(srh_context *ctx, int left_slot, int right_slot, const srh_params *p);
+/* computeDepthMaps minus colourisation (twoviewstereo.cpp:150-227): both passes +
+ * cross-check, progress steps 1,3,5,8; synchronous; host outputs may be NULL. */
+int  srh_twoview_compute(srh_context *ctx, int left_slot, int right_slot, const srh_params *p,
+                         double *left_depth_out, double *right_depth_out);
+
+/* ---- MultiViewStereo ----
+ * computeInitialEstimate(view) non-MRF result (multiviewstereo.cpp:524-604,654-660)
+ * for `view_slot` against up to num_neighbours neighbour slots, rows [y0,y1).
+ * peaks_dev (optional, DEVICE pointer, w*h*top_k*2 doubles) receives the sorted
+ * top-K (cost,depth) pairs the MRF branch would consume. */
+int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *neigh_slots, int nneigh,
+                              const srh_params *p, int y0, int y1, void *peaks_dev);
+/* crossCheck(view) (multiviewstereo.cpp:666-729) over `nviews` slots listed in view
+ * order; call for view index 0..nviews-1 in order to reproduce the reference's
+ * sequential dependence. */
+int  srh_mvs_cross_check(srh_context *ctx, const int32_t *slots, int nviews, int view_index,
+                         const srh_params *p);
+
+/* ---- measurement ---- */
+int  srh_get_stats(srh_context *ctx, srh_stats *out);
+/* When enabled every kernel launch is bracketed by hipEvents on the context
+ * stream; durations are accumulated per kernel name. */
+int  srh_profile_enable(srh_context *ctx, int on);
+int  srh_profile_reset(srh_context *ctx);
+/* total_ms / launches of kernel `name`; returns SRH_E_INVALID if never launched. */
+int  srh_profile_get(srh_context *ctx, const char *name, double *total_ms, int64_t *launches);
+/* Writes up to cap bytes of "name total_ms launches\n" lines. */
+int  srh_profile_dump(srh_context *ctx, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREO_RECON_HIP_H */

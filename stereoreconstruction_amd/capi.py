@@ -1,0 +1,309 @@
+"""ctypes binding of include/stereo_recon_hip.h (libstereo_recon_hip.so).
+
+This is the ONLY compute path of the package: there is no CPU / numpy fallback.
+If the shared library is missing the import of :func:`lib` raises, and if no HIP
+device is present :class:`Context` raises ``StereoHipError`` (SRH_E_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstereo_recon_hip.so")
+
+SRH_OK = 0
+SRH_E_INVALID, SRH_E_DEVICE, SRH_E_NO_DEVICE, SRH_E_CANCELLED, SRH_E_UNSUPPORTED = -1, -2, -3, -4, -5
+WEIGHT_ADAPTIVE, WEIGHT_GEODESIC = 0, 1
+MAX_VIEWS = 64
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class Camera(C.Structure):
+    """srh_camera"""
+    _fields_ = [
+        ("K", C.c_double * 9), ("Kinv", C.c_double * 9), ("R", C.c_double * 9), ("Rinv", C.c_double * 9),
+        ("t", C.c_double * 3), ("C", C.c_double * 3),
+        ("dist", C.c_double * 5),
+        ("is_distorted", C.c_int32), ("is_refractive", C.c_int32),
+        ("plane_normal", C.c_double * 3), ("plane_dist", C.c_double), ("refr_index", C.c_double),
+        ("pdir", C.c_double * 3),
+    ]
+
+
+class Params(C.Structure):
+    """srh_params"""
+    _fields_ = [
+        ("min_depth", C.c_double), ("max_depth", C.c_double),
+        ("num_depth_levels", C.c_int32), ("window_radius", C.c_int32),
+        ("image_scale", C.c_double),
+        ("weight_kind", C.c_int32), ("geodesic_iters", C.c_int32),
+        ("geodesic_sigma", C.c_double), ("geodesic_init", C.c_double),
+        ("adaptive_color_sigma", C.c_double), ("weight_cutoff", C.c_double),
+        ("bad_ret", C.c_double), ("max_color_diff", C.c_double),
+        ("second_best_factor", C.c_double), ("wta_margin", C.c_double),
+        ("inconsistency_thresh", C.c_double),
+        ("peak_threshold", C.c_double), ("cross_check_threshold", C.c_double),
+        ("neighbour_min_dot", C.c_double),
+        ("top_k", C.c_int32), ("num_neighbours", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    """srh_stats"""
+    _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
+                ("used_dense_path", C.c_int32), ("reserved", C.c_int32)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
+
+# every symbol include/stereo_recon_hip.h declares
+EXPORTS = [
+    "srh_abi_version", "srh_last_error", "srh_device_count",
+    "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_mvs_neighbours",
+    "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize",
+    "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
+    "srh_view_depth_device_ptr",
+    "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
+    "srh_mvs_initial_estimate", "srh_mvs_cross_check",
+    "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
+]
+
+
+class StereoHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("srh error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libstereo_recon_hip.so; raises OSError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s not found: build it with `make -C stereoreconstruction_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.srh_abi_version.restype = C.c_int
+    L.srh_last_error.restype = C.c_char_p
+    L.srh_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.srh_params_twoview_defaults.argtypes = [C.POINTER(Params)]
+    L.srh_params_twoview_defaults.restype = None
+    L.srh_params_mvs_defaults.argtypes = [C.POINTER(Params)]
+    L.srh_params_mvs_defaults.restype = None
+    L.srh_camera_from_krt.argtypes = [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                      C.c_double, C.c_double, C.POINTER(Camera)]
+    L.srh_mvs_neighbours.argtypes = [C.c_int, C.POINTER(Camera), C.POINTER(Params), c_int32_p, c_int32_p]
+    L.srh_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.srh_destroy.argtypes = [vp]
+    L.srh_destroy.restype = None
+    L.srh_set_stream.argtypes = [vp, vp]
+    L.srh_set_hooks.argtypes = [vp, C.POINTER(C.c_int), PROGRESS_FN, vp]
+    L.srh_synchronize.argtypes = [vp]
+    L.srh_view_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_uint8_p, c_uint8_p, C.POINTER(Camera)]
+    L.srh_view_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.srh_view_depth_download.argtypes = [vp, C.c_int, c_double_p]
+    L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
+    L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.srh_twoview_wta.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
+    L.srh_twoview_cross_check.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params)]
+    L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
+    L.srh_mvs_initial_estimate.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.c_int, C.c_int, vp]
+    L.srh_mvs_cross_check.argtypes = [vp, c_int32_p, C.c_int, C.c_int, C.POINTER(Params)]
+    L.srh_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.srh_profile_enable.argtypes = [vp, C.c_int]
+    L.srh_profile_reset.argtypes = [vp]
+    L.srh_profile_get.argtypes = [vp, C.c_char_p, c_double_p, C.POINTER(C.c_int64)]
+    L.srh_profile_dump.argtypes = [vp, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != SRH_OK:
+        raise StereoHipError(rc, lib().srh_last_error().decode("utf-8", "replace"))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def params_twoview(**kw):
+    p = Params()
+    lib().srh_params_twoview_defaults(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def params_mvs(**kw):
+    p = Params()
+    lib().srh_params_mvs_defaults(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def camera_from_krt(K, R, t, dist=None, plane_normal=None, plane_dist=0.0, refr_index=1.0):
+    """Camera::set(K,R,t) + distortion + refractive interface -> srh_camera snapshot."""
+    cam = Camera()
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+    d = None if dist is None else np.ascontiguousarray(dist, dtype=np.float64).reshape(5)
+    n = None if plane_normal is None else np.ascontiguousarray(plane_normal, dtype=np.float64).reshape(3)
+    _check(lib().srh_camera_from_krt(_dptr(K), _dptr(R), _dptr(t),
+                                     _dptr(d) if d is not None else None,
+                                     _dptr(n) if n is not None else None,
+                                     plane_dist, refr_index, C.byref(cam)))
+    return cam
+
+
+def mvs_neighbours(cams, p):
+    n = len(cams)
+    arr = (Camera * n)(*cams)
+    neigh = np.full((n, max(1, p.num_neighbours)), -1, dtype=np.int32)
+    cnt = np.zeros(n, dtype=np.int32)
+    _check(lib().srh_mvs_neighbours(n, arr, C.byref(p), neigh.ctypes.data_as(c_int32_p),
+                                    cnt.ctypes.data_as(c_int32_p)))
+    return [[int(v) for v in neigh[i, :cnt[i]]] for i in range(n)]
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().srh_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """One srh_context bound to one GPU."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().srh_create(device, C.byref(self._h)))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            lib().srh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing
+    def set_stream(self, stream_ptr):
+        _check(lib().srh_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_hooks(self, cancel_flag=None, progress=None):
+        """cancel_flag: ctypes.c_int; progress: callable(step, stage_str)."""
+        cb = PROGRESS_FN(lambda step, stage, user: progress(step, stage.decode())) if progress else PROGRESS_FN()
+        self._keep = [cb, cancel_flag]
+        _check(lib().srh_set_hooks(self._h, C.byref(cancel_flag) if cancel_flag is not None else None, cb, None))
+
+    def synchronize(self):
+        _check(lib().srh_synchronize(self._h))
+
+    # -- views
+    def upload_view(self, slot, rgba, mask, cam):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        if rgba.ndim != 3 or rgba.shape[2] != 4:
+            raise ValueError("rgba must be HxWx4 uint8")
+        h, w = rgba.shape[:2]
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            if m.shape != (h, w):
+                raise ValueError("mask must be HxW uint8")
+        _check(lib().srh_view_upload(self._h, slot, w, h, rgba.ctypes.data_as(c_uint8_p),
+                                     m.ctypes.data_as(c_uint8_p) if m is not None else None, C.byref(cam)))
+
+    def view_size(self, slot):
+        w, h = C.c_int(0), C.c_int(0)
+        _check(lib().srh_view_size(self._h, slot, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def download_depth(self, slot):
+        w, h = self.view_size(slot)
+        out = np.empty((h, w), dtype=np.float64)
+        _check(lib().srh_view_depth_download(self._h, slot, _dptr(out)))
+        return out
+
+    def upload_depth(self, slot, depth):
+        w, h = self.view_size(slot)
+        d = np.ascontiguousarray(depth, dtype=np.float64)
+        if d.shape != (h, w):
+            raise ValueError("depth must be %dx%d" % (h, w))
+        _check(lib().srh_view_depth_upload(self._h, slot, _dptr(d)))
+
+    def depth_device_ptr(self, slot):
+        p = C.c_void_p()
+        _check(lib().srh_view_depth_device_ptr(self._h, slot, C.byref(p)))
+        return p.value
+
+    # -- TwoViewStereo
+    def twoview_wta(self, ref_slot, oth_slot, p, y0=0, y1=0):
+        _check(lib().srh_twoview_wta(self._h, ref_slot, oth_slot, C.byref(p), y0, y1))
+
+    def twoview_cross_check(self, left_slot, right_slot, p):
+        _check(lib().srh_twoview_cross_check(self._h, left_slot, right_slot, C.byref(p)))
+
+    def twoview_compute(self, left_slot, right_slot, p):
+        w, h = self.view_size(left_slot)
+        dl = np.empty((h, w), dtype=np.float64)
+        dr = np.empty((h, w), dtype=np.float64)
+        _check(lib().srh_twoview_compute(self._h, left_slot, right_slot, C.byref(p), _dptr(dl), _dptr(dr)))
+        return dl, dr
+
+    # -- MultiViewStereo
+    def mvs_initial_estimate(self, view_slot, neigh_slots, p, y0=0, y1=0, peaks_dev=None):
+        ng = np.ascontiguousarray(neigh_slots, dtype=np.int32)
+        _check(lib().srh_mvs_initial_estimate(self._h, view_slot, ng.ctypes.data_as(c_int32_p), len(ng),
+                                              C.byref(p), y0, y1, C.c_void_p(peaks_dev) if peaks_dev else None))
+
+    def mvs_cross_check(self, slots, view_index, p):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        _check(lib().srh_mvs_cross_check(self._h, s.ctypes.data_as(c_int32_p), len(s), view_index, C.byref(p)))
+
+    # -- measurement
+    def stats(self):
+        s = Stats()
+        _check(lib().srh_get_stats(self._h, C.byref(s)))
+        return dict(n_pixels=s.n_pixels, n_eval=s.n_eval, n_eval_device=s.n_eval_device,
+                    used_dense_path=bool(s.used_dense_path))
+
+    def profile_enable(self, on=True):
+        _check(lib().srh_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _check(lib().srh_profile_reset(self._h))
+
+    def profile(self):
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().srh_profile_dump(self._h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.split()
+            out[name] = (float(ms), int(n))
+        return out

@@ -1,0 +1,597 @@
+// srh_api.hip -- the C-ABI of include/stereo_recon_hip.h: context, view upload,
+// run entry points, measurement.  Host code only; every numeric result comes from
+// the kernels in srh_kernels.hip / srh_dense.hip.  There is no CPU fallback: without
+// a HIP device srh_create fails with SRH_E_NO_DEVICE.
+#include "srh_internal.hpp"
+#include "srh_geom.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace srh;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+	do {                                                                                \
+		hipError_t e_ = (expr);                                                         \
+		if (e_ != hipSuccess)                                                           \
+			return fail(SRH_E_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+// ------------------------------------------------------------------ context
+struct ViewHost {
+	int w = 0, h = 0;
+	bool present = false;
+	uint32_t *rgba = nullptr;
+	uint8_t  *mask = nullptr;
+	double   *gray = nullptr, *gray_tv = nullptr, *depth = nullptr;
+	srh_camera cam;
+};
+
+struct ProfEntry { double ms = 0; int64_t n = 0; };
+struct PendingEvt { std::string name; hipEvent_t a, b; };
+
+struct srh_context {
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	ViewHost views[SRH_MAX_VIEWS];
+	ViewDev *d_views = nullptr;
+	int32_t *d_slots = nullptr;
+	Counters *d_cnt = nullptr;
+	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
+	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
+	Extent *ext = nullptr;    size_t ext_cap = 0;       // pixels
+	size_t wbuf_budget = (size_t)128 << 20;             // bytes per band of support windows
+	const volatile int *cancel = nullptr;
+	srh_progress_fn progress = nullptr;
+	void *user = nullptr;
+	bool profiling = false;
+	bool force_generic = false;
+	std::map<std::string, ProfEntry> prof;
+	std::vector<PendingEvt> pending;
+	srh_stats stats;
+};
+
+static bool cancelled(srh_context *c) { return c->cancel && *c->cancel; }
+static void progress(srh_context *c, int step, const char *stage) { if (c->progress) c->progress(step, stage, c->user); }
+
+static int drain_profile(srh_context *c) {
+	for (auto &p : c->pending) {
+		float ms = 0;
+		HIP_TRY(hipEventSynchronize(p.b));
+		HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+		ProfEntry &e = c->prof[p.name];
+		e.ms += ms; e.n += 1;
+		hipEventDestroy(p.a); hipEventDestroy(p.b);
+	}
+	c->pending.clear();
+	return SRH_OK;
+}
+
+// bracket one kernel launch with events when profiling
+struct Scope {
+	srh_context *c; PendingEvt p; bool on;
+	Scope(srh_context *c_, const char *name) : c(c_), on(c_->profiling) {
+		if (on) {
+			p.name = name;
+			hipEventCreate(&p.a); hipEventCreate(&p.b);
+			hipEventRecord(p.a, c->stream);
+		}
+	}
+	~Scope() {
+		if (on) {
+			hipEventRecord(p.b, c->stream);
+			c->pending.push_back(p);
+			if (c->pending.size() > 4096) drain_profile(c);
+		}
+	}
+};
+
+template <class T>
+static int ensure(T *&ptr, size_t &cap, size_t need) {
+	if (cap >= need) return SRH_OK;
+	if (ptr) { HIP_TRY(hipFree(ptr)); ptr = nullptr; cap = 0; }
+	HIP_TRY(hipMalloc((void **)&ptr, need*sizeof(T)));
+	cap = need;
+	return SRH_OK;
+}
+
+static int check_slot(srh_context *c, int slot, bool must_exist) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (slot < 0 || slot >= SRH_MAX_VIEWS) return fail(SRH_E_INVALID, "view slot %d out of range [0,%d)", slot, SRH_MAX_VIEWS);
+	if (must_exist && !c->views[slot].present) return fail(SRH_E_INVALID, "view slot %d has no image", slot);
+	return SRH_OK;
+}
+
+static int check_params(const srh_params *p) {
+	if (!p) return fail(SRH_E_INVALID, "null params");
+	if (p->num_depth_levels < 2) return fail(SRH_E_INVALID, "num_depth_levels %d < 2", p->num_depth_levels);
+	if (p->window_radius < 1 || p->window_radius > 15) return fail(SRH_E_INVALID, "window_radius %d outside [1,15]", p->window_radius);
+	if (!(p->image_scale > 0)) return fail(SRH_E_INVALID, "image_scale must be > 0");
+	if (p->weight_kind != SRH_WEIGHT_ADAPTIVE && p->weight_kind != SRH_WEIGHT_GEODESIC)
+		return fail(SRH_E_INVALID, "weight_kind %d unknown", p->weight_kind);
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ library
+extern "C" int srh_abi_version(void) { return SRH_ABI_VERSION; }
+extern "C" const char *srh_last_error(void) { return g_err; }
+
+extern "C" int srh_device_count(int *count) {
+	if (!count) return fail(SRH_E_INVALID, "null count");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+	*count = n;
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ params / cameras (host math)
+extern "C" void srh_params_twoview_defaults(srh_params *p) {
+	memset(p, 0, sizeof(*p));
+	p->min_depth = 10; p->max_depth = 100; p->num_depth_levels = 100;   // gui/forms/stereowidget.ui:199-288
+	p->window_radius = 5;                 // twoviewstereo.cpp:66
+	p->image_scale = 1.0;
+	p->weight_kind = SRH_WEIGHT_GEODESIC; // twoviewstereo.cpp:84
+	p->geodesic_iters = 3; p->geodesic_sigma = 50.0; p->geodesic_init = 1000000.0;   // geodesicweight.cpp:33-36,68
+	p->adaptive_color_sigma = 10.0;       // adaptiveweight.cpp:26
+	p->weight_cutoff = 1e-10;
+	p->bad_ret = 1000; p->max_color_diff = 120;            // twoviewstereo.cpp:65,74
+	p->second_best_factor = 0.95; p->wta_margin = 1e-10; p->inconsistency_thresh = 1;   // :78-79,293
+	p->peak_threshold = 0.95;             // multiviewstereo.cpp:589
+	p->cross_check_threshold = 1.0;
+	p->neighbour_min_dot = 0.2;           // multiviewstereo.cpp:343
+	p->top_k = 9; p->num_neighbours = 3;  // multiviewstereo.cpp:94,97
+}
+
+extern "C" void srh_params_mvs_defaults(srh_params *p) {
+	srh_params_twoview_defaults(p);
+	p->window_radius = 2;                 // multiviewstereo.cpp:91
+}
+
+static bool near_zero(double x) { return (x <= 1e-10 && x >= -1e-10); }   // camera.cpp:51-52
+
+extern "C" int srh_camera_from_krt(const double K[9], const double Rin[9], const double t[3],
+                                   const double dist[5], const double plane_normal[3],
+                                   double plane_dist, double refr_index, srh_camera *out)
+{
+	if (!K || !Rin || !t || !out) return fail(SRH_E_INVALID, "null argument");
+	srh_camera c;
+	memset(&c, 0, sizeof(c));
+	memcpy(c.K, K, sizeof(c.K));
+	memcpy(c.R, Rin, sizeof(c.R));
+	memcpy(c.t, t, sizeof(c.t));
+	// orthonormalize(R_): Gram-Schmidt over columns, then flush |v| < 1e-10 to 0 (camera.cpp:140-160)
+	for (int i = 0; i < 3; ++i) {
+		Vec3 accum = v3(0, 0, 0);
+		for (int j = 0; j < i; ++j) {
+			const Vec3 vi = v3(c.R[i], c.R[3 + i], c.R[6 + i]);
+			const Vec3 vj = v3(c.R[j], c.R[3 + j], c.R[6 + j]);
+			const double scale = dot(vi, vj) / dot(vj, vj);
+			accum = accum + vj*scale;
+		}
+		const Vec3 col = normalized(v3(c.R[i], c.R[3 + i], c.R[6 + i]) - accum);
+		c.R[i] = col.x; c.R[3 + i] = col.y; c.R[6 + i] = col.z;
+	}
+	for (int k = 0; k < 9; ++k) if (-1e-10 < c.R[k] && c.R[k] < 1e-10) c.R[k] = 0.0;
+	{   // Kinv_ = K_.inverse() (3x3 cofactor inverse)
+		const double *m = c.K;
+		const double c00 = m[4]*m[8] - m[5]*m[7];
+		const double c01 = m[5]*m[6] - m[3]*m[8];
+		const double c02 = m[3]*m[7] - m[4]*m[6];
+		const double det = (m[0]*c00 + m[1]*c01) + m[2]*c02;
+		const double invdet = 1.0 / det;
+		c.Kinv[0] = c00*invdet;
+		c.Kinv[1] = (m[2]*m[7] - m[1]*m[8])*invdet;
+		c.Kinv[2] = (m[1]*m[5] - m[2]*m[4])*invdet;
+		c.Kinv[3] = c01*invdet;
+		c.Kinv[4] = (m[0]*m[8] - m[2]*m[6])*invdet;
+		c.Kinv[5] = (m[2]*m[3] - m[0]*m[5])*invdet;
+		c.Kinv[6] = c02*invdet;
+		c.Kinv[7] = (m[1]*m[6] - m[0]*m[7])*invdet;
+		c.Kinv[8] = (m[0]*m[4] - m[1]*m[3])*invdet;
+	}
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.Rinv[i*3 + j] = c.R[j*3 + i];
+	{ const Vec3 C = matvec(c.Rinv, v3(-t[0], -t[1], -t[2])); c.C[0] = C.x; c.C[1] = C.y; c.C[2] = C.z; }
+	{   // updatePrincipleRay (camera.cpp:292-298)
+		const Vec3 tc = v3(c.K[2]/c.K[8], c.K[5]/c.K[8], c.K[8]/c.K[8]);
+		const Vec3 dir = normalized(matvec(c.Kinv, tc));
+		const Vec3 pd = normalized(matvec(c.Rinv, dir));
+		c.pdir[0] = pd.x; c.pdir[1] = pd.y; c.pdir[2] = pd.z;
+	}
+	if (dist) {
+		memcpy(c.dist, dist, sizeof(c.dist));
+		c.is_distorted = !near_zero(dist[0]) || !near_zero(dist[1]) || !near_zero(dist[2])
+		              || !near_zero(dist[3]) || !near_zero(dist[4]);
+	}
+	c.plane_normal[2] = 1.0; c.plane_dist = 0.0; c.refr_index = 1.0;
+	if (plane_normal) {
+		const Vec3 n = normalized(load3(plane_normal));       // Plane3d ctor, plane.hpp:32
+		c.plane_normal[0] = n.x; c.plane_normal[1] = n.y; c.plane_normal[2] = n.z;
+		c.plane_dist = plane_dist;
+		c.refr_index = refr_index;
+	}
+	c.is_refractive = (!near_zero(c.refr_index - 1) && !near_zero(c.plane_dist));   // camera.cpp:326-344
+	*out = c;
+	return SRH_OK;
+}
+
+extern "C" int srh_mvs_neighbours(int nviews, const srh_camera *cams, const srh_params *p,
+                                  int32_t *neigh, int32_t *count)
+{
+	if (nviews < 0 || !cams || !p || !neigh || !count) return fail(SRH_E_INVALID, "null argument");
+	if (p->num_neighbours < 0) return fail(SRH_E_INVALID, "num_neighbours < 0");
+	// multiviewstereo.cpp:335-360
+	for (int v = 0; v < nviews; ++v) {
+		std::vector<std::pair<double, int>> nearViews;
+		for (int v2 = 0; v2 < nviews; ++v2) {
+			if (v == v2) continue;
+			if (fabs(dot(load3(cams[v].pdir), load3(cams[v2].pdir))) > p->neighbour_min_dot) {
+				const Vec3 d = load3(cams[v].C) - load3(cams[v2].C);
+				nearViews.push_back(std::make_pair(dot(d, d), v2));
+			}
+		}
+		size_t end = nearViews.size();
+		if ((size_t)p->num_neighbours < nearViews.size()) {
+			std::sort(nearViews.begin(), nearViews.end());
+			end = (size_t)p->num_neighbours;
+		}
+		for (size_t k = 0; k < end; ++k) neigh[(size_t)v*p->num_neighbours + k] = nearViews[k].second;
+		count[v] = (int32_t)end;
+	}
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int srh_create(int device, srh_context **out) {
+	if (!out) return fail(SRH_E_INVALID, "null out");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		(void)hipGetLastError();
+		return fail(SRH_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+		            e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+	}
+	if (device < 0 || device >= n) return fail(SRH_E_INVALID, "device ordinal %d outside [0,%d)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	srh_context *c = new srh_context();
+	c->device = device;
+	memset(&c->stats, 0, sizeof(c->stats));
+	if (const char *s = getenv("SRH_WBUF_MB")) { long mb = atol(s); if (mb > 0) c->wbuf_budget = (size_t)mb << 20; }
+	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
+	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
+	c->stream = c->own_stream;
+	if (hipMalloc((void **)&c->d_views, sizeof(ViewDev)*SRH_MAX_VIEWS) != hipSuccess ||
+	    hipMalloc((void **)&c->d_slots, sizeof(int32_t)*SRH_MAX_VIEWS) != hipSuccess ||
+	    hipMalloc((void **)&c->d_cnt, sizeof(Counters)) != hipSuccess) {
+		srh_destroy(c);
+		return fail(SRH_E_DEVICE, "hipMalloc of context tables failed");
+	}
+	hipMemset(c->d_views, 0, sizeof(ViewDev)*SRH_MAX_VIEWS);
+	hipMemset(c->d_cnt, 0, sizeof(Counters));
+	*out = c;
+	return SRH_OK;
+}
+
+static void free_view(ViewHost &v) {
+	if (v.rgba) hipFree(v.rgba);
+	if (v.mask) hipFree(v.mask);
+	if (v.gray) hipFree(v.gray);
+	if (v.gray_tv) hipFree(v.gray_tv);
+	if (v.depth) hipFree(v.depth);
+	v = ViewHost();
+}
+
+extern "C" void srh_destroy(srh_context *c) {
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->own_stream) hipStreamSynchronize(c->own_stream);
+	drain_profile(c);
+	for (auto &v : c->views) free_view(v);
+	if (c->d_views) hipFree(c->d_views);
+	if (c->d_slots) hipFree(c->d_slots);
+	if (c->d_cnt) hipFree(c->d_cnt);
+	if (c->wbuf) hipFree(c->wbuf);
+	if (c->cost) hipFree(c->cost);
+	if (c->ext) hipFree(c->ext);
+	if (c->own_stream) hipStreamDestroy(c->own_stream);
+	delete c;
+}
+
+extern "C" int srh_set_stream(srh_context *c, void *hip_stream) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+	return SRH_OK;
+}
+
+extern "C" int srh_set_hooks(srh_context *c, const volatile int *cancel, srh_progress_fn progress_fn, void *user) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	c->cancel = cancel; c->progress = progress_fn; c->user = user;
+	return SRH_OK;
+}
+
+extern "C" int srh_synchronize(srh_context *c) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ views
+extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
+                               const uint8_t *rgba, const uint8_t *mask, const srh_camera *cam)
+{
+	int rc = check_slot(c, slot, false); if (rc) return rc;
+	if (w <= 0 || h <= 0 || (size_t)w*h > ((size_t)1 << 30)) return fail(SRH_E_INVALID, "bad image size %dx%d", w, h);
+	if (!rgba || !cam) return fail(SRH_E_INVALID, "null rgba / camera");
+	HIP_TRY(hipSetDevice(c->device));
+	ViewHost &v = c->views[slot];
+	const size_t n = (size_t)w*h;
+	if (!v.present || v.w != w || v.h != h) {
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		free_view(v);
+		HIP_TRY(hipMalloc((void **)&v.rgba, n*4));
+		HIP_TRY(hipMalloc((void **)&v.mask, n));
+		HIP_TRY(hipMalloc((void **)&v.gray, n*sizeof(double)));
+		HIP_TRY(hipMalloc((void **)&v.gray_tv, n*sizeof(double)));
+		HIP_TRY(hipMalloc((void **)&v.depth, n*sizeof(double)));
+		v.w = w; v.h = h; v.present = true;
+	}
+	v.cam = *cam;
+	HIP_TRY(hipMemcpyAsync(v.rgba, rgba, n*4, hipMemcpyHostToDevice, c->stream));
+	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
+	else      HIP_TRY(hipMemsetAsync(v.mask, 1, n, c->stream));
+	{ Scope s(c, "prep_view_kernel"); launch_prep_view(c->stream, v.rgba, v.mask, w, h, v.gray, v.gray_tv); }
+	launch_fill(c->stream, v.depth, n, __builtin_nan(""));
+	ViewDev d;
+	d.w = w; d.h = h; d.rgba = v.rgba; d.mask = v.mask; d.gray = v.gray; d.gray_tv = v.gray_tv; d.depth = v.depth;
+	d.cam = v.cam;
+	HIP_TRY(hipMemcpyAsync(c->d_views + slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));   // the host buffers and `d` may go away after return
+	HIP_TRY(hipGetLastError());
+	return SRH_OK;
+}
+
+extern "C" int srh_view_size(srh_context *c, int slot, int *w, int *h) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (w) *w = c->views[slot].w;
+	if (h) *h = c->views[slot].h;
+	return SRH_OK;
+}
+
+extern "C" int srh_view_depth_download(srh_context *c, int slot, double *host_out) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!host_out) return fail(SRH_E_INVALID, "null output");
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	HIP_TRY(hipMemcpyAsync(host_out, v.depth, (size_t)v.w*v.h*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return SRH_OK;
+}
+
+extern "C" int srh_view_depth_upload(srh_context *c, int slot, const double *host_in) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!host_in) return fail(SRH_E_INVALID, "null input");
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	HIP_TRY(hipMemcpyAsync(v.depth, host_in, (size_t)v.w*v.h*sizeof(double), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return SRH_OK;
+}
+
+extern "C" int srh_view_depth_device_ptr(srh_context *c, int slot, void **dev_ptr) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!dev_ptr) return fail(SRH_E_INVALID, "null output");
+	*dev_ptr = c->views[slot].depth;
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ runs
+static int band_rows(srh_context *c, int W, int H, int T) {
+	size_t rows = c->wbuf_budget / ((size_t)T*sizeof(double)*(size_t)W);
+	if (rows < 1) rows = 1;
+	if (rows > (size_t)H) rows = H;
+	return (int)rows;
+}
+
+static int fetch_counters(srh_context *c, int used_dense) {
+	Counters h;
+	HIP_TRY(hipMemcpyAsync(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->stats.n_pixels = (int64_t)h.n_pixels;
+	c->stats.n_eval = (int64_t)h.n_eval;
+	c->stats.n_eval_device = (int64_t)h.n_eval_device;
+	c->stats.used_dense_path = used_dense;
+	return SRH_OK;
+}
+
+extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1) {
+	int rc;
+	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
+	if (ref == oth) return fail(SRH_E_INVALID, "ref and other view are the same slot");
+	const ViewHost &L = c->views[ref], &Rv = c->views[oth];
+	if (L.w != Rv.w || L.h != Rv.h)
+		return fail(SRH_E_INVALID, "TwoViewStereo needs equal-sized views (%dx%d vs %dx%d; twoviewstereo.cpp:116-119)",
+		            L.w, L.h, Rv.w, Rv.h);
+	HIP_TRY(hipSetDevice(c->device));
+	const int W = L.w, H = L.h;
+	if (y0 < 0) y0 = 0;
+	if (y1 <= 0 || y1 > H) y1 = H;
+	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
+	const int rows = band_rows(c, W, H, T);
+	const size_t wstride = (size_t)rows*W;
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, wstride*T))) return rc;
+	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+	for (int by = y0; by < y1; by += rows) {
+		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+		const int nr = std::min(rows, y1 - by);
+		{ Scope s(c, "weights_kernel"); launch_weights(c->stream, c->d_views, ref, W, *p, by, nr, c->wbuf, wstride); }
+		{ Scope s(c, "twoview_generic_kernel");
+		  launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt); }
+	}
+	HIP_TRY(hipGetLastError());
+	c->stats.used_dense_path = 0;
+	return SRH_OK;
+}
+
+extern "C" int srh_twoview_cross_check(srh_context *c, int left, int right, const srh_params *p) {
+	int rc;
+	if ((rc = check_slot(c, left, true)) || (rc = check_slot(c, right, true)) || (rc = check_params(p))) return rc;
+	const ViewHost &L = c->views[left], &Rv = c->views[right];
+	if (L.w != Rv.w || L.h != Rv.h) return fail(SRH_E_INVALID, "TwoViewStereo needs equal-sized views");
+	HIP_TRY(hipSetDevice(c->device));
+	// left pass completes (stream order) before the right pass reads the filtered left map
+	{ Scope s(c, "twoview_cross_check_kernel"); launch_twoview_cross_check(c->stream, c->d_views, left, right, L.w, L.h, *p); }
+	{ Scope s(c, "twoview_cross_check_kernel"); launch_twoview_cross_check(c->stream, c->d_views, right, left, L.w, L.h, *p); }
+	HIP_TRY(hipGetLastError());
+	return SRH_OK;
+}
+
+extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const srh_params *p,
+                                   double *left_out, double *right_out)
+{
+	int rc;
+	// progress steps as TwoViewStereo emits them (twoviewstereo.cpp:234,405,597,225)
+	progress(c, 1, "Computing cost volume for left image...");
+	if ((rc = srh_twoview_wta(c, left, right, p, 0, 0))) return rc;
+	if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+	srh_stats s_left;
+	if ((rc = fetch_counters(c, c->stats.used_dense_path))) return rc;
+	s_left = c->stats;
+	progress(c, 3, "Computing cost volume for right image...");
+	if ((rc = srh_twoview_wta(c, right, left, p, 0, 0))) return rc;
+	if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+	if ((rc = fetch_counters(c, c->stats.used_dense_path))) return rc;
+	c->stats.n_pixels += s_left.n_pixels;
+	c->stats.n_eval += s_left.n_eval;
+	c->stats.n_eval_device += s_left.n_eval_device;
+	progress(c, 5, "Detecting inconsistencies...");
+	if ((rc = srh_twoview_cross_check(c, left, right, p))) return rc;
+	if (left_out && (rc = srh_view_depth_download(c, left, left_out))) return rc;
+	if (right_out && (rc = srh_view_depth_download(c, right, right_out))) return rc;
+	if ((rc = srh_synchronize(c))) return rc;
+	progress(c, 8, "Finished!");
+	return SRH_OK;
+}
+
+extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t *neigh, int nneigh,
+                                        const srh_params *p, int y0, int y1, void *peaks_dev)
+{
+	int rc;
+	if ((rc = check_slot(c, view, true)) || (rc = check_params(p))) return rc;
+	if (nneigh < 0 || nneigh > 3) return fail(SRH_E_UNSUPPORTED, "nneigh %d outside [0,3] (NUM_NEIGHBOURING_VIEWS is 3)", nneigh);
+	if (nneigh > 0 && !neigh) return fail(SRH_E_INVALID, "null neighbour list");
+	if (peaks_dev && p->top_k < 1) return fail(SRH_E_INVALID, "top_k < 1");
+	for (int i = 0; i < nneigh; ++i) {
+		if ((rc = check_slot(c, neigh[i], true))) return rc;
+		if (neigh[i] == view) return fail(SRH_E_INVALID, "view %d listed as its own neighbour", view);
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &A = c->views[view];
+	const int W = A.w, H = A.h;
+	if (y0 < 0) y0 = 0;
+	if (y1 <= 0 || y1 > H) y1 = H;
+	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
+	const int rows = band_rows(c, W, H, T);
+	const size_t wstride = (size_t)rows*W;
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, wstride*T))) return rc;
+	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+	for (int by = y0; by < y1; by += rows) {
+		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+		const int nr = std::min(rows, y1 - by);
+		{ Scope s(c, "weights_kernel"); launch_weights(c->stream, c->d_views, view, W, *p, by, nr, c->wbuf, wstride); }
+		{ Scope s(c, "mvs_generic_kernel");
+		  launch_mvs_generic(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
+		                     (double *)peaks_dev, c->d_cnt); }
+	}
+	HIP_TRY(hipGetLastError());
+	c->stats.used_dense_path = 0;
+	return SRH_OK;
+}
+
+extern "C" int srh_mvs_cross_check(srh_context *c, const int32_t *slots, int nviews, int view_index,
+                                   const srh_params *p)
+{
+	int rc;
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if ((rc = check_params(p))) return rc;
+	if (!slots || nviews < 1 || nviews > SRH_MAX_VIEWS) return fail(SRH_E_INVALID, "bad view list");
+	if (view_index < 0 || view_index >= nviews) return fail(SRH_E_INVALID, "view_index %d outside [0,%d)", view_index, nviews);
+	for (int i = 0; i < nviews; ++i) if ((rc = check_slot(c, slots[i], true))) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMemcpyAsync(c->d_slots, slots, sizeof(int32_t)*nviews, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));   // `slots` is caller memory
+	const ViewHost &A = c->views[slots[view_index]];
+	{ Scope s(c, "mvs_cross_check_kernel");
+	  launch_mvs_cross_check(c->stream, c->d_views, c->d_slots, nviews, view_index, A.w, A.h, *p); }
+	HIP_TRY(hipGetLastError());
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+extern "C" int srh_get_stats(srh_context *c, srh_stats *out) {
+	if (!c || !out) return fail(SRH_E_INVALID, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = fetch_counters(c, c->stats.used_dense_path);
+	if (rc) return rc;
+	*out = c->stats;
+	return SRH_OK;
+}
+
+extern "C" int srh_profile_enable(srh_context *c, int on) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	c->profiling = on != 0;
+	return SRH_OK;
+}
+
+extern "C" int srh_profile_reset(srh_context *c) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = drain_profile(c); if (rc) return rc;
+	c->prof.clear();
+	return SRH_OK;
+}
+
+extern "C" int srh_profile_get(srh_context *c, const char *name, double *total_ms, int64_t *launches) {
+	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = drain_profile(c); if (rc) return rc;
+	auto it = c->prof.find(name);
+	if (it == c->prof.end()) return fail(SRH_E_INVALID, "kernel '%s' was never launched under profiling", name);
+	if (total_ms) *total_ms = it->second.ms;
+	if (launches) *launches = it->second.n;
+	return SRH_OK;
+}
+
+extern "C" int srh_profile_dump(srh_context *c, char *buf, size_t cap) {
+	if (!c || !buf || cap == 0) return fail(SRH_E_INVALID, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = drain_profile(c); if (rc) return rc;
+	size_t off = 0;
+	buf[0] = 0;
+	for (auto &kv : c->prof) {
+		int n = snprintf(buf + off, cap - off, "%s %.6f %lld\n", kv.first.c_str(), kv.second.ms, (long long)kv.second.n);
+		if (n < 0 || (size_t)n >= cap - off) break;
+		off += (size_t)n;
+	}
+	return SRH_OK;
+}

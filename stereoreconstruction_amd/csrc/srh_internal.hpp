@@ -1,0 +1,56 @@
+// srh_internal.hpp -- shared between the C-ABI host layer (srh_api.hip) and the
+// gfx950 kernels (srh_kernels.hip).  Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stereo_recon_hip.h"
+
+namespace srh {
+
+// One view as the kernels see it (device pointers).  HBM layout, all row-major:
+//   rgba    u32  R | G<<8 | B<<16 | A<<24           4 B/pixel  (weights: colour distances)
+//   mask    u8   1 <=> mask.pixel == WHITE           1 B/pixel  (curve candidates, reference pixels)
+//   gray    f64  toGray(pixel)                       8 B/pixel  (MVS taps: pixel(), every in-bounds pixel)
+//   gray_tv f64  toGray where the TwoView tap test   8 B/pixel  (mask WHITE && sample() valid:
+//                passes, NaN elsewhere                           x+1<w && y+1<h)
+//   depth   f64  result map                          8 B/pixel
+struct ViewDev {
+	int32_t w, h;
+	const uint32_t *rgba;
+	const uint8_t  *mask;
+	const double   *gray;
+	const double   *gray_tv;
+	double         *depth;
+	srh_camera      cam;
+};
+
+// Work counters accumulated by the kernels (device memory, zeroed per run).
+struct Counters {
+	unsigned long long n_pixels;
+	unsigned long long n_eval;
+	unsigned long long n_eval_device;
+	unsigned long long not_row_aligned;   // pixels whose curve leaves their own row
+};
+
+// Per-pixel result of the curve-extent pass (dense path planning)
+struct Extent { int32_t xmin, xmax; };
+
+// ---- launch wrappers (srh_kernels.hip / srh_dense.hip); all asynchronous on `st` ----
+void launch_prep_view(hipStream_t st, const uint32_t *rgba, const uint8_t *mask, int w, int h,
+                      double *gray, double *gray_tv);
+void launch_fill(hipStream_t st, double *p, size_t n, double v);
+void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
+                    int y0, int nrows, double *wbuf, size_t wstride);
+void launch_twoview_generic(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                            int y0, int nrows, const double *wbuf, size_t wstride, Counters *cnt);
+void launch_twoview_cross_check(hipStream_t st, const ViewDev *views, int self, int other, int w, int h,
+                                const srh_params &P);
+void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
+                        const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
+                        double *peaks, Counters *cnt);
+void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t *slots_dev, int nviews,
+                            int view_index, int w, int h, const srh_params &P);
+
+} // namespace srh

@@ -1,0 +1,376 @@
+// srh_kernels.hip -- gfx950 kernels of the dense matching-cost / support-weight /
+// winner-take-all path.  IEEE double in the reference's operation order; built
+// with -ffp-contract=off.
+//
+// General ("curve walk") kernels, one thread per reference pixel:
+//   prep_view_kernel            gray / TwoView-tap-validity planes         
+//   weights_kernel              Geodesic / Adaptive support windows        (#2, #3)
+//   twoview_generic_kernel      epipolarCurve + cost_ncc + running-min WTA (#6-#10)
+//   twoview_cross_check_kernel                                             (#11)
+//   mvs_generic_kernel          epipolarCurve + cost_ncc + top-K / best    (#13-#15)
+//   mvs_cross_check_kernel                                                 (#17)
+// The dense row-aligned TwoView kernels live in srh_dense.hip.
+#include "srh_internal.hpp"
+#include "srh_geom.hpp"
+#include "srh_walk.hpp"
+
+namespace srh {
+
+static inline int grid_for(size_t n, int block, int cap) {
+	size_t b = (n + block - 1)/block;
+	if (b > (size_t)cap) b = cap;
+	if (b < 1) b = 1;
+	return (int)b;
+}
+
+// ------------------------------------------------------------------ prep
+// util/vectorimage.hpp:60-62 toGray; vectorimage.cpp:129-155 sample() validity at
+// integer coordinates (x+1 < w && y+1 < h), where sample() returns pixel() exactly.
+__global__ void prep_view_kernel(const uint32_t *__restrict__ rgba, const uint8_t *__restrict__ mask,
+                                 int w, int h, double *__restrict__ gray, double *__restrict__ gray_tv)
+{
+	const size_t n = (size_t)w*h;
+	for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x) {
+		const uint32_t px = rgba[i];
+		const double r = (double)(px & 255u), g = (double)((px >> 8) & 255u), b = (double)((px >> 16) & 255u);
+		const double gr = (0.11*r + 0.59*g + 0.3*b);
+		const int x = (int)(i % (size_t)w), y = (int)(i / (size_t)w);
+		gray[i] = gr;
+		const bool ok = mask[i] == 1 && x + 1 < w && y + 1 < h;
+		gray_tv[i] = ok ? gr : __builtin_nan("");
+	}
+}
+
+__global__ void fill_kernel(double *__restrict__ p, size_t n, double v) {
+	for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x)
+		p[i] = v;
+}
+
+void launch_prep_view(hipStream_t st, const uint32_t *rgba, const uint8_t *mask, int w, int h,
+                      double *gray, double *gray_tv)
+{
+	hipLaunchKernelGGL(prep_view_kernel, dim3(grid_for((size_t)w*h, 256, 2048)), dim3(256), 0, st,
+	                   rgba, mask, w, h, gray, gray_tv);
+}
+
+void launch_fill(hipStream_t st, double *p, size_t n, double v) {
+	hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, n, v);
+}
+
+// ------------------------------------------------------------------ weights
+// colour distance between two packed pixels: sqrt(dr*dr + dg*dg + db*db) in double
+// (geodesicweight.cpp:89-90, adaptiveweight.cpp:66-68); the squares are small
+// integers, so every partial sum is exact.
+__device__ __forceinline__ double color_dist(uint32_t a, uint32_t b) {
+	const double dr = (double)((int)(a & 255u) - (int)(b & 255u));
+	const double dg = (double)((int)((a >> 8) & 255u) - (int)((b >> 8) & 255u));
+	const double db = (double)((int)((a >> 16) & 255u) - (int)((b >> 16) & 255u));
+	return sqrt(dr*dr + dg*dg + db*db);
+}
+
+// Any-radius version: the window lives in the global weight buffer
+// (wb[tap*wstride + q], coalesced across the threads of a wave).
+__global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_params P,
+                               int y0, int nrows, double *__restrict__ wbuf, size_t wstride)
+{
+	const ViewDev &V = views[ref];
+	const int W = V.w, H = V.h;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (q >= (size_t)nrows*W) return;
+	const int cx = (int)(q % W), cy = y0 + (int)(q / W);
+	if (V.mask[(size_t)cy*W + cx] != 1) return;                 // masked pixels never reach init_weights
+	double *wb = wbuf + q;
+	const int R = P.window_radius, WS = 2*R + 1;
+
+	if (P.weight_kind == SRH_WEIGHT_GEODESIC) {
+		// geodesicweight.cpp:59-131
+		for (int i = 0; i < WS*WS; ++i) wb[(size_t)i*wstride] = P.geodesic_init;
+		wb[(size_t)(R*WS + R)*wstride] = 0.0;
+		for (int iter = 0; iter < P.geodesic_iters; ++iter) {
+			for (int pass = 0; pass < 2; ++pass) {
+				// K1 = (-1,-1)(0,-1)(1,-1)(-1,0) forward; K2 = (-1,1)(0,1)(1,1)(1,0) backward
+				const int sy = pass == 0 ? -1 : 1;
+				for (int yi = 0; yi < WS; ++yi) {
+					const int y = pass == 0 ? (-R + yi) : (R - yi);
+					const int py = cy + y;
+					for (int xi = 0; xi < WS; ++xi) {
+						const int x = pass == 0 ? (-R + xi) : (R - xi);
+						const int px = cx + x;
+						if (px < 0 || py < 0 || px >= W || py >= H) continue;
+						const uint32_t c1 = V.rgba[(size_t)py*W + px];
+						const size_t idx = (size_t)((y + R)*WS + (x + R));
+						double weight = wb[idx*wstride];
+						for (int k = 0; k < 4; ++k) {
+							const int dx = (k == 3) ? (pass == 0 ? -1 : 1) : (k - 1);
+							const int dy = (k == 3) ? 0 : sy;
+							if (x + dx > R || y + dy > R || x + dx < -R || y + dy < -R) continue;
+							const int qx = px + dx, qy = py + dy;
+							if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
+							const double diff = color_dist(V.rgba[(size_t)qy*W + qx], c1);
+							const double cost = wb[(size_t)((y + dy + R)*WS + (x + dx + R))*wstride];
+							const double cand = cost + diff;
+							if (cand < weight) weight = cand;
+						}
+						wb[idx*wstride] = weight;
+					}
+				}
+			}
+		}
+		for (int i = 0; i < WS*WS; ++i) wb[(size_t)i*wstride] = exp(-wb[(size_t)i*wstride] / P.geodesic_sigma);
+	} else {
+		// adaptiveweight.cpp:33-79 (the centre pixel is always in bounds here)
+		const uint32_t crgb = V.rgba[(size_t)cy*W + cx];
+		for (int row = -R; row <= R; ++row) {
+			const double dwr = exp(-abs(row) / (1.0*R));
+			for (int col = -R; col <= R; ++col) {
+				double weight = 0.0;
+				const int px = cx + col, py = cy + row;
+				if (!(px < 0 || py < 0 || px >= W || py >= H)) {
+					const double diff = color_dist(V.rgba[(size_t)py*W + px], crgb);
+					const double w1 = dwr*exp(-abs(col) / (1.0*R));
+					const double w2 = exp(-diff / P.adaptive_color_sigma);
+					weight = w1*w2;
+					if (isnan_d(weight)) weight = 0.0;
+				}
+				wb[(size_t)((row + R)*WS + (col + R))*wstride] = weight;
+			}
+		}
+	}
+}
+
+void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
+                    int y0, int nrows, double *wbuf, size_t wstride)
+{
+	const size_t n = (size_t)nrows*width;
+	hipLaunchKernelGGL(weights_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
+	                   views, ref, P, y0, nrows, wbuf, wstride);
+}
+
+// ------------------------------------------------------------------ TwoView, general geometry
+struct TwoViewDirectVisitor {
+	const ViewDev &L, &Rv;
+	const double *wq;
+	size_t wstride;
+	const srh_params &P;
+	int x, y;
+	double minCost, secondBest;
+	int wx, wy;
+	unsigned n;
+	__device__ __forceinline__ void operator()(int cx, int cy) {
+		const double cost = tv_cost(L, Rv, wq, wstride, P, x, y, cx, cy);
+		++n;
+		if (cost + P.wta_margin < minCost) {                   // twoviewstereo.cpp:293-301
+			secondBest = minCost;
+			minCost = cost;
+			wx = cx; wy = cy;
+		}
+	}
+};
+
+__global__ void twoview_generic_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                                       int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
+                                       Counters *__restrict__ cnt)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	unsigned n_eval = 0, n_pix = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), y = y0 + (int)(q / W);
+		const size_t pv = (size_t)y*W + x;
+		double depth = __builtin_nan("");                       // twoviewstereo.cpp:269
+		if (L.mask[pv] == 1) {
+			n_pix = 1;
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			TwoViewDirectVisitor vis = { L, Rv, wbuf + q, wstride, P, x, y,
+			                             __builtin_inf(), __builtin_inf(), -1, -1, 0 };
+			walk_curve<false>(ray, L.cam, Rv, P, vis);
+			n_eval = vis.n;
+			if (vis.wx >= 0)                                       // at least one candidate was scanned
+				depth = candidate_depth(L.cam, Rv.cam, P, ray, vis.wx, vis.wy);
+			if (vis.minCost > P.second_best_factor*vis.secondBest)   // twoviewstereo.cpp:304-305
+				depth = __builtin_inf();
+		}
+		L.depth[pv] = depth;
+	}
+	block_count_add(&cnt->n_eval, n_eval);
+	block_count_add(&cnt->n_eval_device, n_eval);
+	block_count_add(&cnt->n_pixels, n_pix);
+}
+
+void launch_twoview_generic(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                            int y0, int nrows, const double *wbuf, size_t wstride, Counters *cnt)
+{
+	const size_t n = (size_t)nrows*width;
+	hipLaunchKernelGGL(twoview_generic_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, cnt);
+}
+
+// one direction of TwoViewStereo::crossCheck (twoviewstereo.cpp:604-636 / :638-670)
+__global__ void twoview_cross_check_kernel(const ViewDev *__restrict__ views, int self, int other, srh_params P)
+{
+	const ViewDev &A = views[self];
+	const ViewDev &B = views[other];
+	const int W = A.w, H = A.h;
+	const size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= (size_t)W*H) return;
+	const int x = (int)(i % W), y = (int)(i / W);
+	double depth = A.depth[i];
+	if (!isfinite_d(depth)) return;
+	const double s = P.image_scale;
+	const double inf = __builtin_inf();
+	const Ray ray = cam_unproject(A.cam, (x + 0.5) / s, (y + 0.5) / s);
+	Vec3 p1 = load3(A.cam.C);
+	if (point_from_depth(ray, load3(A.cam.pdir), depth, p1)) {
+		Vec3 q = p1;
+		if (cam_project(B.cam, q)) {
+			const double x2 = q.x*s, y2 = q.y*s;
+			// CONTAINS(resultRight, x2, y2) and PV(x2, y2, resultRight), twoviewstereo.cpp:621-622
+			if (x2 >= 0 && y2 >= 0 && x2 < B.w && y2 < B.h) {
+				const double odepth = B.depth[(size_t)((int)y2)*B.w + (int)x2];
+				if (isfinite_d(odepth)) {
+					const Ray ray2 = cam_unproject(B.cam, (x2 + 0.5) / s, (y2 + 0.5) / s);
+					Vec3 p2 = load3(B.cam.C);
+					if (point_from_depth(ray2, load3(B.cam.pdir), odepth, p2)) {
+						const double nrm = norm(p1 - p2);
+						if (!isfinite_d(nrm) || nrm > P.inconsistency_thresh) depth = inf;
+					} else depth = inf;
+				} else depth = inf;
+			} else depth = inf;
+		} else depth = inf;
+	}
+	A.depth[i] = depth;
+}
+
+void launch_twoview_cross_check(hipStream_t st, const ViewDev *views, int self, int other, int w, int h,
+                                const srh_params &P)
+{
+	const size_t n = (size_t)w*h;
+	hipLaunchKernelGGL(twoview_cross_check_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
+	                   views, self, other, P);
+}
+
+// ------------------------------------------------------------------ MVS, general geometry
+struct MvsVisitor {
+	const ViewDev &A, &B;
+	const double *wq;
+	size_t wstride;
+	const srh_params &P;
+	const Ray &ray;
+	int x, y;
+	double bestCost, bestDepth;
+	double *peaks;          // top_k (cost, depth) pairs, ascending; may be null
+	unsigned n;
+	__device__ __forceinline__ void operator()(int cx, int cy) {
+		const double cost = mvs_cost(A, B, wq, wstride, P, x, y, cx, cy);
+		++n;
+		if (cost > P.peak_threshold) {                          // multiviewstereo.cpp:589-594
+			const double z = candidate_depth(A.cam, B.cam, P, ray, cx, cy);
+			// std::sort of (cost, depth) pairs, keep the last K, result = back()
+			if (cost > bestCost || (cost == bestCost && z > bestDepth)) { bestCost = cost; bestDepth = z; }
+			if (peaks) {
+				const int K = P.top_k;
+				// insert into the ascending top-K list if it beats the smallest entry
+				if (cost > peaks[0] || (cost == peaks[0] && z > peaks[1])) {
+					int k = 0;
+					while (k + 1 < K && (peaks[2*(k+1)] < cost || (peaks[2*(k+1)] == cost && peaks[2*(k+1)+1] < z))) {
+						peaks[2*k] = peaks[2*(k+1)]; peaks[2*k+1] = peaks[2*(k+1)+1];
+						++k;
+					}
+					peaks[2*k] = cost; peaks[2*k+1] = z;
+				}
+			}
+		}
+	}
+};
+
+__global__ void mvs_generic_kernel(const ViewDev *__restrict__ views, int ref,
+                                   int n0, int n1, int n2, int nneigh, srh_params P,
+                                   int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
+                                   double *__restrict__ peaks, Counters *__restrict__ cnt)
+{
+	const ViewDev &A = views[ref];
+	const int W = A.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	unsigned n_eval = 0, n_pix = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), y = y0 + (int)(q / W);
+		const size_t pv = (size_t)y*W + x;
+		double depth = __builtin_inf();                         // multiviewstereo.cpp:559
+		double *pk = peaks ? peaks + pv*(size_t)P.top_k*2 : nullptr;
+		if (pk) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k+1] = -1.0; }   // :562
+		if (A.mask[pv] == 1) {
+			n_pix = 1;
+			const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			MvsVisitor vis = { A, A, wbuf + q, wstride, P, ray, x, y, 0.0, -1.0, pk, 0 };
+			for (int ni = 0; ni < nneigh; ++ni) {
+				const int v2 = ni == 0 ? n0 : (ni == 1 ? n1 : n2);
+				const ViewDev &B = views[v2];
+				MvsVisitor vb = { A, B, vis.wq, wstride, P, ray, x, y, vis.bestCost, vis.bestDepth, pk, vis.n };
+				walk_curve<true>(ray, A.cam, B, P, vb);
+				vis.bestCost = vb.bestCost; vis.bestDepth = vb.bestDepth; vis.n = vb.n;
+			}
+			n_eval = vis.n;
+			depth = vis.bestDepth;                              // peakPairs[y][x].back().second, :658
+		}
+		A.depth[pv] = depth;
+	}
+	block_count_add(&cnt->n_eval, n_eval);
+	block_count_add(&cnt->n_eval_device, n_eval);
+	block_count_add(&cnt->n_pixels, n_pix);
+}
+
+void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
+                        const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
+                        double *peaks, Counters *cnt)
+{
+	const size_t n = (size_t)nrows*width;
+	const int n0 = nneigh > 0 ? neigh[0] : 0, n1 = nneigh > 1 ? neigh[1] : 0, n2 = nneigh > 2 ? neigh[2] : 0;
+	hipLaunchKernelGGL(mvs_generic_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
+	                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, cnt);
+}
+
+// MultiViewStereo::crossCheck(view) (multiviewstereo.cpp:666-729)
+__global__ void mvs_cross_check_kernel(const ViewDev *__restrict__ views, const int32_t *__restrict__ slots,
+                                       int nviews, int view_index, srh_params P)
+{
+	const ViewDev &A = views[slots[view_index]];
+	const int W = A.w, H = A.h;
+	const size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= (size_t)W*H) return;
+	const int x = (int)(i % W), y = (int)(i / W);
+	const double depth = A.depth[i];
+	if (!isfinite_d(depth)) return;
+	const double s = P.image_scale;
+	const Ray ray = cam_unproject(A.cam, (x + 0.5) / s, (y + 0.5) / s);
+	Vec3 p1 = load3(A.cam.C);
+	if (!point_from_depth(ray, load3(A.cam.pdir), depth, p1)) return;   // e.g. depth -1: left unchanged
+	bool found = false;
+	for (int v2 = 0; v2 < nviews && !found; ++v2) {
+		if (v2 == view_index) continue;
+		const ViewDev &B = views[slots[v2]];
+		Vec3 q = p1;
+		if (!cam_project(B.cam, q)) continue;
+		const double x2 = q.x*s, y2 = q.y*s;
+		if (!(x2 >= 0 && y2 >= 0 && x2 < B.w && y2 < B.h)) continue;
+		const double odepth = B.depth[(size_t)((int)y2)*B.w + (int)x2];
+		if (!isfinite_d(odepth)) continue;
+		const Ray ray2 = cam_unproject(B.cam, (x2 + 0.5) / s, (y2 + 0.5) / s);
+		Vec3 p2 = load3(B.cam.C);
+		if (!point_from_depth(ray2, load3(B.cam.pdir), odepth, p2)) continue;
+		const double nrm = norm(p1 - p2);
+		if (isfinite_d(nrm) && nrm < P.cross_check_threshold) found = true;
+	}
+	if (!found) A.depth[i] = __builtin_nan("");
+}
+
+void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t *slots_dev, int nviews,
+                            int view_index, int w, int h, const srh_params &P)
+{
+	const size_t n = (size_t)w*h;
+	hipLaunchKernelGGL(mvs_cross_check_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
+	                   views, slots_dev, nviews, view_index, P);
+}
+
+} // namespace srh
