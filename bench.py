@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: M disparity-hypotheses/s (W x H x D) of
+the TwoView cost-volume / support-weight / WTA path on synthetic 1920x1080x256 pairs.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small]
+
+A "step" is one pass of the hot path over one stereo pair per GPU: WTA left->right,
+WTA right->left, cross-check, and the device-side hand-over of the two depth maps
+(N>1: RCCL gather to rank 0).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (contract in the task description).  N>1 is launched
+by torch.distributed.run, one rank per GPU; pairs are sharded (weak scaling), there
+is no data-path collective other than the final gather.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+from stereoreconstruction_amd import capi, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (datasheet)
+
+WORKLOADS = {
+    # name: (W, H, D, weight_kind, seed, description)
+    "c3": (1920, 1080, 256, capi.WEIGHT_GEODESIC, 0x5EED0003,
+           "C3: synthetic rectified 1920x1080 pair, 256 depth levels, GeodesicWeight r=5"),
+    "c2": (640, 480, 64, capi.WEIGHT_ADAPTIVE, 0x5EED0002,
+           "C2: synthetic rectified 640x480 pair, 64 depth levels, AdaptiveWeight r=5"),
+    "small": (320, 240, 64, capi.WEIGHT_GEODESIC, 0x5EED0009,
+              "dev: synthetic rectified 320x240 pair, 64 depth levels, GeodesicWeight r=5"),
+}
+
+
+def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows):
+    """Time the oracle (CPU restatement, one thread) on a centre row band of the same pair."""
+    import oracle_ffi as O
+    (Kl, Rl, tl), (Kr, Rr, tr) = cam_triples
+    cl, cr = O.camera_set(Kl, Rl, tl), O.camera_set(Kr, Rr, tr)
+    p = O.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=weight_kind)
+    li, ri = O.OImage(L, ml), O.OImage(R, mr)
+    h, w = L.shape[:2]
+    y0 = h // 2 - rows // 2
+    t0 = time.perf_counter()
+    depth, diag = O.twoview_wta(li, ri, cl, cr, p, y0, y0 + rows, want_diag=True)
+    dt = time.perf_counter() - t0
+    return dict(value=rows * w * D / dt / 1e6, unit="Mhyp/s", cores=1, kind="port",
+                sample="oracle/sr_oracle.c sro_twoview_wta, left->right, %d full-width centre rows x %d levels "
+                       "(%d cost evaluations) in %.2f s on 1 host thread" % (rows, D, diag["n_eval"], dt)), depth, y0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-rows", type=int, default=2, help="rows of the CPU-baseline band (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, D, wkind, seed, desc = WORKLOADS[args.workload]
+    # weak scaling: every rank owns one pair (its own seed)
+    L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + 0x10000 * rank)
+    cams3 = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    (Kl, Rl, tl), (Kr, Rr, tr) = cams3
+    cl, cr = capi.camera_from_krt(Kl, Rl, tl), capi.camera_from_krt(Kr, Rr, tr)
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
+
+    ctx = capi.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.upload_view(0, L, ml, cl)
+    ctx.upload_view(1, R, mr, cr)
+    out = torch.empty((2, H, W), dtype=torch.float64, device=dev)
+    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        ctx.twoview_wta(0, 1, p)
+        ctx.twoview_wta(1, 0, p)
+        ctx.twoview_cross_check(0, 1, p)
+        ctx.copy_depth_to_device(0, out[0].data_ptr())
+        ctx.copy_depth_to_device(1, out[1].data_ptr())
+        if world > 1:
+            dist.gather(out, gathered, dst=0)      # RCCL over xGMI: per-view depth maps to rank 0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    prof = ctx.profile()
+    stats = ctx.stats()
+    hyp_per_step_per_gpu = 2 * W * H * D
+    value = world * hyp_per_step_per_gpu * args.steps / dt / 1e6
+
+    result = None
+    if rank == 0:
+        # dominant kernel by accumulated HIP-event time on the launch stream
+        name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+        # algorithmic HBM bytes: 14 B per reference pixel per direction
+        # (u8 RGB+mask of the reference view, u8 gray+mask of the other view, f64 depth out);
+        # one step covers 2*W*H reference pixels, spread over `launches/steps` launches.
+        alg_bytes_total = 14.0 * 2 * W * H * args.steps
+        bytes_per_launch = alg_bytes_total / launches
+        avg_ms = ms / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        T = (2 * p.window_radius + 1) ** 2
+        flops_per_step = hyp_per_step_per_gpu * (15.0 * T + 8)
+        valu_achieved = flops_per_step * args.steps / (ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(value, 3), "unit": "Mhyp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
+                       "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
+                       "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
+                       "pairs_per_gpu": 1, "parallelism": "pairs sharded, RCCL gather" if world > 1 else "single GPU",
+                       "dense_path": bool(stats["used_dense_path"]),
+                       "n_eval_reference_last_pass": stats["n_eval"],
+                       "n_eval_device_last_pass": stats["n_eval_device"]},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                         "alg_bytes_per_launch": round(bytes_per_launch),
+                         "note": "path is FP64-VALU bound, not HBM bound (SURVEY 8(d)); see valu_fp64",
+                         "valu_fp64": {"achieved": round(valu_achieved, 3), "peak": FP64_VALU_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(valu_achieved / FP64_VALU_PEAK_TFLOPS, 5),
+                                       "flops_per_hyp": 15 * T + 8}},
+            "kernels_ms": {k: [round(v[0], 3), v[1]] for k, v in sorted(prof.items())},
+        }
+        if world == 1 and args.cpu_rows > 0:
+            base, cpu_depth, y0 = cpu_baseline(L, R, ml, mr, cams3, zmin, zmax, D, wkind, args.cpu_rows)
+            # the timed CPU band doubles as a full-size parity spot check of the WTA pass
+            ctx.twoview_wta(0, 1, p, y0, y0 + args.cpu_rows)
+            got = ctx.download_depth(0)[y0:y0 + args.cpu_rows]
+            want = cpu_depth[y0:y0 + args.cpu_rows]
+            same_cls = (np.isnan(got) == np.isnan(want)) & (np.isinf(got) == np.isinf(want))
+            fin = np.isfinite(got) & np.isfinite(want)
+            close = np.abs(got[fin] - want[fin]) <= 1e-9 * np.maximum(1.0, np.abs(want[fin]))
+            base["parity_band"] = {"pixels": int(got.size), "class_mismatch": int((~same_cls).sum()),
+                                   "value_mismatch": int((~close).sum())}
+            result["cpu_baseline"] = base
+        else:
+            result["cpu_baseline"] = None
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

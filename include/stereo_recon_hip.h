@@ -124,6 +124,9 @@ void srh_destroy(srh_context *ctx);
 int  srh_set_stream(srh_context *ctx, void *hip_stream);
 int  srh_set_hooks(srh_context *ctx, const volatile int *cancel, srh_progress_fn progress, void *user);
 int  srh_synchronize(srh_context *ctx);
+/* Tuning / test switches: "force_generic" (0/1: never take the dense row-aligned
+ * kernels), "band_budget_mb" (device scratch per row band). */
+int  srh_set_option(srh_context *ctx, const char *name, long value);
 
 /* ---- views: what VectorImage::fromQImage + the mask test hold (util/vectorimage.cpp:48-64) ----
  * rgba: w*h*4 bytes R,G,B,A of the ALREADY SCALED image; mask: w*h bytes,
@@ -135,6 +138,9 @@ int  srh_view_size(srh_context *ctx, int slot, int *w, int *h);
 int  srh_view_depth_download(srh_context *ctx, int slot, double *host_out);
 int  srh_view_depth_upload(srh_context *ctx, int slot, const double *host_in);
 int  srh_view_depth_device_ptr(srh_context *ctx, int slot, void **dev_ptr);
+/* Asynchronous device-to-device copy of the slot's depth map into caller-owned
+ * DEVICE memory (e.g. a tensor that RCCL then gathers); ordered on the context stream. */
+int  srh_view_depth_copy_to_device(srh_context *ctx, int slot, void *dst_dev);
 
 /* ---- TwoViewStereo ----
  * One pass of computeCostVolumes (twoviewstereo.cpp:260-333 with ref=left,

@@ -64,9 +64,9 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 EXPORTS = [
     "srh_abi_version", "srh_last_error", "srh_device_count",
     "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_mvs_neighbours",
-    "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize",
+    "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
-    "srh_view_depth_device_ptr",
+    "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
@@ -108,11 +108,13 @@ def lib():
     L.srh_set_stream.argtypes = [vp, vp]
     L.srh_set_hooks.argtypes = [vp, C.POINTER(C.c_int), PROGRESS_FN, vp]
     L.srh_synchronize.argtypes = [vp]
+    L.srh_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.srh_view_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_uint8_p, c_uint8_p, C.POINTER(Camera)]
     L.srh_view_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.srh_view_depth_download.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.srh_view_depth_copy_to_device.argtypes = [vp, C.c_int, vp]
     L.srh_twoview_wta.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.srh_twoview_cross_check.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params)]
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
@@ -222,6 +224,9 @@ class Context:
         self._keep = [cb, cancel_flag]
         _check(lib().srh_set_hooks(self._h, C.byref(cancel_flag) if cancel_flag is not None else None, cb, None))
 
+    def set_option(self, name, value):
+        _check(lib().srh_set_option(self._h, name.encode(), int(value)))
+
     def synchronize(self):
         _check(lib().srh_synchronize(self._h))
 
@@ -261,6 +266,9 @@ class Context:
         p = C.c_void_p()
         _check(lib().srh_view_depth_device_ptr(self._h, slot, C.byref(p)))
         return p.value
+
+    def copy_depth_to_device(self, slot, dst_dev_ptr):
+        _check(lib().srh_view_depth_copy_to_device(self._h, slot, C.c_void_p(dst_dev_ptr)))
 
     # -- TwoViewStereo
     def twoview_wta(self, ref_slot, oth_slot, p, y0=0, y1=0):

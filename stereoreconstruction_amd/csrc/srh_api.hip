@@ -41,6 +41,7 @@ struct ViewHost {
 	uint32_t *rgba = nullptr;
 	uint8_t  *mask = nullptr;
 	double   *gray = nullptr, *gray_tv = nullptr, *depth = nullptr;
+	double   *edges = nullptr;     // 4 planes of neighbour colour distances (geodesic windows)
 	srh_camera cam;
 };
 
@@ -55,10 +56,11 @@ struct srh_context {
 	ViewDev *d_views = nullptr;
 	int32_t *d_slots = nullptr;
 	Counters *d_cnt = nullptr;
+	int *d_span = nullptr;
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
 	Extent *ext = nullptr;    size_t ext_cap = 0;       // pixels
-	size_t wbuf_budget = (size_t)128 << 20;             // bytes per band of support windows
+	size_t wbuf_budget = (size_t)192 << 20;             // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
 	void *user = nullptr;
@@ -282,7 +284,8 @@ extern "C" int srh_create(int device, srh_context **out) {
 	c->stream = c->own_stream;
 	if (hipMalloc((void **)&c->d_views, sizeof(ViewDev)*SRH_MAX_VIEWS) != hipSuccess ||
 	    hipMalloc((void **)&c->d_slots, sizeof(int32_t)*SRH_MAX_VIEWS) != hipSuccess ||
-	    hipMalloc((void **)&c->d_cnt, sizeof(Counters)) != hipSuccess) {
+	    hipMalloc((void **)&c->d_cnt, sizeof(Counters)) != hipSuccess ||
+	    hipMalloc((void **)&c->d_span, sizeof(int)) != hipSuccess) {
 		srh_destroy(c);
 		return fail(SRH_E_DEVICE, "hipMalloc of context tables failed");
 	}
@@ -298,6 +301,7 @@ static void free_view(ViewHost &v) {
 	if (v.gray) hipFree(v.gray);
 	if (v.gray_tv) hipFree(v.gray_tv);
 	if (v.depth) hipFree(v.depth);
+	if (v.edges) hipFree(v.edges);
 	v = ViewHost();
 }
 
@@ -310,6 +314,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->d_views) hipFree(c->d_views);
 	if (c->d_slots) hipFree(c->d_slots);
 	if (c->d_cnt) hipFree(c->d_cnt);
+	if (c->d_span) hipFree(c->d_span);
 	if (c->wbuf) hipFree(c->wbuf);
 	if (c->cost) hipFree(c->cost);
 	if (c->ext) hipFree(c->ext);
@@ -327,6 +332,17 @@ extern "C" int srh_set_hooks(srh_context *c, const volatile int *cancel, srh_pro
 	if (!c) return fail(SRH_E_INVALID, "null context");
 	c->cancel = cancel; c->progress = progress_fn; c->user = user;
 	return SRH_OK;
+}
+
+extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
+	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
+	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; return SRH_OK; }
+	if (!strcmp(name, "band_budget_mb")) {
+		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
+		c->wbuf_budget = (size_t)value << 20;
+		return SRH_OK;
+	}
+	return fail(SRH_E_INVALID, "unknown option '%s'", name);
 }
 
 extern "C" int srh_synchronize(srh_context *c) {
@@ -354,6 +370,7 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 		HIP_TRY(hipMalloc((void **)&v.gray, n*sizeof(double)));
 		HIP_TRY(hipMalloc((void **)&v.gray_tv, n*sizeof(double)));
 		HIP_TRY(hipMalloc((void **)&v.depth, n*sizeof(double)));
+		HIP_TRY(hipMalloc((void **)&v.edges, 4*n*sizeof(double)));
 		v.w = w; v.h = h; v.present = true;
 	}
 	v.cam = *cam;
@@ -361,6 +378,7 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
 	else      HIP_TRY(hipMemsetAsync(v.mask, 1, n, c->stream));
 	{ Scope s(c, "prep_view_kernel"); launch_prep_view(c->stream, v.rgba, v.mask, w, h, v.gray, v.gray_tv); }
+	{ Scope s(c, "edge_planes_kernel"); launch_edge_planes(c->stream, v.rgba, w, h, v.edges); }
 	launch_fill(c->stream, v.depth, n, __builtin_nan(""));
 	ViewDev d;
 	d.w = w; d.h = h; d.rgba = v.rgba; d.mask = v.mask; d.gray = v.gray; d.gray_tv = v.gray_tv; d.depth = v.depth;
@@ -405,6 +423,15 @@ extern "C" int srh_view_depth_device_ptr(srh_context *c, int slot, void **dev_pt
 	return SRH_OK;
 }
 
+extern "C" int srh_view_depth_copy_to_device(srh_context *c, int slot, void *dst_dev) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!dst_dev) return fail(SRH_E_INVALID, "null destination");
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	HIP_TRY(hipMemcpyAsync(dst_dev, v.depth, (size_t)v.w*v.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+	return SRH_OK;
+}
+
 // ------------------------------------------------------------------ runs
 static int band_rows(srh_context *c, int W, int H, int T) {
 	size_t rows = c->wbuf_budget / ((size_t)T*sizeof(double)*(size_t)W);
@@ -424,6 +451,16 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	return SRH_OK;
 }
 
+// support windows of rows [by, by+nr) of view `ref` into c->wbuf
+static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int by, int nr, size_t wstride) {
+	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic) {
+		Scope s(c, "geodesic_reg_kernel");
+		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride)) return;
+	}
+	Scope s(c, "weights_kernel");
+	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride);
+}
+
 extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1) {
 	int rc;
 	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
@@ -436,20 +473,57 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 	const int W = L.w, H = L.h;
 	if (y0 < 0) y0 = 0;
 	if (y1 <= 0 || y1 > H) y1 = H;
-	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
-	const int rows = band_rows(c, W, H, T);
-	const size_t wstride = (size_t)rows*W;
-	if ((rc = ensure(c->wbuf, c->wbuf_cap, wstride*T))) return rc;
+	if (y1 <= y0) return SRH_OK;
+	const int R = p->window_radius;
+	const int T = (2*R + 1)*(2*R + 1);
 	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
-	for (int by = y0; by < y1; by += rows) {
+
+	// ---- plan: is every epipolar curve confined to its own image row?
+	bool dense = !c->force_generic && (R == 5 || R == 2);
+	int cstride = 0;
+	if (dense) {
+		const size_t npix = (size_t)(y1 - y0)*W;
+		if ((rc = ensure(c->ext, c->ext_cap, npix))) return rc;
+		HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
+		{ Scope s(c, "twoview_extent_kernel");
+		  launch_twoview_extent(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->ext, c->d_cnt, c->d_span); }
+		Counters hc; int span = 0;
+		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemcpyAsync(&span, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		cstride = (span + 7) & ~7;
+		if (hc.not_row_aligned != 0 || span <= 0 || span > 8192) {
+			dense = false;
+			HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+		}
+	}
+
+	size_t per_pixel = (size_t)T*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
+	size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
+	if (rows < 1) rows = 1;
+	if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
+	const size_t wstride = rows*W;
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, wstride*T))) return rc;
+	if (dense && (rc = ensure(c->cost, c->cost_cap, wstride*(size_t)cstride))) return rc;
+
+	for (int by = y0; by < y1; by += (int)rows) {
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
-		const int nr = std::min(rows, y1 - by);
-		{ Scope s(c, "weights_kernel"); launch_weights(c->stream, c->d_views, ref, W, *p, by, nr, c->wbuf, wstride); }
-		{ Scope s(c, "twoview_generic_kernel");
-		  launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt); }
+		const int nr = std::min((int)rows, y1 - by);
+		run_weights(c, ref, W, *p, by, nr, wstride);
+		if (dense) {
+			const Extent *ext = c->ext + (size_t)(by - y0)*W;
+			{ Scope s(c, "twoview_dense_cost_kernel");
+			  launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
+			                            ext, c->cost, cstride, c->d_cnt); }
+			{ Scope s(c, "twoview_scan_kernel");
+			  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, ext, c->cost, cstride); }
+		} else {
+			Scope s(c, "twoview_generic_kernel");
+			launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt);
+		}
 	}
 	HIP_TRY(hipGetLastError());
-	c->stats.used_dense_path = 0;
+	c->stats.used_dense_path = dense ? 1 : 0;
 	return SRH_OK;
 }
 
@@ -518,7 +592,7 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	for (int by = y0; by < y1; by += rows) {
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 		const int nr = std::min(rows, y1 - by);
-		{ Scope s(c, "weights_kernel"); launch_weights(c->stream, c->d_views, view, W, *p, by, nr, c->wbuf, wstride); }
+		run_weights(c, view, W, *p, by, nr, wstride);
 		{ Scope s(c, "mvs_generic_kernel");
 		  launch_mvs_generic(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
 		                     (double *)peaks_dev, c->d_cnt); }

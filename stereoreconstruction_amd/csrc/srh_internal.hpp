@@ -53,4 +53,16 @@ void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int
 void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t *slots_dev, int nviews,
                             int view_index, int w, int h, const srh_params &P);
 
+// Dense (row-aligned) TwoView path, srh_dense.hip
+void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
+bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
+                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride);
+void launch_twoview_extent(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                           int y0, int nrows, Extent *ext, Counters *cnt, int *max_span);
+bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                               int y0, int nrows, const double *wbuf, size_t wstride,
+                               const Extent *ext, double *cost, int cstride, Counters *cnt);
+void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                         int y0, int nrows, const Extent *ext, const double *cost, int cstride);
+
 } // namespace srh

@@ -127,3 +127,53 @@ def test_mvs_initial_estimate_and_cross_check(hip_ctx, name):
     for v in range(nv):
         ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(v), ref[v], RTOL)
         assert ok, "view %d cross-check: %s" % (v, msg)
+
+
+def _same_bits(a, b):
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("name,over", [
+    ("geodesic_rect", dict(w=100, h=37, D=24)),                 # width not a multiple of the 32-pixel tile
+    ("adaptive_rect", dict(w=75, h=20, D=40)),
+    ("geodesic_masks", dict(w=90, h=33, D=20)),                 # masked taps: general form inside the dense kernel
+    ("geodesic_r2", dict(w=70, h=30, D=18)),
+])
+def test_dense_path_matches_oracle_and_generic(hip_ctx, name, over):
+    """Row-aligned geometry takes the LDS-tiled dense kernels; they must reproduce the
+    oracle and be bit-identical to the general curve-walk kernels."""
+    case = cases.get_twoview(name, **over)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    for ref, oth in ((0, 1), (1, 0)):
+        want, diag = O.twoview_wta(imgs[ref], imgs[oth], ocams[ref], ocams[oth], op, want_diag=True)
+        hip_ctx.set_option("force_generic", 0)
+        hip_ctx.set_option("band_budget_mb", 1)                 # several row bands
+        hip_ctx.twoview_wta(ref, oth, p)
+        dense = hip_ctx.download_depth(ref)
+        st = hip_ctx.stats()
+        assert st["used_dense_path"], "rectified case did not take the dense path"
+        assert st["n_eval"] == diag["n_eval"]                   # candidates the reference evaluates
+        assert st["n_eval_device"] <= st["n_eval"]              # joint duplicates are evaluated once
+        hip_ctx.set_option("force_generic", 1)
+        hip_ctx.twoview_wta(ref, oth, p)
+        generic = hip_ctx.download_depth(ref)
+        hip_ctx.set_option("force_generic", 0)
+        hip_ctx.set_option("band_budget_mb", 192)
+        assert not hip_ctx.stats()["used_dense_path"]
+        ok, msg, _ = cases.compare_depth(dense, want, RTOL)
+        assert ok, "dense vs oracle (ref %d): %s" % (ref, msg)
+        assert _same_bits(dense, generic), "dense and general kernels differ (ref %d)" % ref
+
+
+def test_non_aligned_geometry_falls_back(hip_ctx):
+    case = cases.get_twoview("adaptive_verged", radius=5)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.twoview_wta(0, 1, p)
+    assert not hip_ctx.stats()["used_dense_path"]
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), want, RTOL)
+    assert ok, msg
