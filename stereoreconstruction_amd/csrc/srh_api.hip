@@ -448,6 +448,14 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.n_eval = (int64_t)h.n_eval;
 	c->stats.n_eval_device = (int64_t)h.n_eval_device;
 	c->stats.used_dense_path = used_dense;
+	if (h.dbg_waves)
+		fprintf(stderr, "[srh dbg] dense: waves %llu, cycles/wave %.0f, fast blocks/wave %.1f, cycles/fast block %.0f\n",
+		        h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_blocks/h.dbg_waves,
+		        h.dbg_blocks ? (double)h.dbg_cycles/h.dbg_blocks : 0.0);
+	if (h.dbg_waves)
+		fprintf(stderr, "[srh dbg] phases/wave: stage_w %.0f prologue %.0f sync %.0f stage_rt %.0f compute %.0f tail %.0f\n",
+		        (double)h.dbg_phase[0]/h.dbg_waves, (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
+		        (double)h.dbg_phase[3]/h.dbg_waves, (double)h.dbg_phase[4]/h.dbg_waves, (double)h.dbg_phase[5]/h.dbg_waves);
 	return SRH_OK;
 }
 
@@ -502,9 +510,9 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 	size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
 	if (rows < 1) rows = 1;
 	if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
-	const size_t wstride = rows*W;
-	if ((rc = ensure(c->wbuf, c->wbuf_cap, wstride*T))) return rc;
-	if (dense && (rc = ensure(c->cost, c->cost_cap, wstride*(size_t)cstride))) return rc;
+	const size_t wstride = SRH_WTILE;
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
+	if (dense && (rc = ensure(c->cost, c->cost_cap, rows*W*(size_t)cstride))) return rc;
 
 	for (int by = y0; by < y1; by += (int)rows) {
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
@@ -586,8 +594,8 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	if (y1 <= 0 || y1 > H) y1 = H;
 	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
 	const int rows = band_rows(c, W, H, T);
-	const size_t wstride = (size_t)rows*W;
-	if ((rc = ensure(c->wbuf, c->wbuf_cap, wstride*T))) return rc;
+	const size_t wstride = SRH_WTILE;
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, rows, T)))) return rc;
 	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 	for (int by = y0; by < y1; by += rows) {
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");

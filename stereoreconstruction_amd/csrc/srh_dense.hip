@@ -13,6 +13,8 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
+#include <cstdlib>
+
 namespace srh {
 
 // ------------------------------------------------------------------ edge planes
@@ -134,7 +136,7 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			}
 		}
 	}
-	double *wb = wbuf + ((size_t)trow*W + cx);
+	double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
 #pragma unroll
 	for (int a = 0; a < WS; ++a)
 #pragma unroll
@@ -227,78 +229,96 @@ void launch_twoview_extent(hipStream_t st, const ViewDev *views, int ref, int ot
 // remain -- the same operations, in the same order, as twoviewstereo.cpp:917-976.
 #define DC_TP 32
 #define DC_G 8
-#define DC_NCB 8
 #define DC_THREADS (DC_TP*DC_G)
-#define DC_CHUNK 320               // candidate columns staged per pass (>= TP + D for C3)
 
-template <int R>
+// LDS image of one workgroup.  Everything a lane reads in the hot loop is 16-byte
+// aligned so that it moves as ds_read_b128: window rows are padded to an even tap
+// count, candidate blocks start on even tile columns.  Lanes of a wave are laid out
+// pixel-fastest (lane = g*8 + pixel), so one wave-instruction touches 64
+// consecutive doubles of a right-image row: bank-conflict free.
+template <int R, int DC_NCB, int DC_CHUNK>
 struct DenseSmem {
 	static constexpr int WS = 2*R + 1;
 	static constexpr int T = WS*WS;
-	static constexpr int RW = DC_CHUNK + 2*R + DC_NCB;      // right tile width
+	static constexpr int WP = (WS + 1) & ~1;                // taps per window row, padded even
+	static constexpr int WPIX = WS*WP;                      // doubles per pixel window
+	static constexpr int RW = DC_CHUNK + 2*R + DC_NCB + 2;  // right tile width (even)
 	static constexpr int LW = DC_TP + 2*R;                  // left tile width
-	double w[T][DC_TP];
+	double w[DC_TP][WPIX];                                  // w[pixel][row*WP + col]
 	double rt[WS][RW];
 	double lt[WS][LW];
 	double meanL[DC_TP], totalW[DC_TP], sum2[DC_TP];
 	int lall[DC_TP];
+	int pxmin[DC_TP], pxmax[DC_TP];                         // candidate range of each pixel (empty: max < min)
 	unsigned char rfull[RW];
 	unsigned char colok[RW];
+	static constexpr int GL_CAP = 2048;                     // pairs examined per compaction round
+	static_assert(DC_CHUNK <= 512 && DC_TP <= 64, "work-list entry = pixel*512 + column in 16 bits");
+	unsigned short glist[GL_CAP];
+	int glist_n;
 };
 
-// general (any validity pattern) cost of one candidate from the LDS tiles
-template <int R>
-__device__ __noinline__ double dense_cost_general(const DenseSmem<R> &S, int i, int rc,
+// general (any validity pattern) cost of one candidate from the LDS tiles.  Skipped taps add
+// +0.0 to every sum, which leaves each partial sum bit-for-bit unchanged, so the selects
+// below are the reference's "continue" (twoviewstereo.cpp:920-938, 955-972).
+template <int R, int DC_NCB, int DC_CHUNK>
+__device__ __noinline__ double dense_cost_general(const DenseSmem<R, DC_NCB, DC_CHUNK> &S, int i, int rc,
                                                   double weight_cutoff, double bad_ret, double max_color_diff)
 {
 	constexpr int WS = 2*R + 1;
+	constexpr int WP = DenseSmem<R, DC_NCB, DC_CHUNK>::WP;
 	double meanL = 0, meanR = 0, totalWeight = 0.0;
 #pragma unroll 1
-	for (int row = 0; row < WS; ++row)
-#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = S.lt[row][i + col]; gr[col] = S.rt[row][rc + col]; wt[col] = S.w[i][row*WP + col]; }
+#pragma unroll
 		for (int col = 0; col < WS; ++col) {
-			const double gl = S.lt[row][i + col];
-			const double gr = S.rt[row][rc + col];
-			const double weight = S.w[row*WS + col][i];
-			if (gl == gl && gr == gr && weight > weight_cutoff) {
-				meanL += weight*gl;
-				meanR += weight*gr;
-				totalWeight += weight;
-			}
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > weight_cutoff;
+			const double pl = wt[col]*gl[col], pr = wt[col]*gr[col];
+			meanL += ok ? pl : 0.0;
+			meanR += ok ? pr : 0.0;
+			totalWeight += ok ? wt[col] : 0.0;
 		}
+	}
 	if (totalWeight < 1e-10) return bad_ret;
 	meanL /= totalWeight;
 	meanR /= totalWeight;
 	double sum1 = 0, sum2 = 0, sum3 = 0;
 #pragma unroll 1
-	for (int row = 0; row < WS; ++row)
-#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = S.lt[row][i + col]; gr[col] = S.rt[row][rc + col]; wt[col] = S.w[i][row*WP + col]; }
+#pragma unroll
 		for (int col = 0; col < WS; ++col) {
-			const double gl = S.lt[row][i + col];
-			const double gr = S.rt[row][rc + col];
-			const double weight = S.w[row*WS + col][i];
-			if (gl == gl && gr == gr && weight > weight_cutoff) {
-				const double pgl = weight*gl;
-				const double pgr = weight*gr;
-				sum1 += (pgl - meanL)*(pgr - meanR);
-				sum2 += (pgl - meanL)*(pgl - meanL);
-				sum3 += (pgr - meanR)*(pgr - meanR);
-			}
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > weight_cutoff;
+			const double a = wt[col]*gl[col] - meanL;
+			const double b = wt[col]*gr[col] - meanR;
+			const double ab = a*b, aa = a*a, bb = b*b;
+			sum1 += ok ? ab : 0.0;
+			sum2 += ok ? aa : 0.0;
+			sum3 += ok ? bb : 0.0;
 		}
+	}
 	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
 	return (v < max_color_diff) ? v : max_color_diff;
 }
 
-template <int R>
-__global__ __launch_bounds__(DC_THREADS, 2)
+template <int R, int DC_NCB, int DC_CHUNK, int MINW>
+__global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                                const Extent *__restrict__ ext, double *__restrict__ cost, int cstride,
-                               Counters *__restrict__ cnt)
+                               Counters *__restrict__ cnt, int dbg)
 {
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
-	typedef DenseSmem<R> Smem;
+	typedef DenseSmem<R, DC_NCB, DC_CHUNK> Smem;
+	constexpr int WP = Smem::WP;
+	constexpr int NR = DC_NCB + 2*R;           // right-row values a block needs (even)
+	static_assert(NR % 2 == 0 && WP % 2 == 0 && Smem::RW % 2 == 0 && DC_CHUNK % 2 == 0, "16-byte rows");
 	extern __shared__ __align__(16) unsigned char smem_raw[];
 	Smem &S = *reinterpret_cast<Smem *>(smem_raw);
 
@@ -310,42 +330,96 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	const int x0 = (blockIdx.x % tiles_per_row)*DC_TP;
 	const int y = y0 + trow;
 	const int tid = threadIdx.x;
-	const int i = tid / DC_G;                  // pixel within the tile
-	const int g = tid % DC_G;                  // lane within the pixel
+	const int lane = tid & 63;
+	const int i = (tid >> 6)*8 + (lane & 7);   // pixel within the tile (pixel-fastest inside a wave)
+	const int g = lane >> 3;                   // lane within the pixel
 	const int x = x0 + i;
 	const size_t qbase = (size_t)trow*W + x0;  // band-relative index of the tile's first pixel
 	const double nan = __builtin_nan("");
 
-	// ---- stage windows and the reference rows
-	for (int idx = tid; idx < T*DC_TP; idx += DC_THREADS) {
-		const int t = idx / DC_TP, pi = idx % DC_TP;
-		S.w[t][pi] = (x0 + pi < W) ? wbuf[(size_t)t*wstride + qbase + pi] : 0.0;
-	}
-	for (int idx = tid; idx < WS*Smem::LW; idx += DC_THREADS) {
-		const int ty = idx / Smem::LW, tx = idx % Smem::LW;
-		const int gx = x0 - R + tx, gy = y - R + ty;
-		S.lt[ty][tx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
-	}
-	// union of the candidate ranges of the tile
+	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long tp = (dbg & 2) ? __builtin_readcyclecounter() : 0;
+#define SRH_STAMP(k) do { if (dbg & 2) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
+
+	// Staging and bookkeeping run at raised wave priority: a freshly dispatched workgroup
+	// shares its SIMDs with an older one that is deep in the FP64 loops, and must get its
+	// loads issued immediately so that their latency hides under the other's arithmetic.
+	__builtin_amdgcn_s_setprio(3);
+	// ---- union of the candidate ranges of the tile (one global load, one LDS reduction)
 	__shared__ int s_cmin, s_cmax;
 	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; }
-	__syncthreads();
 	Extent e; e.xmin = 0; e.xmax = -1;
 	if (x < W) e = ext[qbase + i];
-	if (g == 0 && e.xmax >= e.xmin) { atomicMin(&s_cmin, e.xmin); atomicMax(&s_cmax, e.xmax); }
 	__syncthreads();
-	const int cmin = s_cmin, cmax = s_cmax;
+	if (g == 0) {
+		S.pxmin[i] = e.xmin; S.pxmax[i] = e.xmax;
+		if (e.xmax >= e.xmin) { atomicMin(&s_cmin, e.xmin); atomicMax(&s_cmax, e.xmax); }
+	}
+	__syncthreads();
+	const int cmin = s_cmin & ~1, cmax = s_cmax;            // chunks start on even columns
+	SRH_STAMP(0);
 
-	// ---- per-pixel constants of the fast form (one lane per pixel)
+	// ---- stage the windows, the reference rows and the first chunk of the other view's rows.
+	// Every global load of the thread is issued before the first LDS store, so the whole
+	// staging costs about one memory latency.
+	constexpr int NBW = (T*DC_TP + DC_THREADS - 1)/DC_THREADS;
+	constexpr int NBL = (WS*Smem::LW + DC_THREADS - 1)/DC_THREADS;
+	constexpr int NBR = (WS*Smem::RW + DC_THREADS - 1)/DC_THREADS;
+	{
+		// tile-major window buffer: the T*DC_TP doubles of this tile are contiguous
+		static_assert(DC_TP == SRH_WTILE, "dense tile = window-buffer tile");
+		const double *wtile = wbuf + ((dbg & 16) ? wbuf_offset(W, T, 10, 320) : wbuf_offset(W, T, trow, x0));
+		double tw_[NBW], tl_[NBL], tr_[NBR];
+#pragma unroll
+		for (int k = 0; k < NBW; ++k) {
+			const int idx = tid + k*DC_THREADS;
+			tw_[k] = (!(dbg & 8) && idx < T*DC_TP && x0 + (idx % DC_TP) < W) ? wtile[idx] : 0.5;
+		}
+#pragma unroll
+		for (int k = 0; k < NBL; ++k) {
+			const int idx = tid + k*DC_THREADS;
+			const int ty = idx / Smem::LW, tx = idx % Smem::LW;
+			const int gx = x0 - R + tx, gy = y - R + ty;
+			tl_[k] = (dbg & 8) ? 1.0*idx : (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
+		}
+#pragma unroll
+		for (int k = 0; k < NBR; ++k) {
+			const int idx = tid + k*DC_THREADS;
+			const int ty = idx / Smem::RW, tx = idx % Smem::RW;
+			const int gx = cmin - R + tx, gy = y - R + ty;
+			tr_[k] = (dbg & 8) ? 2.0*idx : (cmin <= cmax && idx < WS*Smem::RW && gx >= 0 && gy >= 0 && gx < Rv.w && gy < Rv.h)
+			       ? Rv.gray_tv[(size_t)gy*Rv.w + gx] : nan;
+		}
+#pragma unroll
+		for (int k = 0; k < NBW; ++k) {
+			const int idx = tid + k*DC_THREADS;
+			const int t = idx / DC_TP, pi = idx % DC_TP;
+			if (idx < T*DC_TP) S.w[pi][(t / WS)*WP + (t % WS)] = tw_[k];
+		}
+#pragma unroll
+		for (int k = 0; k < NBL; ++k) {
+			const int idx = tid + k*DC_THREADS;
+			if (idx < WS*Smem::LW) S.lt[idx / Smem::LW][idx % Smem::LW] = tl_[k];
+		}
+#pragma unroll
+		for (int k = 0; k < NBR; ++k) {
+			const int idx = tid + k*DC_THREADS;
+			if (idx < WS*Smem::RW) S.rt[idx / Smem::RW][idx % Smem::RW] = tr_[k];
+		}
+	}
+	__syncthreads();
+	SRH_STAMP(1);
+
+	// ---- per-pixel constants of the fast form (one lane per pixel) ...
 	if (g == 0) {
 		bool all = (x < W) && (e.xmax >= e.xmin);
 		double mL = 0, tw = 0;
 #pragma unroll 1
 		for (int row = 0; row < WS; ++row)
-#pragma unroll 1
+#pragma unroll
 			for (int col = 0; col < WS; ++col) {
 				const double gl = S.lt[row][i + col];
-				const double wt = S.w[row*WS + col][i];
+				const double wt = S.w[i][row*WP + col];
 				if (!(gl == gl && wt > P.weight_cutoff)) all = false;
 				mL += wt*gl;
 				tw += wt;
@@ -355,29 +429,44 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			mL /= tw;
 #pragma unroll 1
 			for (int row = 0; row < WS; ++row)
-#pragma unroll 1
+#pragma unroll
 				for (int col = 0; col < WS; ++col) {
-					const double a = S.w[row*WS + col][i]*S.lt[row][i + col] - mL;
+					const double a = S.w[i][row*WP + col]*S.lt[row][i + col] - mL;
 					s2 += a*a;
 				}
 		} else all = false;
 		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
 	}
+	SRH_STAMP(2);
 
 	unsigned n_dev = 0;
+	unsigned long long t_fast = 0, n_fast = 0;
+	const unsigned long long t_begin = (dbg & 2) ? __builtin_readcyclecounter() : 0;
 	const Smem &CS = S;
 	for (int cs = cmin; cs <= cmax; cs += DC_CHUNK) {
-		__syncthreads();   // previous chunk fully consumed (and the stores above visible)
-		// ---- stage the other view's rows for columns [cs-R, cs+CHUNK+R+NCB)
-		for (int idx = tid; idx < WS*Smem::RW; idx += DC_THREADS) {
-			const int ty = idx / Smem::RW, tx = idx % Smem::RW;
-			const int gx = cs - R + tx, gy = y - R + ty;
-			S.rt[ty][tx] = (gx >= 0 && gy >= 0 && gx < Rv.w && gy < Rv.h) ? Rv.gray_tv[(size_t)gy*Rv.w + gx] : nan;
+		if (cs != cmin) {
+			__builtin_amdgcn_s_setprio(3);
+			__syncthreads();   // previous chunk fully consumed
+			double tr_[NBR];
+#pragma unroll
+			for (int k = 0; k < NBR; ++k) {
+				const int idx = tid + k*DC_THREADS;
+				const int ty = idx / Smem::RW, tx = idx % Smem::RW;
+				const int gx = cs - R + tx, gy = y - R + ty;
+				tr_[k] = (idx < WS*Smem::RW && gx >= 0 && gy >= 0 && gx < Rv.w && gy < Rv.h)
+				       ? Rv.gray_tv[(size_t)gy*Rv.w + gx] : nan;
+			}
+#pragma unroll
+			for (int k = 0; k < NBR; ++k) {
+				const int idx = tid + k*DC_THREADS;
+				if (idx < WS*Smem::RW) S.rt[idx / Smem::RW][idx % Smem::RW] = tr_[k];
+			}
+			__syncthreads();
 		}
-		__syncthreads();
+		// ... and, on the other lanes meanwhile, which candidate columns have a fully usable window
 		for (int tx = tid; tx < Smem::RW; tx += DC_THREADS) {
 			bool ok = true;
-#pragma unroll 1
+#pragma unroll
 			for (int ty = 0; ty < WS; ++ty) { const double v = S.rt[ty][tx]; ok = ok && (v == v); }
 			S.colok[tx] = ok ? 1 : 0;
 		}
@@ -385,78 +474,191 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		for (int tx = tid; tx < Smem::RW; tx += DC_THREADS) {
 			// rfull[k]: window of candidate column cs+k fully usable (tile columns k .. k+2R)
 			bool ok = tx + 2*R < Smem::RW;
-			for (int k = 0; ok && k < WS; ++k) ok = S.colok[tx + k] != 0;
+			if (ok) {
+#pragma unroll
+				for (int k = 0; k < WS; ++k) ok = ok && S.colok[tx + k] != 0;
+			}
 			S.rfull[tx] = ok ? 1 : 0;
 		}
 		__syncthreads();
+		SRH_STAMP(3);
+		__builtin_amdgcn_s_setprio(0);
 
 		if (x < W && e.xmax >= e.xmin) {
 			const int lo = e.xmin > cs ? e.xmin : cs;
 			const int hi = e.xmax < cs + DC_CHUNK - 1 ? e.xmax : cs + DC_CHUNK - 1;
-			const int nblocks = hi >= lo ? (hi - lo + DC_NCB)/DC_NCB : 0;
+			const int lo_e = lo & ~1;                               // blocks start on even columns (>= cs)
+			const int nblocks = hi >= lo ? (hi - lo_e + DC_NCB)/DC_NCB : 0;
 			double *crow = cost + (qbase + i)*(size_t)cstride;
-			for (int b = g; b < nblocks; b += DC_G) {
-				const int c0 = lo + b*DC_NCB;
-				const int nv = (hi - c0 + 1) < DC_NCB ? (hi - c0 + 1) : DC_NCB;
-				const int rc = c0 - cs;                 // tile column of the window's left edge
-				bool fast = CS.lall[i] != 0;
-				for (int j = 0; j < nv; ++j) fast = fast && CS.rfull[rc + j] != 0;
-				n_dev += nv;
+			// phase 1: blocks of DC_NCB candidates in the fast form.  Candidates whose window is
+			// not fully usable still ride along in the block but are not stored; phase 2 below
+			// evaluates them (and every candidate of a pixel that has unusable taps itself).
+			for (int b = g; b < (CS.lall[i] ? nblocks : 0); b += DC_G) {
+				const int c0 = lo_e + b*DC_NCB;
+				const int rc = c0 - cs;                 // tile column of the window's left edge (even)
+				bool fast = false;
+#pragma unroll
+				for (int j = 0; j < DC_NCB; ++j) {
+					const int c = c0 + j;
+					if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) { fast = true; ++n_dev; }
+				}
+				if (dbg & 1) { if (c0 == -12345) crow[0] = 1.0; continue; }
+				const unsigned long long t0 = (dbg & 2) ? __builtin_readcyclecounter() : 0;
+				if (dbg & 32) fast = true;
 				if (fast) {
 					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
-					double acc[DC_NCB];
+					// Both passes are modulo-scheduled by hand: r[] / wv[] / av[] hold the current
+					// window row; as soon as a value has had its last use, the same register is
+					// refilled with the next row's value, so the LDS latency is always a row ahead.
+					static_assert(WS % 2 == 1, "odd window");
+					double r[NR], wv[WS], acc[DC_NCB];
+					{
+						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[0][rc]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
+#pragma unroll
+						for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+#pragma unroll
+						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][WS - 1];
+					}
 #pragma unroll
 					for (int j = 0; j < DC_NCB; ++j) acc[j] = 0.0;
+					// all LDS reads of the loop pre-header have landed: inside the loop the compiler can
+					// then count only the reads of the previous iteration (lgkmcnt(N) instead of 0)
+					__builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
-						double r[DC_NCB + 2*R];
-#pragma unroll
-						for (int k = 0; k < DC_NCB + 2*R; ++k) r[k] = CS.rt[row][rc + k];
+						const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for pass 2
+						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nrow][rc]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
-							const double wt = CS.w[row*WS + col][i];
+							// products first, sums second: no instruction waits on its predecessor, so a
+							// wave keeps the FP64 pipe full even when it is alone on its SIMD
+							double pr[DC_NCB];
 #pragma unroll
-							for (int j = 0; j < DC_NCB; ++j) acc[j] += wt*r[col + j];   // meanR += weight*gray
+							for (int j = 0; j < DC_NCB; ++j) pr[j] = wv[col]*r[col + j];
 							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) acc[j] += pr[j];            // meanR += weight*gray
+							__builtin_amdgcn_sched_barrier(0);              // keep each refill where it is written
+							if (col & 1) {                                  // r[col-1], r[col], wv[col-1], wv[col] are dead
+								const double2 v = rp[col >> 1]; r[col - 1] = v.x; r[col] = v.y;
+								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
+								__builtin_amdgcn_sched_barrier(0);
+							}
 						}
+#pragma unroll
+						for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];           // (the pad tap is never read)
 					}
-					double mR[DC_NCB], s1[DC_NCB], s3[DC_NCB];
+					double mR[DC_NCB], s1[DC_NCB], s3[DC_NCB], av[WS];
+#pragma unroll
+					for (int col = 0; col < WS; ++col) av[col] = CS.lt[0][i + col];
 #pragma unroll
 					for (int j = 0; j < DC_NCB; ++j) { mR[j] = acc[j]/tw; s1[j] = 0.0; s3[j] = 0.0; }
+					__builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
-						double r[DC_NCB + 2*R];
-#pragma unroll
-						for (int k = 0; k < DC_NCB + 2*R; ++k) r[k] = CS.rt[row][rc + k];
+						const int nrow = row + 1 < WS ? row + 1 : 0;
+						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nrow][rc]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const double *lp = &CS.lt[nrow][i];
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
-							const double wt = CS.w[row*WS + col][i];
-							const double a = wt*CS.lt[row][i + col] - mL;     // pixel_gray_l - meanL
+							const double wt = wv[col];
+							double bb[DC_NCB], u1[DC_NCB], u3[DC_NCB];
+							const double pa = wt*av[col];
 #pragma unroll
-							for (int j = 0; j < DC_NCB; ++j) {
-								const double bb = wt*r[col + j] - mR[j];      // pixel_gray_r - meanR
-								s1[j] += a*bb;
-								s3[j] += bb*bb;
+							for (int j = 0; j < DC_NCB; ++j) bb[j] = wt*r[col + j];
+							__builtin_amdgcn_sched_barrier(0);
+							const double a = pa - mL;                         // pixel_gray_l - meanL
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+							__builtin_amdgcn_sched_barrier(0);
+							av[col] = lp[col];
+							if (col & 1) {
+								const double2 v = rp[col >> 1]; r[col - 1] = v.x; r[col] = v.y;
+								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
+#pragma unroll
+						for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];           // (the pad tap is never read)
 					}
 #pragma unroll
 					for (int j = 0; j < DC_NCB; ++j) {
-						if (j < nv) {
+						const int c = c0 + j;
+						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							crow[c0 + j - e.xmin] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							if (!(dbg & 4) || v == -12345.0)
+							crow[c - e.xmin] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
-				} else {
-					for (int j = 0; j < nv; ++j)
-						crow[c0 + j - e.xmin] = dense_cost_general<R>(CS, i, rc + j, P.weight_cutoff, P.bad_ret, P.max_color_diff);
+					if (dbg & 2) { t_fast += __builtin_readcyclecounter() - t0; ++n_fast; }
 				}
 			}
 		}
+		// phase 2: the remaining candidates in the general form (any validity pattern), spread
+		// over all lanes of the workgroup: pair p = (pixel, chunk column), consecutive lanes take
+		// consecutive columns, so image-border columns and border rows are shared evenly.
+		// The pairs are first compacted into an LDS work list (rounds of GL_CAP pairs) so that a
+		// wave that enters the general code has (nearly) all of its lanes busy.
+		for (int base = 0; base < DC_TP*DC_CHUNK; base += Smem::GL_CAP) {
+			if (tid == 0) S.glist_n = 0;
+			__syncthreads();
+			for (int p = base + tid; p < base + Smem::GL_CAP && p < DC_TP*DC_CHUNK; p += DC_THREADS) {
+				const int pi = p / DC_CHUNK, k = p % DC_CHUNK;
+				const int c = cs + k;
+				if (c < S.pxmin[pi] || c > S.pxmax[pi]) continue;
+				if (CS.lall[pi] && CS.rfull[k]) continue;         // done in phase 1
+				S.glist[atomicAdd(&S.glist_n, 1)] = (unsigned short)(pi*512 + k);
+			}
+			__syncthreads();
+			const int nl = S.glist_n;
+			for (int q = tid; q < nl; q += DC_THREADS) {
+				const int pi = S.glist[q] >> 9, k = S.glist[q] & 511;
+				++n_dev;
+				cost[(qbase + pi)*(size_t)cstride + (cs + k - S.pxmin[pi])] =
+					dense_cost_general<R, DC_NCB, DC_CHUNK>(CS, pi, k, P.weight_cutoff, P.bad_ret, P.max_color_diff);
+			}
+		}
 	}
+	SRH_STAMP(4);
 	block_count_add(&cnt->n_eval_device, n_dev);
+	SRH_STAMP(5);
+	if ((dbg & 2) && (tid & 63) == 0) {
+		for (int k = 0; k < 8; ++k) atomicAdd(&cnt->dbg_phase[k], ph[k]);
+		atomicAdd(&cnt->dbg_cycles, t_fast);
+		atomicAdd(&cnt->dbg_blocks, n_fast);
+		atomicAdd(&cnt->dbg_total_cycles, (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+		atomicAdd(&cnt->dbg_waves, 1ull);
+	}
+}
+
+template <int R, int NCB, int CHUNK, int MINW>
+static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
+                                 int y0, int nrows, const double *wbuf, size_t wstride,
+                                 const Extent *ext, double *cost, int cstride, Counters *cnt)
+{
+	typedef DenseSmem<R, NCB, CHUNK> Smem;
+	static bool attr = false;
+	if (!attr) {
+		(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>,
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+		attr = true;
+	}
+	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>), grid, dim3(DC_THREADS), sizeof(Smem), st,
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, ext, cost, cstride, cnt,
+	                   getenv("SRH_DENSE_DBG") ? atoi(getenv("SRH_DENSE_DBG")) : 0);
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -464,22 +666,25 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const Extent *ext, double *cost, int cstride, Counters *cnt)
 {
 	const int tiles = (width + DC_TP - 1)/DC_TP;
-	const dim3 grid((unsigned)(tiles*nrows)), block(DC_THREADS);
+	const dim3 grid((unsigned)(tiles*nrows));
+	static int variant = -1;
+	if (variant < 0) { const char *v = getenv("SRH_DENSE_VARIANT"); variant = v ? atoi(v) : 0; }
+#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, ext, cost, cstride, cnt
 	switch (P.window_radius) {
-	case 5: {
-		static bool attr5 = false;
-		if (!attr5) { (void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DenseSmem<5>)); attr5 = true; }
-		hipLaunchKernelGGL(twoview_dense_cost_kernel<5>, grid, block, sizeof(DenseSmem<5>), st,
-		                   views, ref, oth, P, y0, nrows, wbuf, wstride, ext, cost, cstride, cnt);
-		return true; }
-	case 2: {
-		static bool attr2 = false;
-		if (!attr2) { (void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DenseSmem<2>)); attr2 = true; }
-		hipLaunchKernelGGL(twoview_dense_cost_kernel<2>, grid, block, sizeof(DenseSmem<2>), st,
-		                   views, ref, oth, P, y0, nrows, wbuf, wstride, ext, cost, cstride, cnt);
-		return true; }
+	case 5:
+		switch (variant) {
+		case 1:  launch_dense_variant<5, 6, 128, 3>(SRH_ARGS); break;
+		case 2:  launch_dense_variant<5, 4, 320, 2>(SRH_ARGS); break;
+		case 3:  launch_dense_variant<5, 4, 128, 3>(SRH_ARGS); break;
+		default: launch_dense_variant<5, 8, 320, 2>(SRH_ARGS); break;
+		}
+		return true;
+	case 2:
+		launch_dense_variant<2, 8, 320, 2>(SRH_ARGS);
+		return true;
 	default: return false;
 	}
+#undef SRH_ARGS
 }
 
 // ------------------------------------------------------------------ scan: walk + look-up + WTA

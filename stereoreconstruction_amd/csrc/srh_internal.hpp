@@ -26,12 +26,26 @@ struct ViewDev {
 	srh_camera      cam;
 };
 
+// Support-window buffer of one row band: tile-major, a tile = SRH_WTILE consecutive
+// pixels of one image row holding T taps: wbuf[tile][tap][SRH_WTILE] (31 KB contiguous
+// per tile at r=5).  A pixel's window is  base + tap*SRH_WTILE.
+#define SRH_WTILE 32
+__host__ __device__ inline size_t wbuf_doubles(int W, int nrows, int T) {
+	return (size_t)nrows*((W + SRH_WTILE - 1)/SRH_WTILE)*SRH_WTILE*T;
+}
+__host__ __device__ inline size_t wbuf_offset(int W, int T, int band_row, int x) {
+	const size_t tile = (size_t)band_row*((W + SRH_WTILE - 1)/SRH_WTILE) + x/SRH_WTILE;
+	return tile*(size_t)T*SRH_WTILE + (x % SRH_WTILE);
+}
+
 // Work counters accumulated by the kernels (device memory, zeroed per run).
 struct Counters {
 	unsigned long long n_pixels;
 	unsigned long long n_eval;
 	unsigned long long n_eval_device;
 	unsigned long long not_row_aligned;   // pixels whose curve leaves their own row
+	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
+	unsigned long long dbg_phase[8];
 };
 
 // Per-pixel result of the curve-extent pass (dense path planning)

@@ -69,7 +69,7 @@ __device__ __forceinline__ double color_dist(uint32_t a, uint32_t b) {
 }
 
 // Any-radius version: the window lives in the global weight buffer
-// (wb[tap*wstride + q], coalesced across the threads of a wave).
+// (tile-major layout of srh_internal.hpp: wb[tap*wstride], wstride = SRH_WTILE).
 __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_params P,
                                int y0, int nrows, double *__restrict__ wbuf, size_t wstride)
 {
@@ -79,8 +79,8 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 	if (q >= (size_t)nrows*W) return;
 	const int cx = (int)(q % W), cy = y0 + (int)(q / W);
 	if (V.mask[(size_t)cy*W + cx] != 1) return;                 // masked pixels never reach init_weights
-	double *wb = wbuf + q;
 	const int R = P.window_radius, WS = 2*R + 1;
+	double *wb = wbuf + wbuf_offset(W, WS*WS, (int)(q / W), cx);
 
 	if (P.weight_kind == SRH_WEIGHT_GEODESIC) {
 		// geodesicweight.cpp:59-131
@@ -183,7 +183,8 @@ __global__ void twoview_generic_kernel(const ViewDev *__restrict__ views, int re
 		if (L.mask[pv] == 1) {
 			n_pix = 1;
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-			TwoViewDirectVisitor vis = { L, Rv, wbuf + q, wstride, P, x, y,
+			const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+			TwoViewDirectVisitor vis = { L, Rv, wbuf + wbuf_offset(W, T, (int)(q / W), x), wstride, P, x, y,
 			                             __builtin_inf(), __builtin_inf(), -1, -1, 0 };
 			walk_curve<false>(ray, L.cam, Rv, P, vis);
 			n_eval = vis.n;
@@ -303,7 +304,8 @@ __global__ void mvs_generic_kernel(const ViewDev *__restrict__ views, int ref,
 		if (A.mask[pv] == 1) {
 			n_pix = 1;
 			const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-			MvsVisitor vis = { A, A, wbuf + q, wstride, P, ray, x, y, 0.0, -1.0, pk, 0 };
+			const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+			MvsVisitor vis = { A, A, wbuf + wbuf_offset(W, T, (int)(q / W), x), wstride, P, ray, x, y, 0.0, -1.0, pk, 0 };
 			for (int ni = 0; ni < nneigh; ++ni) {
 				const int v2 = ni == 0 ? n0 : (ni == 1 ? n1 : n2);
 				const ViewDev &B = views[v2];
