@@ -25,6 +25,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 from stereoreconstruction_amd import capi, synthetic  # noqa: E402
+from stereoreconstruction_amd.distributed import gather_depth_maps, shard_units  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (datasheet)
@@ -82,8 +83,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     W, H, D, wkind, seed, desc = WORKLOADS[args.workload]
-    # weak scaling: every rank owns one pair (its own seed)
-    L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + 0x10000 * rank)
+    # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair
+    (unit,) = list(shard_units(world, world, rank))
+    L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + 0x10000 * unit)
     cams3 = synthetic.rectified_cameras(W, H)
     zmin, zmax = synthetic.rectified_depth_range(W, D)
     (Kl, Rl, tl), (Kr, Rr, tr) = cams3
@@ -95,7 +97,7 @@ def main():
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
     out = torch.empty((2, H, W), dtype=torch.float64, device=dev)
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = None
 
     def step():
         ctx.twoview_wta(0, 1, p)
@@ -103,8 +105,8 @@ def main():
         ctx.twoview_cross_check(0, 1, p)
         ctx.copy_depth_to_device(0, out[0].data_ptr())
         ctx.copy_depth_to_device(1, out[1].data_ptr())
-        if world > 1:
-            dist.gather(out, gathered, dst=0)      # RCCL over xGMI: per-view depth maps to rank 0
+        nonlocal gathered
+        gathered = gather_depth_maps(out, dst=0)   # RCCL over xGMI: per-view depth maps to rank 0
 
     def fence():
         if world > 1:

@@ -107,3 +107,36 @@ void refp_weights(void *h, int cx, int cy, int radius, int kind, double *out) {
 }
 
 } /* extern "C" */
+
+/* ---- example-project ingest, exactly as the reference does it (needs only Qt):
+ * image  = QImage(file).scaledToWidth(w*scale, Qt::SmoothTransformation) -> VectorImage::fromQImage
+ *          (stereo/twoviewstereo.cpp:97, stereo/multiviewstereo.cpp:220-222)
+ * mask   = alpha == 255 on a FastTransformation copy (multiviewstereo.cpp:225-234)
+ * out_rgba: w*h*4 doubles->bytes R,G,B,A as fromQImage stores them; returns 0 on failure. */
+extern "C" int refp_load_scaled(const char *path, double scale, int max_w, int max_h,
+                                unsigned char *out_rgba, unsigned char *out_mask, int *out_w, int *out_h)
+{
+	QImage base(path);
+	if (base.isNull()) return 0;
+	QImage image = base.scaledToWidth(base.width() * scale, Qt::SmoothTransformation);
+	VectorImage vi = VectorImage::fromQImage(image);
+	const int w = vi.width(), h = vi.height();
+	*out_w = w; *out_h = h;
+	if (w > max_w || h > max_h) return 0;
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x) {
+			const RGBA &p = vi.pixel(x, y);
+			unsigned char *o = out_rgba + (static_cast<size_t>(y)*w + x)*4;
+			o[0] = static_cast<unsigned char>(p.r); o[1] = static_cast<unsigned char>(p.g);
+			o[2] = static_cast<unsigned char>(p.b); o[3] = static_cast<unsigned char>(p.a);
+		}
+	if (base.hasAlphaChannel()) {
+		QImage mask = base.scaledToWidth(image.width(), Qt::FastTransformation);
+		for (int y = 0; y < h; ++y)
+			for (int x = 0; x < w; ++x)
+				out_mask[static_cast<size_t>(y)*w + x] = (qAlpha(mask.pixel(x, y)) == 255) ? 1 : 0;
+	} else {
+		memset(out_mask, 1, static_cast<size_t>(w)*h);
+	}
+	return 1;
+}

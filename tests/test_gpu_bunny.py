@@ -1,0 +1,64 @@
+"""BASELINE config C1: the example project's `bunny` pair (cameras 7310085 / 7310087) as the
+reference ingests it (tests/golden/bunny_pair.npz: Qt smooth scaling 0.25, alpha mask, lens
+distortion, 100 levels) -- TwoView WTA + cross-check, HIP vs oracle.
+
+Depth range: the README suggests 300-800, but the projection matrices of example/project.xml
+put these two cameras 19 units apart, converging at z ~ 48, and the object at z ~ 41-44 (the
+README range projects outside the other image: empty curves).  The test sweeps 30-80."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+from stereoreconstruction_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bunny_pair.npz")
+
+
+def _load():
+    g = np.load(GOLD)
+    views = []
+    for tag in ("left", "right"):
+        views.append((g[tag + "_rgba"], g[tag + "_mask"], (g[tag + "_K"], g[tag + "_R"], g[tag + "_t"]),
+                      g[tag + "_dist"], None))
+    params = dict(min_depth=30.0, max_depth=80.0, num_depth_levels=100, image_scale=float(g["scale"][0]),
+                  window_radius=5, weight_kind=1)
+    return dict(name="bunny", kind="twoview", views=views, params=params)
+
+
+def test_bunny_pair_twoview(hip_ctx):
+    case = _load()
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    assert cams[0].is_distorted and cams[1].is_distorted
+    cases.upload_case(hip_ctx, case, cams)
+    y0, y1 = 84, 108                       # a band through the object: keeps the CPU oracle to seconds
+    want_l = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op, y0, y1)
+    want_r = O.twoview_wta(imgs[1], imgs[0], ocams[1], ocams[0], op, y0, y1)
+    nan = np.full(want_l.shape, np.nan)
+    hip_ctx.upload_depth(0, nan)
+    hip_ctx.upload_depth(1, nan)
+    hip_ctx.twoview_wta(0, 1, p, y0, y1)
+    assert not hip_ctx.stats()["used_dense_path"]          # distorted, verged cameras: general kernels
+    hip_ctx.twoview_wta(1, 0, p, y0, y1)
+    got_l, got_r = hip_ctx.download_depth(0), hip_ctx.download_depth(1)
+    ok, msg, _ = cases.compare_depth(got_l[y0:y1], want_l[y0:y1], 1e-9)
+    assert ok, "left: " + msg
+    ok, msg, _ = cases.compare_depth(got_r[y0:y1], want_r[y0:y1], 1e-9)
+    assert ok, "right: " + msg
+    fin = np.isfinite(want_l[y0:y1])
+    assert fin.sum() > 200, "band misses the object"
+    z = want_l[y0:y1][fin]
+    assert 38 < np.median(z) < 48                           # the bunny sits at z ~ 41-44
+    # cross-check on the band (rows outside are NaN on both sides)
+    cl, cr = O.twoview_cross_check(ocams[0], ocams[1], op, want_l, want_r)
+    hip_ctx.upload_depth(0, want_l)
+    hip_ctx.upload_depth(1, want_r)
+    hip_ctx.twoview_cross_check(0, 1, p)
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), cl, 1e-9)
+    assert ok, "left cross-check: " + msg
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(1), cr, 1e-9)
+    assert ok, "right cross-check: " + msg
