@@ -1,0 +1,61 @@
+// multiviewstereo.hpp -- MultiViewStereo with the reference's public interface
+// (stereo/multiviewstereo.hpp:36-113) on libstereo_recon_hip.  initialize() takes the views'
+// already-loaded, already-scaled images instead of (ProjectPtr, ImageSetPtr): the project /
+// image-set data model is out of scope and only its outputs --
+// camera parameters and pixels -- feed this path.
+#pragma once
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "camera.hpp"
+#include "image.hpp"
+#include "task.hpp"
+
+struct PLYPoint { double p[3]; uint8_t rgb[3]; };
+void outputPLYFile(const std::string &path, const std::vector<PLYPoint> &points);   // multiviewstereo.cpp:291-315
+
+class MultiViewStereo : public Task {
+public:
+	typedef std::vector<double> DepthMap;
+
+	explicit MultiViewStereo(int deviceOrdinal = 0);
+	~MultiViewStereo();
+
+	// images[i] is the default image of views[i] scaled by imageScale; its alpha channel is the
+	// mask (alpha == 255 <=> WHITE, multiviewstereo.cpp:225-234).  Views with a null image are skipped.
+	void initialize(const std::vector<CameraPtr> &views, const std::vector<Image> &images,
+	                double minDepth, double maxDepth,
+	                int numDepthLevels,
+	                double crossCheckThreshold,
+	                double imageScale = 1.0);
+
+	std::string title() const { return "Multi-View Stereo"; }
+	int numSteps() const;                              // 2 * views (multiviewstereo.cpp:319-321)
+
+	Image depthMap(CameraPtr view) const;              // grayscale, NaN/INF/unknown white (:252-276)
+	const DepthMap *depths(CameraPtr view) const;      // computedDepths[view]
+	const std::vector<std::vector<int> > &neighbourViews() const { return neighbours; }
+
+	srh_params &params() { return params_; }
+	const std::string &lastError() const { return error_; }
+
+protected:
+	void runTask();
+
+private:
+	void colorize(size_t v);
+
+	std::vector<CameraPtr> views;
+	std::vector<Image> images;
+	std::vector<std::vector<uint8_t> > masks;
+	std::vector<Image> results;
+	std::vector<DepthMap> computedDepths;
+	std::vector<std::vector<int> > neighbours;
+	double minDepth, maxDepth, crossCheckThreshold, imageScale;
+	int numDepthLevels;
+	srh_params params_;
+	srh_context *ctx_;
+	std::string error_;
+};

@@ -1,0 +1,59 @@
+// twoviewstereo.hpp -- TwoViewStereo with the reference's public interface
+// (stereo/twoviewstereo.hpp:39-126), running on libstereo_recon_hip (MI355X).
+// Differences forced by dropping Qt: QImage -> Image (already scaled by imageScale),
+// QString -> std::string, signals -> std::function members of Task.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "camera.hpp"
+#include "image.hpp"
+#include "task.hpp"
+
+class TwoViewStereo : public Task {
+public:
+	typedef std::vector<double> DepthMap;
+
+	TwoViewStereo(CameraPtr leftView, Image left, Image leftMask,
+	              CameraPtr rightView, Image right, Image rightMask,
+	              double minDepth, double maxDepth,
+	              int numDepthLevels,
+	              double imageScale = 1.0,
+	              int deviceOrdinal = 0);
+	~TwoViewStereo();
+
+	std::string title() const { return "Two-View Stereo"; }
+	int numSteps() const { return 8; }
+
+	void computeDepthMaps();
+
+	Image leftDepthMap() const { return resultLeft; }
+	Image rightDepthMap() const { return resultRight; }
+
+	// raw results (computedDepthLeft / computedDepthRight of the reference, twoviewstereo.hpp:113-114)
+	const DepthMap &leftDepths() const { return computedDepthLeft; }
+	const DepthMap &rightDepths() const { return computedDepthRight; }
+
+	srh_params &params() { return params_; }          // every hard-coded constant, with the reference's defaults
+	const std::string &lastError() const { return error_; }
+
+protected:
+	void runTask() { computeDepthMaps(); }
+
+private:
+	void colorize(const DepthMap &d, Image &out) const;
+	void colorFromDepth(double depth, uint8_t rgb[3]) const;
+
+	CameraPtr leftView, rightView;
+	Image left, right;
+	std::vector<uint8_t> leftMask, rightMask;
+	double minDepth, maxDepth;
+	int numDepthLevels;
+	double imageScale;
+	Image resultLeft, resultRight;
+	DepthMap computedDepthLeft, computedDepthRight;
+	srh_params params_;
+	srh_context *ctx_;
+	std::string error_;
+};

@@ -1,0 +1,93 @@
+// host_api_test.cpp -- drives the Qt-free TwoViewStereo / MultiViewStereo classes
+// (stereoreconstruction_amd/host) the way StereoWidget drives the reference's
+// (gui/widgets/stereowidget.cpp:974-1002, 954-970).  Inputs / outputs are flat binary files
+// written and checked by tests/test_gpu_host_api.py.
+//
+//   host_api_test twoview in.bin out.bin
+//   host_api_test mvs     in.bin out.bin
+//
+// in.bin : int32 nviews, w, h, D, radius, weight_kind; double minDepth, maxDepth, scale, crossCheck;
+//          per view: double K[9], R[9], t[3], dist[5]; uint8 rgba[w*h*4]; uint8 mask[w*h] (twoview only)
+// out.bin: per view double depth[w*h]; then int32 nsteps, then the progress steps seen
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "multiviewstereo.hpp"
+#include "twoviewstereo.hpp"
+
+template <class T> static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
+
+int main(int argc, char **argv) {
+	if (argc != 4) { fprintf(stderr, "usage: %s twoview|mvs in out\n", argv[0]); return 2; }
+	const bool mvs = !strcmp(argv[1], "mvs");
+	FILE *f = fopen(argv[2], "rb");
+	if (!f) { perror(argv[2]); return 2; }
+	int32_t hdr[6]; double dh[4];
+	rd(f, hdr, 6); rd(f, dh, 4);
+	const int nviews = hdr[0], w = hdr[1], h = hdr[2], D = hdr[3], radius = hdr[4], wkind = hdr[5];
+	std::vector<CameraPtr> cams;
+	std::vector<Image> images, maskImages;
+	for (int v = 0; v < nviews; ++v) {
+		double K[9], R[9], t[3]; LensDistortions dist;
+		rd(f, K, 9); rd(f, R, 9); rd(f, t, 3); rd(f, dist.data(), 5);
+		CameraPtr c(new Camera(std::to_string(v), "cam" + std::to_string(v)));
+		c->set(K, R, t);
+		c->setLensDistortion(dist);
+		cams.push_back(c);
+		Image im(w, h);
+		rd(f, im.rgba.data(), im.rgba.size());
+		images.push_back(im);
+		if (!mvs) {
+			std::vector<uint8_t> m(static_cast<size_t>(w)*h);
+			rd(f, m.data(), m.size());
+			Image mi(w, h);
+			for (size_t k = 0; k < m.size(); ++k) if (!m[k]) { mi.rgba[4*k] = mi.rgba[4*k+1] = mi.rgba[4*k+2] = 0; }
+			maskImages.push_back(mi);
+		}
+	}
+	fclose(f);
+
+	std::vector<int> steps;
+	std::vector<std::vector<double> > out;
+	bool started = false, finished = false;
+	if (!mvs) {
+		TwoViewStereo tvs(cams[0], images[0], maskImages[0], cams[1], images[1], maskImages[1], dh[0], dh[1], D, dh[2]);
+		if (!tvs.lastError().empty()) { fprintf(stderr, "ctor: %s\n", tvs.lastError().c_str()); return 3; }
+		tvs.params().window_radius = radius; tvs.params().weight_kind = wkind;
+		tvs.progressUpdate = [&](int s) { steps.push_back(s); };
+		tvs.started = [&](const Task *) { started = true; };
+		tvs.finished = [&](const Task *) { finished = true; };
+		if (tvs.numSteps() != 8 || tvs.title() != "Two-View Stereo") return 4;
+		tvs.run();                                     // Task::run -> runTask -> computeDepthMaps
+		if (!tvs.lastError().empty()) { fprintf(stderr, "run: %s\n", tvs.lastError().c_str()); return 3; }
+		out.push_back(tvs.leftDepths()); out.push_back(tvs.rightDepths());
+		const Image lm = tvs.leftDepthMap();
+		if (lm.width() != w || lm.height() != h) return 5;
+	} else {
+		std::shared_ptr<MultiViewStereo> m(new MultiViewStereo());
+		if (!m->lastError().empty()) { fprintf(stderr, "ctor: %s\n", m->lastError().c_str()); return 3; }
+		m->params().window_radius = radius; m->params().weight_kind = wkind;
+		m->initialize(cams, images, dh[0], dh[1], D, dh[3], dh[2]);
+		m->progressUpdate = [&](int s) { steps.push_back(s); };
+		m->started = [&](const Task *) { started = true; };
+		m->finished = [&](const Task *) { finished = true; };
+		if (m->numSteps() != 2*nviews) return 4;
+		m->run();
+		if (!m->lastError().empty()) { fprintf(stderr, "run: %s\n", m->lastError().c_str()); return 3; }
+		for (int v = 0; v < nviews; ++v) out.push_back(*m->depths(cams[v]));
+		if (!m->depthMap(CameraPtr(new Camera("x"))).isNull()) return 5;     // unknown view => null image
+		if (m->depthMap(cams[0]).width() != w) return 5;
+	}
+	if (!started || !finished) return 6;
+	FILE *o = fopen(argv[3], "wb");
+	if (!o) { perror(argv[3]); return 2; }
+	for (size_t v = 0; v < out.size(); ++v) fwrite(out[v].data(), sizeof(double), out[v].size(), o);
+	const int32_t ns = static_cast<int32_t>(steps.size());
+	fwrite(&ns, sizeof(ns), 1, o);
+	for (int s : steps) { const int32_t v = s; fwrite(&v, sizeof(v), 1, o); }
+	fclose(o);
+	return 0;
+}

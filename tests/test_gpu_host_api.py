@@ -1,0 +1,105 @@
+"""The Qt-free C++ classes TwoViewStereo / MultiViewStereo (stereoreconstruction_amd/host), driven
+like the reference's GUI drives its own, against the oracle.  The C++ driver is compiled here with
+g++ and linked to libstereo_recon_hip.so -- this is the drop-in boundary a maintainer would use."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "stereoreconstruction_amd", "host")
+LIBDIR = os.path.join(ROOT, "stereoreconstruction_amd")
+
+
+def _build(tmp):
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    exe = os.path.join(tmp, "host_api_test")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+                           os.path.join(ROOT, "tests", "host_api_test.cpp"),
+                           os.path.join(HOST, "libstereo_recon_host.a"),
+                           "-L" + LIBDIR, "-lstereo_recon_hip", "-Wl,-rpath," + LIBDIR, "-o", exe])
+    return exe
+
+
+def _write_input(path, case, with_masks):
+    p = case["params"]
+    views = case["views"]
+    h, w = views[0][0].shape[:2]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i", len(views), w, h, p["num_depth_levels"], p["window_radius"], p["weight_kind"]))
+        f.write(struct.pack("<4d", p["min_depth"], p["max_depth"], p["image_scale"], p.get("cross_check_threshold", 1.0)))
+        for (rgba, mask, (K, R, t), dist, plane) in views:
+            assert plane is None
+            f.write(np.ascontiguousarray(K, np.float64).tobytes())
+            f.write(np.ascontiguousarray(R, np.float64).tobytes())
+            f.write(np.ascontiguousarray(t, np.float64).tobytes())
+            f.write(np.ascontiguousarray(dist if dist is not None else np.zeros(5), np.float64).tobytes())
+            f.write(np.ascontiguousarray(rgba, np.uint8).tobytes())
+            if with_masks:
+                f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+
+
+def _read_output(path, nmaps, w, h):
+    raw = open(path, "rb").read()
+    n = w * h * 8
+    maps = [np.frombuffer(raw[i * n:(i + 1) * n], np.float64).reshape(h, w) for i in range(nmaps)]
+    (ns,) = struct.unpack_from("<i", raw, nmaps * n)
+    steps = list(struct.unpack_from("<%di" % ns, raw, nmaps * n + 4))
+    return maps, steps
+
+
+def test_host_classes_compile_without_gpu(tmp_path):
+    """CPU check: the host layer and its driver build and link against the C-ABI library."""
+    assert os.path.exists(_build(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_twoviewstereo_class(tmp_path):
+    exe = _build(str(tmp_path))
+    case = cases.get_twoview("geodesic_masks", w=72, h=40, D=16)
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_input(inp, case, True)
+    subprocess.check_call([exe, "twoview", inp, outp])
+    (gl, gr), steps = _read_output(outp, 2, 72, 40)
+    assert steps == [1, 3, 5, 8]
+    imgs, ocams, op = cases.oracle_inputs(case)
+    dl = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
+    dr = O.twoview_wta(imgs[1], imgs[0], ocams[1], ocams[0], op)
+    cl, cr = O.twoview_cross_check(ocams[0], ocams[1], op, dl, dr)
+    ok, msg, _ = cases.compare_depth(gl, cl, 1e-9)
+    assert ok, msg
+    ok, msg, _ = cases.compare_depth(gr, cr, 1e-9)
+    assert ok, msg
+
+
+@pytest.mark.gpu
+def test_multiviewstereo_class(tmp_path):
+    exe = _build(str(tmp_path))
+    case = cases.get_mvs("mvs_geodesic")
+    # the class takes the mask from the image's alpha channel (multiviewstereo.cpp:225-234)
+    views = []
+    for (rgba, mask, cam, dist, plane) in case["views"]:
+        im = rgba.copy()
+        im[..., 3] = np.where(mask == 1, 255, 51)
+        views.append((im, mask, cam, dist, plane))
+    case = dict(case, views=views)
+    h, w = views[0][0].shape[:2]
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_input(inp, case, False)
+    subprocess.check_call([exe, "mvs", inp, outp])
+    nv = len(views)
+    got, steps = _read_output(outp, nv, w, h)
+    assert steps == list(range(2 * nv))                     # numSteps() = 2*views, emitted 0..2V-1
+    imgs, ocams, op = cases.oracle_inputs(case)
+    neigh = O.mvs_neighbours(ocams, op)
+    ref = [O.mvs_initial_estimate(imgs, ocams, v, neigh[v], op)[0] for v in range(nv)]
+    for v in range(nv):
+        O.mvs_cross_check(imgs, ocams, v, op, ref)
+    for v in range(nv):
+        ok, msg, _ = cases.compare_depth(got[v], ref[v], 1e-9)
+        assert ok, "view %d: %s" % (v, msg)
