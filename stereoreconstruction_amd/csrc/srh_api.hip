@@ -60,7 +60,7 @@ struct srh_context {
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
 	Extent *ext = nullptr;    size_t ext_cap = 0;       // pixels
-	size_t wbuf_budget = (size_t)192 << 20;             // bytes per band: support windows (+ dense cost rows)
+	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
 	void *user = nullptr;

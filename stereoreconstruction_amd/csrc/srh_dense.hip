@@ -346,8 +346,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	// loads issued immediately so that their latency hides under the other's arithmetic.
 	__builtin_amdgcn_s_setprio(3);
 	// ---- union of the candidate ranges of the tile (one global load, one LDS reduction)
-	__shared__ int s_cmin, s_cmax;
-	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; }
+	__shared__ int s_cmin, s_cmax, s_need_pix, s_need_col;
+	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; s_need_pix = 0; s_need_col = 0; }
 	Extent e; e.xmin = 0; e.xmax = -1;
 	if (x < W) e = ext[qbase + i];
 	__syncthreads();
@@ -436,6 +436,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 				}
 		} else all = false;
 		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
+		if (!all && x < W && e.xmax >= e.xmin) s_need_pix = 1;      // this pixel needs the general form
 	}
 	SRH_STAMP(2);
 
@@ -470,6 +471,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			for (int ty = 0; ty < WS; ++ty) { const double v = S.rt[ty][tx]; ok = ok && (v == v); }
 			S.colok[tx] = ok ? 1 : 0;
 		}
+		if (tid == 0) s_need_col = 0;
 		__syncthreads();
 		for (int tx = tid; tx < Smem::RW; tx += DC_THREADS) {
 			// rfull[k]: window of candidate column cs+k fully usable (tile columns k .. k+2R)
@@ -479,6 +481,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 				for (int k = 0; k < WS; ++k) ok = ok && S.colok[tx + k] != 0;
 			}
 			S.rfull[tx] = ok ? 1 : 0;
+			const int c = cs + tx;
+			if (!ok && c >= s_cmin && c <= cmax && tx < DC_CHUNK) s_need_col = 1;   // a candidate column needs it
 		}
 		__syncthreads();
 		SRH_STAMP(3);
@@ -612,7 +616,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		// consecutive columns, so image-border columns and border rows are shared evenly.
 		// The pairs are first compacted into an LDS work list (rounds of GL_CAP pairs) so that a
 		// wave that enters the general code has (nearly) all of its lanes busy.
-		for (int base = 0; base < DC_TP*DC_CHUNK; base += Smem::GL_CAP) {
+		const bool need_general = s_need_pix != 0 || s_need_col != 0;   // uniform: read after the barrier above
+		for (int base = 0; need_general && base < DC_TP*DC_CHUNK; base += Smem::GL_CAP) {
 			if (tid == 0) S.glist_n = 0;
 			__syncthreads();
 			for (int p = base + tid; p < base + Smem::GL_CAP && p < DC_TP*DC_CHUNK; p += DC_THREADS) {

@@ -160,7 +160,7 @@ def test_dense_path_matches_oracle_and_generic(hip_ctx, name, over):
         hip_ctx.twoview_wta(ref, oth, p)
         generic = hip_ctx.download_depth(ref)
         hip_ctx.set_option("force_generic", 0)
-        hip_ctx.set_option("band_budget_mb", 192)
+        hip_ctx.set_option("band_budget_mb", 1536)
         assert not hip_ctx.stats()["used_dense_path"]
         ok, msg, _ = cases.compare_depth(dense, want, RTOL)
         assert ok, "dense vs oracle (ref %d): %s" % (ref, msg)
