@@ -75,15 +75,30 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 
 	__shared__ double eE[WS][TWD], eS[WS][TWD], eSE[WS][TWD], eSW[WS][TWD];
 	const double inf = __builtin_inf();
-	for (int idx = threadIdx.x; idx < WS*TWD; idx += GW_TW) {
-		const int ty = idx / TWD, tx = idx % TWD;
-		const int gx = x0 - R + tx, gy = cy - R + ty;
-		const bool in = gx >= 0 && gy >= 0 && gx < W && gy < H;
-		const size_t gi = (size_t)gy*W + gx;
-		eE[ty][tx]  = in ? edges[0*n + gi] : inf;
-		eS[ty][tx]  = in ? edges[1*n + gi] : inf;
-		eSE[ty][tx] = in ? edges[2*n + gi] : inf;
-		eSW[ty][tx] = in ? edges[3*n + gi] : inf;
+	{
+		// all global loads of the thread first, LDS stores after: one memory latency per tile
+		constexpr int NB = (WS*TWD + GW_TW - 1)/GW_TW;
+		double t0[NB], t1[NB], t2[NB], t3[NB];
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const int idx = threadIdx.x + k*GW_TW;
+			const int ty = idx / TWD, tx = idx % TWD;
+			const int gx = x0 - R + tx, gy = cy - R + ty;
+			const bool in = idx < WS*TWD && gx >= 0 && gy >= 0 && gx < W && gy < H;
+			const size_t gi = in ? (size_t)gy*W + gx : 0;
+			t0[k] = in ? edges[0*n + gi] : inf;
+			t1[k] = in ? edges[1*n + gi] : inf;
+			t2[k] = in ? edges[2*n + gi] : inf;
+			t3[k] = in ? edges[3*n + gi] : inf;
+		}
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const int idx = threadIdx.x + k*GW_TW;
+			if (idx < WS*TWD) {
+				const int ty = idx / TWD, tx = idx % TWD;
+				eE[ty][tx] = t0[k]; eS[ty][tx] = t1[k]; eSE[ty][tx] = t2[k]; eSW[ty][tx] = t3[k];
+			}
+		}
 	}
 	__syncthreads();
 
@@ -101,22 +116,31 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 
 #pragma unroll 1
 	for (int iter = 0; iter < P.geodesic_iters; ++iter) {
-		// forward pass, K1 = (-1,-1) (0,-1) (1,-1) (-1,0)   (geodesicweight.cpp:73-97)
+		// forward pass, K1 = (-1,-1) (0,-1) (1,-1) (-1,0)   (geodesicweight.cpp:73-97).
+		// std::min(weight, cost + diff): no operand is ever NaN (finite or +inf sums), so v_min_f64
+		// returns exactly what the compare-and-select does.  A cell outside the image is never
+		// relaxed because every edge that touches it is +inf.  The edges of one window row are
+		// fetched from LDS in one batch (the asm barrier keeps the loop-invariant reads from being
+		// hoisted out of the sweep, which would spill).
 #pragma unroll
 		for (int yy = 0; yy < WS; ++yy) {
-			// keep the edge loads of each window row next to their use (no hoisting of
-			// the loop-invariant LDS reads out of the sweep, which would spill)
 			asm volatile("" ::: "memory");
+			double se[WS], s_[WS], sw[WS], ee[WS];
 #pragma unroll
 			for (int xx = 0; xx < WS; ++xx) {
-				const int tx = i + xx;                      // tile column of window cell xx
+				const int tx = i + xx;
+				se[xx] = (yy > 0 && xx > 0)      ? eSE[yy-1][tx-1] : inf;
+				s_[xx] = (yy > 0)                ? eS[yy-1][tx]    : inf;
+				sw[xx] = (yy > 0 && xx < WS - 1) ? eSW[yy-1][tx+1] : inf;
+				ee[xx] = (xx > 0)                ? eE[yy][tx-1]    : inf;
+			}
+#pragma unroll
+			for (int xx = 0; xx < WS; ++xx) {
 				double wt = w[yy][xx];
-				// a cell outside the image is never relaxed: freeze it by testing its own
-				// position through an edge that touches it (all its edges are +inf)
-				if (yy > 0 && xx > 0)      { const double c = w[yy-1][xx-1] + eSE[yy-1][tx-1]; wt = (c < wt) ? c : wt; }
-				if (yy > 0)                { const double c = w[yy-1][xx]   + eS[yy-1][tx];    wt = (c < wt) ? c : wt; }
-				if (yy > 0 && xx < WS - 1) { const double c = w[yy-1][xx+1] + eSW[yy-1][tx+1]; wt = (c < wt) ? c : wt; }
-				if (xx > 0)                { const double c = w[yy][xx-1]   + eE[yy][tx-1];    wt = (c < wt) ? c : wt; }
+				if (yy > 0 && xx > 0)      wt = __builtin_fmin(w[yy-1][xx-1] + se[xx], wt);
+				if (yy > 0)                wt = __builtin_fmin(w[yy-1][xx]   + s_[xx], wt);
+				if (yy > 0 && xx < WS - 1) wt = __builtin_fmin(w[yy-1][xx+1] + sw[xx], wt);
+				if (xx > 0)                wt = __builtin_fmin(w[yy][xx-1]   + ee[xx], wt);
 				w[yy][xx] = wt;
 			}
 		}
@@ -124,28 +148,35 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 #pragma unroll
 		for (int yy = WS - 1; yy >= 0; --yy) {
 			asm volatile("" ::: "memory");
+			double se[WS], s_[WS], sw[WS], ee[WS];
+#pragma unroll
+			for (int xx = 0; xx < WS; ++xx) {
+				const int tx = i + xx;
+				sw[xx] = (yy < WS - 1 && xx > 0)      ? eSW[yy][tx] : inf;
+				s_[xx] = (yy < WS - 1)                ? eS[yy][tx]  : inf;
+				se[xx] = (yy < WS - 1 && xx < WS - 1) ? eSE[yy][tx] : inf;
+				ee[xx] = (xx < WS - 1)                ? eE[yy][tx]  : inf;
+			}
 #pragma unroll
 			for (int xx = WS - 1; xx >= 0; --xx) {
-				const int tx = i + xx;
 				double wt = w[yy][xx];
-				if (yy < WS - 1 && xx > 0)      { const double c = w[yy+1][xx-1] + eSW[yy][tx]; wt = (c < wt) ? c : wt; }
-				if (yy < WS - 1)                { const double c = w[yy+1][xx]   + eS[yy][tx];  wt = (c < wt) ? c : wt; }
-				if (yy < WS - 1 && xx < WS - 1) { const double c = w[yy+1][xx+1] + eSE[yy][tx]; wt = (c < wt) ? c : wt; }
-				if (xx < WS - 1)                { const double c = w[yy][xx+1]   + eE[yy][tx];  wt = (c < wt) ? c : wt; }
+				if (yy < WS - 1 && xx > 0)      wt = __builtin_fmin(w[yy+1][xx-1] + sw[xx], wt);
+				if (yy < WS - 1)                wt = __builtin_fmin(w[yy+1][xx]   + s_[xx], wt);
+				if (yy < WS - 1 && xx < WS - 1) wt = __builtin_fmin(w[yy+1][xx+1] + se[xx], wt);
+				if (xx < WS - 1)                wt = __builtin_fmin(w[yy][xx+1]   + ee[xx], wt);
 				w[yy][xx] = wt;
 			}
 		}
 	}
 	double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
+	// exponential weighting (geodesicweight.cpp:128-130)
 #pragma unroll
-	for (int a = 0; a < WS; ++a)
+	for (int a = 0; a < WS; ++a) {
 #pragma unroll
 		for (int b = 0; b < WS; ++b)
-			wb[(size_t)(a*WS + b)*wstride] = w[a][b];
-	// exponential weighting (geodesicweight.cpp:128-130), rolled: one exp body instead of (2R+1)^2
-#pragma unroll 1
-	for (int t = 0; t < WS*WS; ++t)
-		wb[(size_t)t*wstride] = exp(-wb[(size_t)t*wstride] / P.geodesic_sigma);
+			wb[(size_t)(a*WS + b)*wstride] = exp(-w[a][b] / P.geodesic_sigma);
+		asm volatile("" ::: "memory");
+	}
 }
 
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
