@@ -59,7 +59,7 @@ struct srh_context {
 	int *d_span = nullptr;
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
-	Extent *ext = nullptr;    size_t ext_cap = 0;       // pixels
+	double *tnum = nullptr;   size_t tnum_cap = 0;      // per-label table of the pinhole walk
 	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
@@ -317,7 +317,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->d_span) hipFree(c->d_span);
 	if (c->wbuf) hipFree(c->wbuf);
 	if (c->cost) hipFree(c->cost);
-	if (c->ext) hipFree(c->ext);
+	if (c->tnum) hipFree(c->tnum);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -469,6 +469,23 @@ static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int
 	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride);
 }
 
+// Can every epipolar curve of `a` in `b` stay on its own image row?  Undistorted, non-refractive
+// cameras with the same orientation and the same second and third rows of K, displaced along the
+// camera x axis.  This only *proposes* the dense path: the scan kernel verifies every candidate.
+static bool rig_is_row_aligned(const srh_camera &a, const srh_camera &b, double *fx_bx) {
+	if (a.is_distorted || b.is_distorted || a.is_refractive || b.is_refractive) return false;
+	for (int k = 0; k < 9; ++k) if (fabs(a.R[k] - b.R[k]) > 1e-13) return false;
+	for (int k = 3; k < 9; ++k) if (fabs(a.K[k] - b.K[k]) > 1e-9*(1.0 + fabs(a.K[k]))) return false;
+	if (fabs(a.K[1]) > 1e-12 || fabs(b.K[1]) > 1e-12 || fabs(a.K[3]) > 1e-12 || fabs(a.K[6]) > 1e-12 || fabs(a.K[7]) > 1e-12)
+		return false;
+	const Vec3 d = load3(b.C) - load3(a.C);
+	const Vec3 bc = matvec(a.R, d);                               // baseline in camera axes
+	const double len = norm(bc);
+	if (!(len > 0) || fabs(bc.y) > 1e-12*len || fabs(bc.z) > 1e-12*len) return false;
+	*fx_bx = fabs(b.K[0]*bc.x);
+	return true;
+}
+
 extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1) {
 	int rc;
 	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
@@ -484,53 +501,60 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 	if (y1 <= y0) return SRH_OK;
 	const int R = p->window_radius;
 	const int T = (2*R + 1)*(2*R + 1);
-	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 
-	// ---- plan: is every epipolar curve confined to its own image row?
+	// ---- plan: dense row-aligned kernels, or the general curve-walk kernel
 	bool dense = !c->force_generic && (R == 5 || R == 2);
 	int cstride = 0;
+	double fx_bx = 0;
+	if (dense && !rig_is_row_aligned(L.cam, Rv.cam, &fx_bx)) dense = false;
 	if (dense) {
-		const size_t npix = (size_t)(y1 - y0)*W;
-		if ((rc = ensure(c->ext, c->ext_cap, npix))) return rc;
-		HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
-		{ Scope s(c, "twoview_extent_kernel");
-		  launch_twoview_extent(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->ext, c->d_cnt, c->d_span); }
-		Counters hc; int span = 0;
-		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipMemcpyAsync(&span, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		cstride = (span + 7) & ~7;
-		if (hc.not_row_aligned != 0 || span <= 0 || span > 8192) {
-			dense = false;
-			HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
-		}
+		// widest candidate range a pixel can have: disparity(min_depth) - disparity(max_depth) + margins
+		const double span = fx_bx*p->image_scale*fabs(1.0/p->min_depth - 1.0/p->max_depth);
+		if (!(p->min_depth > 0) || !(p->max_depth > 0) || !(span < 4096.0)) dense = false;
+		else cstride = (((int)ceil(span) + 3) + 7) & ~7;
+		if (cstride > W + 8) cstride = (W + 8 + 7) & ~7;
 	}
 
-	size_t per_pixel = (size_t)T*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
-	size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
-	if (rows < 1) rows = 1;
-	if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
-	const size_t wstride = SRH_WTILE;
-	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
-	if (dense && (rc = ensure(c->cost, c->cost_cap, rows*W*(size_t)cstride))) return rc;
-
-	for (int by = y0; by < y1; by += (int)rows) {
-		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
-		const int nr = std::min((int)rows, y1 - by);
-		run_weights(c, ref, W, *p, by, nr, wstride);
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		if (dense) {
-			const Extent *ext = c->ext + (size_t)(by - y0)*W;
-			{ Scope s(c, "twoview_dense_cost_kernel");
-			  launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-			                            ext, c->cost, cstride, c->d_cnt); }
-			{ Scope s(c, "twoview_scan_kernel");
-			  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, ext, c->cost, cstride); }
-		} else {
-			Scope s(c, "twoview_generic_kernel");
-			launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt);
+			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
+			Scope s(c, "pinhole_label_table_kernel");
+			launch_pinhole_label_table(c->stream, c->d_views, ref, *p, c->tnum);
 		}
+		size_t per_pixel = (size_t)T*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
+		size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
+		if (rows < 1) rows = 1;
+		if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
+		const size_t wstride = SRH_WTILE;
+		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
+		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*W*(size_t)cstride))) return rc;
+
+		for (int by = y0; by < y1; by += (int)rows) {
+			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+			const int nr = std::min((int)rows, y1 - by);
+			run_weights(c, ref, W, *p, by, nr, wstride);
+			if (dense) {
+				{ Scope s(c, "twoview_dense_cost_kernel");
+				  launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
+				                            c->tnum, c->cost, cstride, c->d_cnt); }
+				{ Scope s(c, "twoview_scan_kernel");
+				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
+				                      c->wbuf, wstride, c->d_cnt); }
+			} else {
+				Scope s(c, "twoview_generic_kernel");
+				launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt);
+			}
+		}
+		HIP_TRY(hipGetLastError());
+		if (!dense) break;
+		// the dense result stands only if no candidate left its row / column range
+		Counters hc;
+		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (hc.not_row_aligned == 0) break;
+		dense = false;                                              // redo with the general kernel
 	}
-	HIP_TRY(hipGetLastError());
 	c->stats.used_dense_path = dense ? 1 : 0;
 	return SRH_OK;
 }

@@ -6,7 +6,7 @@
 //
 //   edge_planes_kernel        colour distances between 8-neighbours, once per view
 //   geodesic_reg_kernel<R>    GeodesicWeight windows, window held in registers     (8(a) #2)
-//   twoview_extent_kernel     per pixel: candidate column range, row-alignment test (#6,#7)
+//   pinhole_label_table_kernel  per-label part of pointFromDepth for an undistorted pair     (#6)
 //   twoview_dense_cost_kernel weighted NCC for every candidate column, LDS-tiled    (#8)
 //   twoview_scan_kernel       curve walk + cost look-up + running-min WTA + depth   (#9,#10)
 #include "srh_internal.hpp"
@@ -191,59 +191,17 @@ bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int widt
 	}
 }
 
-// ------------------------------------------------------------------ extent pass
-struct ExtentVisitor {
-	int y, xmin, xmax, n;
-	bool aligned;
-	__device__ __forceinline__ void operator()(int cx, int cy) {
-		if (cy != y) aligned = false;
-		xmin = cx < xmin ? cx : xmin;
-		xmax = cx > xmax ? cx : xmax;
-		++n;
-	}
-};
-
-__global__ void twoview_extent_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
-                                      int y0, int nrows, Extent *__restrict__ ext, Counters *__restrict__ cnt,
-                                      int *__restrict__ max_span)
+// ------------------------------------------------------------------ per-label table of the pinhole walk
+__global__ void pinhole_label_table_kernel(const ViewDev *__restrict__ views, int ref, srh_params P,
+                                           double *__restrict__ tnum)
 {
-	const ViewDev &L = views[ref];
-	const ViewDev &Rv = views[oth];
-	const int W = L.w;
-	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
-	unsigned n_eval = 0, n_pix = 0, bad = 0;
-	int span = 0;
-	if (q < (size_t)nrows*W) {
-		const int x = (int)(q % W), y = y0 + (int)(q / W);
-		Extent e; e.xmin = 0; e.xmax = -1;
-		if (L.mask[(size_t)y*W + x] == 1) {
-			n_pix = 1;
-			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-			ExtentVisitor vis = { y, 2147483647, -2147483647, 0, true };
-			walk_curve<false>(ray, L.cam, Rv, P, vis);
-			n_eval = vis.n;
-			if (vis.n > 0) { e.xmin = vis.xmin; e.xmax = vis.xmax; span = vis.xmax - vis.xmin + 1; }
-			if (!vis.aligned) bad = 1;
-		}
-		ext[q] = e;
-	}
-	__shared__ int s_span;
-	if (threadIdx.x == 0) s_span = 0;
-	__syncthreads();
-	if (span > 0) atomicMax(&s_span, span);
-	__syncthreads();
-	if (threadIdx.x == 0 && s_span > 0) atomicMax(max_span, s_span);
-	block_count_add(&cnt->n_eval, n_eval);
-	block_count_add(&cnt->n_pixels, n_pix);
-	block_count_add(&cnt->not_row_aligned, bad);
+	const int d = blockIdx.x*blockDim.x + threadIdx.x;
+	if (d < P.num_depth_levels) tnum[d] = pinhole_label_tnum(views[ref].cam, P, false, d);
 }
 
-void launch_twoview_extent(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                           int y0, int nrows, Extent *ext, Counters *cnt, int *max_span)
-{
-	const size_t n = (size_t)nrows*width;
-	hipLaunchKernelGGL(twoview_extent_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-	                   views, ref, oth, P, y0, nrows, ext, cnt, max_span);
+void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, double *tnum) {
+	hipLaunchKernelGGL(pinhole_label_table_kernel, dim3((unsigned)((P.num_depth_levels + 63)/64)), dim3(64), 0, st,
+	                   views, ref, P, tnum);
 }
 
 // ------------------------------------------------------------------ dense cost
@@ -341,7 +299,7 @@ template <int R, int DC_NCB, int DC_CHUNK, int MINW>
 __global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
-                               const Extent *__restrict__ ext, double *__restrict__ cost, int cstride,
+                               const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
                                Counters *__restrict__ cnt, int dbg)
 {
 	constexpr int WS = 2*R + 1;
@@ -379,14 +337,20 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	// ---- union of the candidate ranges of the tile (one global load, one LDS reduction)
 	__shared__ int s_cmin, s_cmax, s_need_pix, s_need_col;
 	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; s_need_pix = 0; s_need_col = 0; }
-	Extent e; e.xmin = 0; e.xmax = -1;
-	if (x < W) e = ext[qbase + i];
 	__syncthreads();
 	if (g == 0) {
-		S.pxmin[i] = e.xmin; S.pxmax[i] = e.xmax;
-		if (e.xmax >= e.xmin) { atomicMin(&s_cmin, e.xmin); atomicMax(&s_cmax, e.xmax); }
+		// candidate column range of the pixel (verified later by the scan kernel)
+		int lo = 0, hi = -1;
+		if (x < W && L.mask[(size_t)y*W + x] == 1) {
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
+			if (hi >= lo) hi = dense_cover_hi(lo, hi, DC_NCB, DC_G);   // columns beyond: evaluated lazily by the scan
+		}
+		S.pxmin[i] = lo; S.pxmax[i] = hi;
+		if (hi >= lo) { atomicMin(&s_cmin, lo); atomicMax(&s_cmax, hi); }
 	}
 	__syncthreads();
+	Extent e; e.xmin = S.pxmin[i]; e.xmax = S.pxmax[i];
 	const int cmin = s_cmin & ~1, cmax = s_cmax;            // chunks start on even columns
 	SRH_STAMP(0);
 
@@ -683,7 +647,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 template <int R, int NCB, int CHUNK, int MINW>
 static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
                                  int y0, int nrows, const double *wbuf, size_t wstride,
-                                 const Extent *ext, double *cost, int cstride, Counters *cnt)
+                                 const double *tnum, double *cost, int cstride, Counters *cnt)
 {
 	typedef DenseSmem<R, NCB, CHUNK> Smem;
 	static bool attr = false;
@@ -693,19 +657,19 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
 		attr = true;
 	}
 	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>), grid, dim3(DC_THREADS), sizeof(Smem), st,
-	                   views, ref, oth, P, y0, nrows, wbuf, wstride, ext, cost, cstride, cnt,
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt,
 	                   getenv("SRH_DENSE_DBG") ? atoi(getenv("SRH_DENSE_DBG")) : 0);
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const Extent *ext, double *cost, int cstride, Counters *cnt)
+                               const double *tnum, double *cost, int cstride, Counters *cnt)
 {
 	const int tiles = (width + DC_TP - 1)/DC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
 	static int variant = -1;
 	if (variant < 0) { const char *v = getenv("SRH_DENSE_VARIANT"); variant = v ? atoi(v) : 0; }
-#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, ext, cost, cstride, cnt
+#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt
 	switch (P.window_radius) {
 	case 5:
 		switch (variant) {
@@ -726,12 +690,21 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 // ------------------------------------------------------------------ scan: walk + look-up + WTA
 struct TwoViewLookupVisitor {
 	const double *crow;
-	int xmin;
+	int x, y, lo, hi, cover_hi;
 	const srh_params &P;
+	const ViewDev &L, &Rv;
+	const double *wq;
+	size_t wstride;
 	double minCost, secondBest;
 	int wx, wy;
+	unsigned n, n_lazy;
+	bool violated;
 	__device__ __forceinline__ void operator()(int cx, int cy) {
-		const double cost = crow[cx - xmin];
+		++n;
+		if (cy != y || cx < lo || cx > hi) { violated = true; return; }   // not the row-aligned case after all
+		double cost;
+		if (cx <= cover_hi) cost = crow[cx - lo];
+		else { cost = tv_cost(L, Rv, wq, wstride, P, x, y, cx, cy); ++n_lazy; }   // column left out by the dense kernel
 		if (cost + P.wta_margin < minCost) {                   // twoviewstereo.cpp:293-301
 			secondBest = minCost;
 			minCost = cost;
@@ -741,35 +714,61 @@ struct TwoViewLookupVisitor {
 };
 
 __global__ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
-                                    int y0, int nrows, const Extent *__restrict__ ext,
-                                    const double *__restrict__ cost, int cstride)
+                                    int y0, int nrows, const double *__restrict__ tnum,
+                                    const double *__restrict__ cost, int cstride,
+                                    const double *__restrict__ wbuf, size_t wstride, int ncb, int lanes,
+                                    Counters *__restrict__ cnt)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
 	const int W = L.w;
 	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
-	if (q >= (size_t)nrows*W) return;
-	const int x = (int)(q % W), y = y0 + (int)(q / W);
-	const size_t pv = (size_t)y*W + x;
-	double depth = __builtin_nan("");
-	if (L.mask[pv] == 1) {
-		const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-		TwoViewLookupVisitor vis = { cost + q*(size_t)cstride, ext[q].xmin, P, __builtin_inf(), __builtin_inf(), -1, -1 };
-		walk_curve<false>(ray, L.cam, Rv, P, vis);
-		if (vis.wx >= 0)
-			depth = candidate_depth(L.cam, Rv.cam, P, ray, vis.wx, vis.wy);
-		if (vis.minCost > P.second_best_factor*vis.secondBest)
-			depth = __builtin_inf();
+	unsigned n_eval = 0, n_pix = 0, bad = 0, n_lazy = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), y = y0 + (int)(q / W);
+		const size_t pv = (size_t)y*W + x;
+		double depth = __builtin_nan("");
+		if (L.mask[pv] == 1) {
+			n_pix = 1;
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			int lo, hi;
+			pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
+			const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+			TwoViewLookupVisitor vis = { cost + q*(size_t)cstride, x, y, lo, hi,
+			                             hi >= lo ? dense_cover_hi(lo, hi, ncb, lanes) : hi, P, L, Rv,
+			                             wbuf + wbuf_offset(W, T, (int)(q / W), x), wstride,
+			                             __builtin_inf(), __builtin_inf(), -1, -1, 0, 0, false };
+			walk_curve_pinhole(ray, L.cam, Rv, P, tnum, vis);
+			n_eval = vis.n;
+			n_lazy = vis.n_lazy;
+			bad = vis.violated ? 1 : 0;
+			if (vis.wx >= 0)
+				depth = candidate_depth(L.cam, Rv.cam, P, ray, vis.wx, vis.wy);
+			if (vis.minCost > P.second_best_factor*vis.secondBest)
+				depth = __builtin_inf();
+		}
+		L.depth[pv] = depth;
 	}
-	L.depth[pv] = depth;
+	block_count_add(&cnt->n_eval, n_eval);
+	block_count_add(&cnt->n_eval_device, n_lazy);
+	block_count_add(&cnt->n_pixels, n_pix);
+	block_count_add(&cnt->not_row_aligned, bad);
 }
 
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                         int y0, int nrows, const Extent *ext, const double *cost, int cstride)
+                         int y0, int nrows, const double *tnum, const double *cost, int cstride,
+                         const double *wbuf, size_t wstride, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
+	// block geometry of the dense kernel (dense_cover_hi must agree on both sides)
+	int ncb = 8, lanes = DC_G;
+	if (P.window_radius == 5) {
+		const char *v = getenv("SRH_DENSE_VARIANT");
+		const int variant = v ? atoi(v) : 0;
+		ncb = variant == 1 ? 6 : (variant == 2 || variant == 3 ? 4 : 8);
+	}
 	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-	                   views, ref, oth, P, y0, nrows, ext, cost, cstride);
+	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, wbuf, wstride, ncb, lanes, cnt);
 }
 
 } // namespace srh

@@ -71,12 +71,12 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride);
-void launch_twoview_extent(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                           int y0, int nrows, Extent *ext, Counters *cnt, int *max_span);
+void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, double *tnum);
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const Extent *ext, double *cost, int cstride, Counters *cnt);
+                               const double *tnum, double *cost, int cstride, Counters *cnt);
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                         int y0, int nrows, const Extent *ext, const double *cost, int cstride);
+                         int y0, int nrows, const double *tnum, const double *cost, int cstride,
+                         const double *wbuf, size_t wstride, Counters *cnt);
 
 } // namespace srh

@@ -60,6 +60,104 @@ __device__ __forceinline__ void walk_curve(const Ray &ray, const srh_camera &ref
 	}
 }
 
+// ---- pinhole fast walk -----------------------------------------------------------------
+// For an undistorted, non-refractive pair the per-label plane intersection of
+// pointFromDepth/intersect (twoviewstereo.cpp:987-995, util/ray.cpp:78-88) splits into a part
+// that depends only on the label -- t_num[d] = n . (dist_d*n - src), the ray source being the
+// camera centre for every pixel -- and one division by  n . dir  per pixel and label.  The
+// operands and operations are those of point_from_depth(), so the results are bit-identical;
+// only the redundant recomputation (normalising the plane normal, the label depth, ...) goes.
+__device__ __forceinline__ Vec3 pinhole_ray_source(const srh_camera &cam) {
+	return matvec(cam.Rinv, v3(0, 0, 0) - load3(cam.t));        // cam_unproject: out.src
+}
+
+__device__ __forceinline__ double pinhole_label_tnum(const srh_camera &refcam, const srh_params &P, bool mvs, int label) {
+	const Vec3 normal = load3(refcam.pdir);
+	const Vec3 n = normalized(normal);                          // Plane3d ctor
+	const double depth = depth_from_label(P, mvs, label);
+	const Vec3 x0 = load3(refcam.C) + normal*depth;             // p + normal*depth, p = camera centre
+	const double d = dot(n, x0);                                // Plane3d::dist_
+	const Vec3 x0p = d*n;                                       // Plane3d::x0()
+	return dot(n, x0p - pinhole_ray_source(refcam));
+}
+
+// projection of label `d` of the ray into the other (pinhole) view, in scaled pixels
+__device__ __forceinline__ bool pinhole_project_label(const Ray &ray, double nd, double tnum, const srh_camera &oth,
+                                                      double scale, double &x2, double &y2)
+{
+	const double t = tnum / nd;
+	if (t < 1e-10) return false;
+	const Vec3 point = ray.src + t*ray.dir;
+	const Vec3 pl = matvec(oth.R, point) + load3(oth.t);
+	const Vec3 pk = matvec(oth.K, pl);
+	const double z = pk.z;
+	x2 = (pk.x/z)*scale;
+	y2 = (pk.y/z)*scale;
+	return true;
+}
+
+template <class Visitor>
+__device__ __forceinline__ void walk_curve_pinhole(const Ray &ray, const srh_camera &refcam, const ViewDev &oth,
+                                                   const srh_params &P, const double *__restrict__ tnum, Visitor &vis)
+{
+	const Vec3 n = normalized(load3(refcam.pdir));
+	const double nd = dot(n, ray.dir);
+	if (fabs(nd) < 1e-10) return;                               // intersect() fails for every label
+	const int OW = oth.w, OH = oth.h;
+	double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+	for (int d = 0; d < P.num_depth_levels; ++d) {
+		double x2, y2;
+		if (!pinhole_project_label(ray, nd, tnum[d], oth.cam, P.image_scale, x2, y2)) continue;
+		if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
+		const double dx = x2 - x1, dy = y2 - y1;
+		if (!(dx*dx + dy*dy >= 1)) continue;
+		LineWalk lw;
+		lw.begin(trunc_sat(x1), trunc_sat(y1), trunc_sat(x2), trunc_sat(y2), OW, OH);
+		while (lw.has_next()) {
+			int tx, ty;
+			lw.current(tx, ty);
+			if (tx >= 0 && ty >= 0 && tx < OW && ty < OH && oth.mask[(size_t)ty*OW + tx] == 1) vis(tx, ty);
+			lw.next();
+		}
+		x1 = x2; y1 = y2;
+	}
+}
+
+// Column range [lo, hi] that contains every candidate of the pixel when the curve stays on
+// one image row: the truncated projections of the first and last label (Bresenham segments
+// between successive projections cannot leave that interval while the projection is monotone
+// in depth), clamped to the image.  The scan kernel verifies the claim for every candidate.
+__device__ __forceinline__ void pinhole_column_range(const Ray &ray, const srh_camera &refcam, const ViewDev &oth,
+                                                     const srh_params &P, const double *__restrict__ tnum,
+                                                     int max_span, int &lo, int &hi)
+{
+	lo = 0; hi = -1;
+	const Vec3 n = normalized(load3(refcam.pdir));
+	const double nd = dot(n, ray.dir);
+	if (fabs(nd) < 1e-10) return;
+	double xa, ya, xb, yb;
+	if (!pinhole_project_label(ray, nd, tnum[0], oth.cam, P.image_scale, xa, ya)) return;
+	if (!pinhole_project_label(ray, nd, tnum[P.num_depth_levels - 1], oth.cam, P.image_scale, xb, yb)) return;
+	const int ia = trunc_sat(xa), ib = trunc_sat(xb);
+	lo = (ia < ib ? ia : ib);
+	hi = (ia < ib ? ib : ia);
+	if (lo < 0) lo = 0;
+	if (hi > oth.w - 1) hi = oth.w - 1;
+	if (hi - lo + 1 > max_span) hi = lo + max_span - 1;
+}
+
+// The dense kernel evaluates the columns [lo & ~1, cover_hi] of a pixel in blocks of `ncb`
+// shared by `lanes` lanes.  When the last block would cost a whole extra round of the lanes for
+// at most two columns (typically the never-visited column of the last label plus the alignment
+// pad), it is left out: the scan evaluates such a column on demand with the general cost.
+__device__ __forceinline__ int dense_cover_hi(int lo, int hi, int ncb, int lanes) {
+	const int lo_e = lo & ~1;
+	const int nblocks = (hi - lo_e + ncb)/ncb;
+	const int last_cols = (hi - lo_e + 1) - (nblocks - 1)*ncb;
+	if (nblocks > lanes && nblocks % lanes == 1 && last_cols <= 2) return lo_e + (nblocks - 1)*ncb - 1;
+	return hi;
+}
+
 // gray value of a TwoView tap, NaN when the tap is skipped on that side
 __device__ __forceinline__ double tv_tap(const ViewDev &V, int x, int y) {
 	if (x < 0 || y < 0 || x >= V.w || y >= V.h) return __builtin_nan("");
