@@ -688,67 +688,155 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 }
 
 // ------------------------------------------------------------------ scan: walk + look-up + WTA
-struct TwoViewLookupVisitor {
-	const double *crow;
-	int x, y, lo, hi, cover_hi;
-	const srh_params &P;
-	const ViewDev &L, &Rv;
-	const double *wq;
-	size_t wstride;
+// One thread per reference pixel, one wave (64 consecutive pixels of a row) per workgroup.
+// The curve walk is pure arithmetic; what used to serialise it were two dependent global loads
+// per candidate (mask byte, cost).  Here the other view's mask row segment sits in LDS, and the
+// candidates' columns go through a small per-thread LDS queue: every SC_QN candidates their
+// costs are fetched with SC_QN independent loads and then consumed in order, so the running-min
+// scan of twoviewstereo.cpp:293-301 sees exactly the reference's candidate sequence.
+#define SC_TW 64
+#define SC_QN 16
+#define SC_MW 1024
+
+struct TwoViewScanState {
 	double minCost, secondBest;
-	int wx, wy;
-	unsigned n, n_lazy;
-	bool violated;
-	__device__ __forceinline__ void operator()(int cx, int cy) {
-		++n;
-		if (cy != y || cx < lo || cx > hi) { violated = true; return; }   // not the row-aligned case after all
-		double cost;
-		if (cx <= cover_hi) cost = crow[cx - lo];
-		else { cost = tv_cost(L, Rv, wq, wstride, P, x, y, cx, cy); ++n_lazy; }   // column left out by the dense kernel
-		if (cost + P.wta_margin < minCost) {                   // twoviewstereo.cpp:293-301
-			secondBest = minCost;
-			minCost = cost;
-			wx = cx; wy = cy;
-		}
-	}
+	int wcol;                 // winning column relative to lo, -1 = none
 };
 
-__global__ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
-                                    int y0, int nrows, const double *__restrict__ tnum,
-                                    const double *__restrict__ cost, int cstride,
-                                    const double *__restrict__ wbuf, size_t wstride, int ncb, int lanes,
-                                    Counters *__restrict__ cnt)
+__global__ __launch_bounds__(SC_TW)
+void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                         int y0, int nrows, const double *__restrict__ tnum,
+                         const double *__restrict__ cost, int cstride,
+                         const double *__restrict__ wbuf, size_t wstride, int ncb, int lanes,
+                         Counters *__restrict__ cnt)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
-	const int W = L.w;
-	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	const int W = L.w, OW = Rv.w, OH = Rv.h;
+	const int tiles_per_row = (W + SC_TW - 1)/SC_TW;
+	const int trow = blockIdx.x / tiles_per_row;
+	const int x0 = (blockIdx.x % tiles_per_row)*SC_TW;
+	const int y = y0 + trow;
+	const int tid = threadIdx.x;
+	const int x = x0 + tid;
+	const size_t q = (size_t)trow*W + x;
+
+	__shared__ unsigned short queue[SC_QN][SC_TW];
+	__shared__ unsigned char mrow[SC_MW];
+	__shared__ int s_umin;
+
 	unsigned n_eval = 0, n_pix = 0, bad = 0, n_lazy = 0;
-	if (q < (size_t)nrows*W) {
-		const int x = (int)(q % W), y = y0 + (int)(q / W);
-		const size_t pv = (size_t)y*W + x;
-		double depth = __builtin_nan("");
-		if (L.mask[pv] == 1) {
-			n_pix = 1;
-			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-			int lo, hi;
-			pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
-			const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
-			TwoViewLookupVisitor vis = { cost + q*(size_t)cstride, x, y, lo, hi,
-			                             hi >= lo ? dense_cover_hi(lo, hi, ncb, lanes) : hi, P, L, Rv,
-			                             wbuf + wbuf_offset(W, T, (int)(q / W), x), wstride,
-			                             __builtin_inf(), __builtin_inf(), -1, -1, 0, 0, false };
-			walk_curve_pinhole(ray, L.cam, Rv, P, tnum, vis);
-			n_eval = vis.n;
-			n_lazy = vis.n_lazy;
-			bad = vis.violated ? 1 : 0;
-			if (vis.wx >= 0)
-				depth = candidate_depth(L.cam, Rv.cam, P, ray, vis.wx, vis.wy);
-			if (vis.minCost > P.second_best_factor*vis.secondBest)
-				depth = __builtin_inf();
-		}
-		L.depth[pv] = depth;
+	const bool active = x < W && L.mask[(size_t)y*W + x] == 1;
+	Ray ray;
+	int lo = 0, hi = -1, cover_hi = -1;
+	if (active) {
+		ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
+		if (hi >= lo) cover_hi = dense_cover_hi(lo, hi, ncb, lanes);
 	}
+	if (tid == 0) s_umin = 2147483647;
+	__syncthreads();
+	if (hi >= lo) atomicMin(&s_umin, lo);
+	__syncthreads();
+	const int umin = s_umin;
+	// mask bytes of row y of the other view, columns [umin, umin + SC_MW)
+	for (int k = tid; k < SC_MW; k += SC_TW) {
+		const int cx = umin + k;
+		mrow[k] = (umin != 2147483647 && y >= 0 && y < OH && cx >= 0 && cx < OW) ? Rv.mask[(size_t)y*OW + cx] : 0;
+	}
+	__syncthreads();
+
+	double depth = __builtin_nan("");
+	if (active) {
+		n_pix = 1;
+		const double *crow = cost + q*(size_t)cstride;
+		const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+		const double *wq = wbuf + wbuf_offset(W, T, trow, x);
+		TwoViewScanState st = { __builtin_inf(), __builtin_inf(), -1 };
+		int qn = 0;
+
+		// consume `count` queued candidates (count == SC_QN except for the final, partial flush)
+		auto flush = [&](int count) {
+			int col[SC_QN];
+			double c[SC_QN];
+#pragma unroll
+			for (int k = 0; k < SC_QN; ++k) col[k] = queue[k][tid];
+#pragma unroll
+			for (int k = 0; k < SC_QN; ++k)
+				c[k] = (k < count && lo + col[k] <= cover_hi) ? crow[col[k]] : __builtin_inf();
+#pragma unroll
+			for (int k = 0; k < SC_QN; ++k) {
+				if (k < count) {
+					double cv = c[k];
+					if (lo + col[k] > cover_hi) {                   // column left out by the dense kernel
+						cv = tv_cost(L, Rv, wq, wstride, P, x, y, lo + col[k], y);
+						++n_lazy;
+					}
+					if (cv + P.wta_margin < st.minCost) {           // twoviewstereo.cpp:293-301
+						st.secondBest = st.minCost;
+						st.minCost = cv;
+						st.wcol = col[k];
+					}
+				}
+			}
+		};
+
+		// ---- the pinhole walk (walk_curve_pinhole), candidates pushed instead of visited
+		const Vec3 nrm = normalized(load3(L.cam.pdir));
+		const double nd = dot(nrm, ray.dir);
+		if (!(fabs(nd) < 1e-10)) {
+			double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+			for (int d = 0; d < P.num_depth_levels; ++d) {
+				double x2, y2;
+				if (!pinhole_project_label(ray, nd, tnum[d], Rv.cam, P.image_scale, x2, y2)) continue;
+				if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
+				const double dx = x2 - x1, dy = y2 - y1;
+				if (!(dx*dx + dy*dy >= 1)) continue;
+				const int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+				const int a = ix0 < ix1 ? ix0 : ix1, b = ix0 < ix1 ? ix1 : ix0;
+				if (iy0 == y && iy1 == y && a >= lo && b <= hi) {
+					// a segment inside row y: LineIterator with deltay == 0 visits (a..b, y) in
+					// ascending x whatever the direction of the segment (lineiter.hpp:96-111)
+					for (int tx = a; tx <= b; ++tx) {
+						const int k = tx - umin;
+						const bool white = (k >= 0 && k < SC_MW) ? (mrow[k] == 1) : (Rv.mask[(size_t)y*OW + tx] == 1);
+						if (white) {
+							++n_eval;
+							queue[qn][tid] = (unsigned short)(tx - lo);
+							if (++qn == SC_QN) { flush(SC_QN); qn = 0; }
+						}
+					}
+				} else {
+					LineWalk lw;
+					lw.begin(ix0, iy0, ix1, iy1, OW, OH);
+					while (lw.has_next()) {
+						int tx, ty;
+						lw.current(tx, ty);
+						if (tx >= 0 && ty >= 0 && tx < OW && ty < OH && Rv.mask[(size_t)ty*OW + tx] == 1) {
+							++n_eval;
+							if (ty != y || tx < lo || tx > hi) bad = 1;          // not row-aligned after all
+							else {
+								queue[qn][tid] = (unsigned short)(tx - lo);
+								if (++qn == SC_QN) { flush(SC_QN); qn = 0; }
+							}
+						}
+						lw.next();
+					}
+				}
+				x1 = x2; y1 = y2;
+				// flush wave-wide as soon as one lane's queue is half full: all lanes take the
+				// look-up path together instead of each on its own (divergent) schedule
+				if (__any(qn >= SC_QN/2)) { flush(qn); qn = 0; }
+			}
+		}
+		if (qn > 0) flush(qn);
+
+		if (st.wcol >= 0)
+			depth = candidate_depth(L.cam, Rv.cam, P, ray, lo + st.wcol, y);
+		if (st.minCost > P.second_best_factor*st.secondBest)
+			depth = __builtin_inf();
+	}
+	if (x < W) L.depth[(size_t)y*W + x] = depth;
 	block_count_add(&cnt->n_eval, n_eval);
 	block_count_add(&cnt->n_eval_device, n_lazy);
 	block_count_add(&cnt->n_pixels, n_pix);
@@ -767,7 +855,9 @@ void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth,
 		const int variant = v ? atoi(v) : 0;
 		ncb = variant == 1 ? 6 : (variant == 2 || variant == 3 ? 4 : 8);
 	}
-	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
+	(void)n;
+	const int tiles = (width + SC_TW - 1)/SC_TW;
+	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
 	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, wbuf, wstride, ncb, lanes, cnt);
 }
 
