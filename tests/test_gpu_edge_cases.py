@@ -1,0 +1,110 @@
+"""Edge cases of the C-ABI on the device: argument errors, degenerate inputs, cancellation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+from stereoreconstruction_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_argument_validation(hip_ctx):
+    case = cases.get_twoview("adaptive_rect", w=32, h=20, D=8)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    with pytest.raises(capi.StereoHipError) as e:
+        hip_ctx.twoview_wta(0, 0, p)
+    assert e.value.code == capi.SRH_E_INVALID
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.twoview_wta(0, 63, p)                       # empty slot
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.twoview_wta(0, 64, p)                       # slot out of range
+    bad = capi.params_twoview(num_depth_levels=1)
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.twoview_wta(0, 1, bad)
+    bad = capi.params_twoview(window_radius=0)
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.twoview_wta(0, 1, bad)
+    # unequal sizes: the reference sizes the right map from the left image (twoviewstereo.cpp:119)
+    rgba, mask, cam, dist, plane = case["views"][1]
+    hip_ctx.upload_view(2, rgba[:, :-1].copy(), mask[:, :-1].copy(), cams[1])
+    with pytest.raises(capi.StereoHipError) as e:
+        hip_ctx.twoview_wta(0, 2, p)
+    assert "equal-sized" in str(e.value)
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.mvs_initial_estimate(0, [0], capi.params_mvs())      # own neighbour
+    with pytest.raises(capi.StereoHipError) as e:
+        hip_ctx.mvs_initial_estimate(0, [1, 2, 1, 2], capi.params_mvs())
+    assert e.value.code == capi.SRH_E_UNSUPPORTED
+
+
+def test_other_view_fully_masked_and_out_of_range_depths(hip_ctx):
+    case = cases.get_twoview("geodesic_rect", w=40, h=24, D=8)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    # no candidate survives an all-zero mask of the other view: empty curve => NaN everywhere
+    rgba, mask, cam, dist, plane = case["views"][1]
+    hip_ctx.upload_view(1, rgba, np.zeros_like(mask), cams[1])
+    hip_ctx.twoview_wta(0, 1, p)
+    assert np.isnan(hip_ctx.download_depth(0)).all()
+    assert hip_ctx.stats()["n_eval"] == 0
+    hip_ctx.upload_view(1, rgba, mask, cams[1])
+    # a depth range that projects outside the other image: same answer as the oracle (all NaN)
+    far = dict(case["params"], min_depth=1e-3, max_depth=2e-3)
+    p2 = capi.params_twoview(**far)
+    op2 = O.params_twoview(**far)
+    hip_ctx.twoview_wta(0, 1, p2)
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op2)
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), want, 1e-9)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("radius", [1, 3, 4])
+def test_other_window_radii_use_the_general_kernels(hip_ctx, radius):
+    case = cases.get_twoview("geodesic_rect", w=44, h=26, D=10, radius=radius)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.twoview_wta(0, 1, p)
+    assert not hip_ctx.stats()["used_dense_path"]
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), want, 1e-9)
+    assert ok, msg
+
+
+def test_cancel_flag_is_honoured(hip_ctx):
+    case = cases.get_twoview("adaptive_rect", w=32, h=20, D=8)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    flag = C.c_int(1)
+    hip_ctx.set_hooks(flag, None)
+    try:
+        with pytest.raises(capi.StereoHipError) as e:
+            hip_ctx.twoview_wta(0, 1, p)
+        assert e.value.code == capi.SRH_E_CANCELLED
+    finally:
+        hip_ctx.set_hooks(None, None)
+    hip_ctx.twoview_wta(0, 1, p)                             # and works again afterwards
+
+
+def test_mvs_topk_peaks_match_oracle(hip_ctx):
+    """The sorted top-K (cost, depth) list the MRF branch would consume (multiviewstereo.cpp:600-602)."""
+    import torch
+    case = cases.get_mvs("mvs_geodesic", w=40, h=28, D=16, nviews=3)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    neigh = O.mvs_neighbours(ocams, op)
+    want_d, want_pk, _ = O.mvs_initial_estimate(imgs, ocams, 0, neigh[0], op, want_peaks=True)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    pk = torch.zeros((28, 40, p.top_k, 2), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    hip_ctx.mvs_initial_estimate(0, neigh[0], p, peaks_dev=pk.data_ptr())
+    hip_ctx.synchronize()
+    got = pk.cpu().numpy()
+    assert np.allclose(got[..., 0], want_pk[..., 0], rtol=0, atol=1e-12)
+    assert np.allclose(got[..., 1], want_pk[..., 1], rtol=1e-9, atol=0)
+    assert (want_pk[..., 0] > 0.95).any()
