@@ -14,6 +14,8 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
+#include <cstdlib>
+
 namespace srh {
 
 static inline int grid_for(size_t n, int block, int cap) {
@@ -323,12 +325,191 @@ __global__ void mvs_generic_kernel(const ViewDev *__restrict__ views, int ref,
 	block_count_add(&cnt->n_pixels, n_pix);
 }
 
+// ------------------------------------------------------------------ MVS, window in registers
+// Same work as mvs_generic_kernel, organised for the small MVS window (r=2, 25 taps): the
+// support weights and the reference window's gray values are read once into registers, the
+// per-pixel constants of the all-taps-usable form (meanL, totalWeight, sum2, a_t) are
+// computed once, and a candidate costs 25 gathers of the other view's gray plane plus the
+// reference's arithmetic in the reference's order (multiviewstereo.cpp:113-189).
+template <int R>
+struct MvsRegVisitor {
+	static constexpr int WS = 2*R + 1, T = WS*WS;
+	const ViewDev &A;
+	const ViewDev *B;
+	const srh_params &P;
+	const Ray &ray;
+	const double *w;          // T weights
+	const double *a;          // T values w*gl - meanL (all-usable form)
+	int x, y;                 // reference pixel (the rare general form re-reads its window)
+	unsigned okL;             // bit t: reference tap usable (valid && w > cutoff)
+	bool all;
+	double tw, s2;
+	double bestCost, bestDepth;
+	double *peaks;
+	unsigned n;
+
+	__device__ __forceinline__ double cost(int cx, int cy) const {
+		const ViewDev &Bv = *B;
+		double gr[T];
+		const bool inside = cx - R >= 0 && cy - R >= 0 && cx + R < Bv.w && cy + R < Bv.h;
+		if (inside) {
+#pragma unroll
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col)
+					gr[row*WS + col] = Bv.gray[(size_t)(cy - R + row)*Bv.w + (cx - R + col)];
+		} else {
+#pragma unroll
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col) gr[row*WS + col] = mvs_tap(Bv, cx - R + col, cy - R + row);
+		}
+		if (all && inside) {
+			double mR = 0;
+#pragma unroll
+			for (int t = 0; t < T; ++t) mR += w[t]*gr[t];
+			mR /= tw;
+			double s1 = 0, s3 = 0;
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
+				const double b = w[t]*gr[t] - mR;
+				s1 += a[t]*b;
+				s3 += b*b;
+			}
+			if (s2 * s3 < 1e-10) return 0;
+			return s1 / sqrt(s2 * s3);
+		}
+		// any validity pattern: a skipped tap adds +0.0, which leaves every partial sum unchanged
+		double gl[T];
+#pragma unroll
+		for (int row = 0; row < WS; ++row)
+#pragma unroll
+			for (int col = 0; col < WS; ++col) gl[row*WS + col] = mvs_tap(A, x - R + col, y - R + row);
+		double mL = 0, mR = 0, twg = 0.0;
+#pragma unroll
+		for (int t = 0; t < T; ++t) {
+			const bool ok = ((okL >> t) & 1u) && gr[t] == gr[t];
+			const double pl = w[t]*gl[t], pr = w[t]*gr[t];
+			mL += ok ? pl : 0.0;
+			mR += ok ? pr : 0.0;
+			twg += ok ? w[t] : 0.0;
+		}
+		if (twg < 1e-10) return 0;
+		mL /= twg;
+		mR /= twg;
+		double s1 = 0, s2g = 0, s3 = 0;
+#pragma unroll
+		for (int t = 0; t < T; ++t) {
+			const bool ok = ((okL >> t) & 1u) && gr[t] == gr[t];
+			const double aa = w[t]*gl[t] - mL, bb = w[t]*gr[t] - mR;
+			const double ab = aa*bb, a2 = aa*aa, b2 = bb*bb;
+			s1 += ok ? ab : 0.0;
+			s2g += ok ? a2 : 0.0;
+			s3 += ok ? b2 : 0.0;
+		}
+		if (s2g * s3 < 1e-10) return 0;
+		return s1 / sqrt(s2g * s3);
+	}
+
+	__device__ __forceinline__ void operator()(int cx, int cy) {
+		const double c = cost(cx, cy);
+		++n;
+		if (c > P.peak_threshold) {                              // multiviewstereo.cpp:589-594
+			const double z = candidate_depth(A.cam, B->cam, P, ray, cx, cy);
+			if (c > bestCost || (c == bestCost && z > bestDepth)) { bestCost = c; bestDepth = z; }
+			if (peaks) {
+				const int K = P.top_k;
+				if (c > peaks[0] || (c == peaks[0] && z > peaks[1])) {
+					int k = 0;
+					while (k + 1 < K && (peaks[2*(k+1)] < c || (peaks[2*(k+1)] == c && peaks[2*(k+1)+1] < z))) {
+						peaks[2*k] = peaks[2*(k+1)]; peaks[2*k+1] = peaks[2*(k+1)+1];
+						++k;
+					}
+					peaks[2*k] = c; peaks[2*k+1] = z;
+				}
+			}
+		}
+	}
+};
+
+template <int R>
+__global__ __launch_bounds__(128)
+void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, int nneigh, srh_params P,
+                    int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
+                    double *__restrict__ peaks, Counters *__restrict__ cnt)
+{
+	constexpr int WS = 2*R + 1, T = WS*WS;
+	const ViewDev &A = views[ref];
+	const int W = A.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	unsigned n_eval = 0, n_pix = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), y = y0 + (int)(q / W);
+		const size_t pv = (size_t)y*W + x;
+		double depth = __builtin_inf();
+		double *pk = peaks ? peaks + pv*(size_t)P.top_k*2 : nullptr;
+		if (pk) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k+1] = -1.0; }
+		if (A.mask[pv] == 1) {
+			n_pix = 1;
+			const double *wq = wbuf + wbuf_offset(W, T, (int)(q / W), x);
+			double w[T], a[T];
+			unsigned okL = 0;
+			bool all = true;
+			double mL = 0, tw = 0;
+#pragma unroll
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col) {
+					const int t = row*WS + col;
+					w[t] = wq[(size_t)t*wstride];
+					a[t] = mvs_tap(A, x - R + col, y - R + row);     // gray for now
+				}
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
+				const bool ok = a[t] == a[t] && w[t] > P.weight_cutoff;
+				okL |= ok ? (1u << t) : 0u;
+				all = all && ok;
+				mL += w[t]*a[t];
+				tw += w[t];
+			}
+			double s2 = 0;
+			if (all && !(tw < 1e-10)) {
+				mL /= tw;
+#pragma unroll
+				for (int t = 0; t < T; ++t) { a[t] = w[t]*a[t] - mL; s2 += a[t]*a[t]; }
+			} else {
+				all = false;
+#pragma unroll
+				for (int t = 0; t < T; ++t) a[t] = 0.0;
+			}
+			const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			MvsRegVisitor<R> vis = { A, &A, P, ray, w, a, x, y, okL, all, tw, s2, 0.0, -1.0, pk, 0 };
+			for (int ni = 0; ni < nneigh; ++ni) {
+				const int v2 = ni == 0 ? n0 : (ni == 1 ? n1 : n2);
+				vis.B = &views[v2];
+				walk_curve<true>(ray, A.cam, views[v2], P, vis);
+			}
+			n_eval = vis.n;
+			depth = vis.bestDepth;
+		}
+		A.depth[pv] = depth;
+	}
+	block_count_add(&cnt->n_eval, n_eval);
+	block_count_add(&cnt->n_eval_device, n_eval);
+	block_count_add(&cnt->n_pixels, n_pix);
+}
+
 void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                         const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                         double *peaks, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
 	const int n0 = nneigh > 0 ? neigh[0] : 0, n1 = nneigh > 1 ? neigh[1] : 0, n2 = nneigh > 2 ? neigh[2] : 0;
+	if (P.window_radius == 2 && !getenv("SRH_MVS_GENERIC")) {
+		hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
+		                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, cnt);
+		return;
+	}
 	hipLaunchKernelGGL(mvs_generic_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
 	                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, cnt);
 }
