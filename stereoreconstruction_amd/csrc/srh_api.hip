@@ -42,6 +42,8 @@ struct ViewHost {
 	uint8_t  *mask = nullptr;
 	double   *gray = nullptr, *gray_tv = nullptr, *depth = nullptr;
 	double   *edges = nullptr;     // 4 planes of neighbour colour distances (geodesic windows)
+	uint8_t  *full = nullptr;      // 1 where the whole (2*full_r+1)^2 TwoView window is usable
+	int       full_r = 0;
 	srh_camera cam;
 };
 
@@ -60,6 +62,9 @@ struct srh_context {
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
 	double *tnum = nullptr;   size_t tnum_cap = 0;      // per-label table of the pinhole walk
+	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
+	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
+	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
 	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
@@ -302,6 +307,7 @@ static void free_view(ViewHost &v) {
 	if (v.gray_tv) hipFree(v.gray_tv);
 	if (v.depth) hipFree(v.depth);
 	if (v.edges) hipFree(v.edges);
+	if (v.full) hipFree(v.full);
 	v = ViewHost();
 }
 
@@ -318,6 +324,8 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->wbuf) hipFree(c->wbuf);
 	if (c->cost) hipFree(c->cost);
 	if (c->tnum) hipFree(c->tnum);
+	if (c->lcount) hipFree(c->lcount);
+	if (c->lcand) hipFree(c->lcand);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -336,7 +344,7 @@ extern "C" int srh_set_hooks(srh_context *c, const volatile int *cancel, srh_pro
 
 extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
-	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; return SRH_OK; }
+	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
@@ -371,9 +379,11 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 		HIP_TRY(hipMalloc((void **)&v.gray_tv, n*sizeof(double)));
 		HIP_TRY(hipMalloc((void **)&v.depth, n*sizeof(double)));
 		HIP_TRY(hipMalloc((void **)&v.edges, 4*n*sizeof(double)));
+		HIP_TRY(hipMalloc((void **)&v.full, n));
 		v.w = w; v.h = h; v.present = true;
 	}
 	v.cam = *cam;
+	v.full_r = 0;                                               // recomputed on demand for the new pixels
 	HIP_TRY(hipMemcpyAsync(v.rgba, rgba, n*4, hipMemcpyHostToDevice, c->stream));
 	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
 	else      HIP_TRY(hipMemsetAsync(v.mask, 1, n, c->stream));
@@ -517,6 +527,46 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+		// ---- arbitrary geometry: candidate lists (the one-thread-per-pixel walk kernel is the last resort)
+		if (!dense && !c->force_walk && R <= 5 && W < 65536 && H < 65536) {
+			const size_t npix = (size_t)(y1 - y0)*W;
+			if ((rc = ensure(c->lcount, c->lcount_cap, npix))) return rc;
+			HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
+			{ Scope s(c, "twoview_count_kernel");
+			  launch_twoview_count(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->lcount, c->d_cnt, c->d_span); }
+			int maxc = 0;
+			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			const int cmax = std::max(8, (maxc + 7) & ~7);
+			ViewHost &O = c->views[oth];
+			if (O.full_r != R) {
+				Scope s(c, "full_window_kernel");
+				launch_full_window(c->stream, O.gray_tv, O.w, O.h, R, O.full);
+				O.full_r = R;
+			}
+			const size_t per_px = (size_t)T*sizeof(double) + (size_t)cmax*(sizeof(double) + sizeof(uint32_t));
+			size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
+			if (lrows < 1) lrows = 1;
+			if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
+			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
+			if ((rc = ensure(c->cost, c->cost_cap, lrows*W*(size_t)cmax))) return rc;
+			if ((rc = ensure(c->lcand, c->lcand_cap, lrows*W*(size_t)cmax))) return rc;
+			for (int by = y0; by < y1; by += (int)lrows) {
+				if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+				const int nr = std::min((int)lrows, y1 - by);
+				const int32_t *cnt_band = c->lcount + (size_t)(by - y0)*W;
+				run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+				{ Scope s(c, "twoview_list_kernel");
+				  launch_twoview_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax); }
+				{ Scope s(c, "twoview_list_cost_kernel");
+				  launch_twoview_list_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
+				                           cnt_band, c->lcand, c->cost, cmax, c->d_cnt); }
+				{ Scope s(c, "twoview_list_scan_kernel");
+				  launch_twoview_list_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, c->cost, cmax); }
+			}
+			HIP_TRY(hipGetLastError());
+			break;
+		}
 		if (dense) {
 			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
 			Scope s(c, "pinhole_label_table_kernel");

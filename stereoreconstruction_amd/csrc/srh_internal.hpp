@@ -79,4 +79,16 @@ void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          const double *wbuf, size_t wstride, Counters *cnt);
 
+// Candidate-list TwoView path for arbitrary geometry, srh_list.hip
+void launch_twoview_count(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                          int y0, int nrows, int32_t *count, Counters *cnt, int *max_count);
+void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                         int y0, int nrows, uint32_t *cand, int cmax);
+void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full);
+bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
+                              const int32_t *count, const uint32_t *cand, double *cost, int cmax, Counters *cnt);
+void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const int32_t *count, const uint32_t *cand, const double *cost, int cmax);
+
 } // namespace srh

@@ -36,7 +36,7 @@ def test_c2_full_size_dense_equals_general(hip_ctx):
     (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0002, capi.WEIGHT_ADAPTIVE)
     out = {}
     for mode in ("dense", "general"):
-        hip_ctx.set_option("force_generic", 1 if mode == "general" else 0)
+        hip_ctx.set_option("force_generic", 2 if mode == "general" else 0)
         dl, dr = hip_ctx.twoview_compute(0, 1, p)
         st = hip_ctx.stats()
         assert st["used_dense_path"] == (mode == "dense")

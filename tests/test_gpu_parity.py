@@ -38,6 +38,12 @@ def test_twoview_wta_and_cross_check(hip_ctx, name):
     assert ok, "left WTA: " + msg
     ok, msg, _ = cases.compare_depth(gr, dr, RTOL)
     assert ok, "right WTA: " + msg
+    # the one-thread-per-pixel curve-walk kernel (last resort) must give the same bits
+    hip_ctx.set_option("force_generic", 2)
+    hip_ctx.twoview_wta(0, 1, p)
+    walk = hip_ctx.download_depth(0)
+    hip_ctx.set_option("force_generic", 0)
+    assert np.array_equal(gl.view(np.uint64), walk.view(np.uint64)), "default path and curve-walk kernel differ"
     assert st["n_pixels"] == int((case["views"][0][1] == 1).sum())
     assert np.isfinite(dl).sum() > 0.2 * dl.size, "degenerate case: too few finite depths"
 
@@ -141,7 +147,7 @@ def _same_bits(a, b):
 ])
 def test_dense_path_matches_oracle_and_generic(hip_ctx, name, over):
     """Row-aligned geometry takes the LDS-tiled dense kernels; they must reproduce the
-    oracle and be bit-identical to the general curve-walk kernels."""
+    oracle and be bit-identical to both general-geometry paths (candidate lists, curve walk)."""
     case = cases.get_twoview(name, **over)
     imgs, ocams, op = cases.oracle_inputs(case)
     cams, p = cases.hip_inputs(case)
@@ -156,15 +162,19 @@ def test_dense_path_matches_oracle_and_generic(hip_ctx, name, over):
         assert st["used_dense_path"], "rectified case did not take the dense path"
         assert st["n_eval"] == diag["n_eval"]                   # candidates the reference evaluates
         assert st["n_eval_device"] <= st["n_eval"]              # joint duplicates are evaluated once
-        hip_ctx.set_option("force_generic", 1)
-        hip_ctx.twoview_wta(ref, oth, p)
-        generic = hip_ctx.download_depth(ref)
+        others = {}
+        for mode, tag in ((1, "candidate-list"), (2, "curve-walk")):       # the two general-geometry paths
+            hip_ctx.set_option("force_generic", mode)
+            hip_ctx.twoview_wta(ref, oth, p)
+            others[tag] = hip_ctx.download_depth(ref)
+            st2 = hip_ctx.stats()
+            assert not st2["used_dense_path"] and st2["n_eval"] == diag["n_eval"]
         hip_ctx.set_option("force_generic", 0)
         hip_ctx.set_option("band_budget_mb", 1536)
-        assert not hip_ctx.stats()["used_dense_path"]
         ok, msg, _ = cases.compare_depth(dense, want, RTOL)
         assert ok, "dense vs oracle (ref %d): %s" % (ref, msg)
-        assert _same_bits(dense, generic), "dense and general kernels differ (ref %d)" % ref
+        for tag, other in others.items():
+            assert _same_bits(dense, other), "dense and %s kernels differ (ref %d)" % (tag, ref)
 
 
 def test_non_aligned_geometry_falls_back(hip_ctx):
