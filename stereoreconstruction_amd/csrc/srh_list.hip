@@ -248,14 +248,22 @@ void twoview_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				// fast form: every tap usable on both sides (twoviewstereo.cpp:917-976 with constant meanL,
 				// totalWeight, sum2 and a_t): p = w*gr; meanR += p;  b = p - meanR; sum1 += a*b; sum3 += b*b
 				const double *rbase = Rv.gray_tv + (size_t)(cy - R)*OW + (cx - R);
+				// the gathers of window row r+1 are issued before the arithmetic of row r
+				double gn[WS];
+#pragma unroll
+				for (int col = 0; col < WS; ++col) gn[col] = rbase[col];
 				double mR = 0;
 #pragma unroll 1
 				for (int row = 0; row < WS; ++row) {
 					double gr[WS], wv[WS];
 #pragma unroll
-					for (int col = 0; col < WS; ++col) gr[col] = rbase[(size_t)row*OW + col];
+					for (int col = 0; col < WS; ++col) gr[col] = gn[col];
+					const double *rn = rbase + (size_t)(row + 1 < WS ? row + 1 : 0)*OW;     // last: row 0 again, for pass 2
+#pragma unroll
+					for (int col = 0; col < WS; ++col) gn[col] = rn[col];
 #pragma unroll
 					for (int col = 0; col < WS; ++col) wv[col] = CS.w[i][row*WP + col];
+					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 					for (int col = 0; col < WS; ++col) mR += wv[col]*gr[col];
 				}
@@ -265,9 +273,13 @@ void twoview_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				for (int row = 0; row < WS; ++row) {
 					double gr[WS], wv[WS], av[WS];
 #pragma unroll
-					for (int col = 0; col < WS; ++col) gr[col] = rbase[(size_t)row*OW + col];
+					for (int col = 0; col < WS; ++col) gr[col] = gn[col];
+					const double *rn = rbase + (size_t)(row + 1 < WS ? row + 1 : 0)*OW;
+#pragma unroll
+					for (int col = 0; col < WS; ++col) gn[col] = rn[col];
 #pragma unroll
 					for (int col = 0; col < WS; ++col) { wv[col] = CS.w[i][row*WP + col]; av[col] = CS.lt[row][i + col]; }
+					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 					for (int col = 0; col < WS; ++col) {
 						const double a = wv[col]*av[col] - mL;
