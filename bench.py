@@ -84,10 +84,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SRH_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the
+    # visible GPUs and the gather goes through host memory.  The measured configuration is "nccl" (RCCL).
+    backend = os.environ.get("SRH_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W, H, D, wkind, seed, desc = WORKLOADS[args.workload]
     # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair
@@ -104,7 +111,7 @@ def main():
         cl, cr = capi.camera_from_krt(Kl, Rl, tl), capi.camera_from_krt(Kr, Rr, tr)
     p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
@@ -118,7 +125,10 @@ def main():
         ctx.copy_depth_to_device(0, out[0].data_ptr())
         ctx.copy_depth_to_device(1, out[1].data_ptr())
         nonlocal gathered
-        gathered = gather_depth_maps(out, dst=0)   # RCCL over xGMI: per-view depth maps to rank 0
+        if backend == "nccl":
+            gathered = gather_depth_maps(out, dst=0)   # RCCL over xGMI: per-view depth maps to rank 0
+        else:
+            gathered = gather_depth_maps(out.cpu(), dst=0)
 
     def fence():
         if world > 1:
@@ -137,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -176,7 +186,7 @@ def main():
             "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
                        "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
-                       "pairs_per_gpu": 1, "parallelism": "pairs sharded, RCCL gather" if world > 1 else "single GPU",
+                       "pairs_per_gpu": 1, "parallelism": ("pairs sharded, %s gather" % ("RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                        "dense_path": bool(stats["used_dense_path"]),
                        "n_eval_reference_last_pass": stats["n_eval"],
                        "n_eval_device_last_pass": stats["n_eval_device"]},
