@@ -170,6 +170,20 @@ int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *ne
 int  srh_mvs_cross_check(srh_context *ctx, const int32_t *slots, int nviews, int view_index,
                          const srh_params *p);
 
+/* ---- multi-GPU exchange (RCCL over xGMI; one process and one context per GPU) ----
+ * srh_comm_unique_id: rank 0 creates the 128-byte id and hands it to the other ranks by any
+ * means (MPI, files, torch.distributed ...).  srh_comm_init is collective.  librccl is loaded on
+ * first use; SRH_E_UNSUPPORTED if it is absent. */
+#define SRH_COMM_ID_BYTES 128
+int  srh_comm_unique_id(void *id_out);
+int  srh_comm_init(srh_context *ctx, int nranks, int rank, const void *id);
+/* Gather the depth map of `slot` (w*h doubles, equal on all ranks) to `root`:
+ * recv_dev (DEVICE, nranks*w*h doubles, rank order) is written on the root only. */
+int  srh_comm_gather_depth(srh_context *ctx, int slot, int root, void *recv_dev);
+/* Every rank receives every rank's map of `slot` (MVS cross-check input). */
+int  srh_comm_allgather_depth(srh_context *ctx, int slot, void *recv_dev);
+int  srh_comm_destroy(srh_context *ctx);
+
 /* ---- measurement ---- */
 int  srh_get_stats(srh_context *ctx, srh_stats *out);
 /* When enabled every kernel launch is bracketed by hipEvents on the context

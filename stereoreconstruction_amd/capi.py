@@ -69,6 +69,7 @@ EXPORTS = [
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check",
+    "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
 ]
 
@@ -120,6 +121,11 @@ def lib():
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
     L.srh_mvs_initial_estimate.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.c_int, C.c_int, vp]
     L.srh_mvs_cross_check.argtypes = [vp, c_int32_p, C.c_int, C.c_int, C.POINTER(Params)]
+    L.srh_comm_unique_id.argtypes = [vp]
+    L.srh_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.srh_comm_gather_depth.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.srh_comm_allgather_depth.argtypes = [vp, C.c_int, vp]
+    L.srh_comm_destroy.argtypes = [vp]
     L.srh_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.srh_profile_enable.argtypes = [vp, C.c_int]
     L.srh_profile_reset.argtypes = [vp]
@@ -293,6 +299,25 @@ class Context:
     def mvs_cross_check(self, slots, view_index, p):
         s = np.ascontiguousarray(slots, dtype=np.int32)
         _check(lib().srh_mvs_cross_check(self._h, s.ctypes.data_as(c_int32_p), len(s), view_index, C.byref(p)))
+
+    # -- multi-GPU exchange (RCCL)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().srh_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        _check(lib().srh_comm_init(self._h, nranks, rank, C.c_char_p(unique_id)))
+
+    def comm_gather_depth(self, slot, root, recv_dev_ptr):
+        _check(lib().srh_comm_gather_depth(self._h, slot, root, C.c_void_p(recv_dev_ptr)))
+
+    def comm_allgather_depth(self, slot, recv_dev_ptr):
+        _check(lib().srh_comm_allgather_depth(self._h, slot, C.c_void_p(recv_dev_ptr)))
+
+    def comm_destroy(self):
+        _check(lib().srh_comm_destroy(self._h))
 
     # -- measurement
     def stats(self):

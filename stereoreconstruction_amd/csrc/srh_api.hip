@@ -65,6 +65,7 @@ struct srh_context {
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
+	void *comm = nullptr; int comm_ranks = 0, comm_rank = 0;   // RCCL communicator (srh_comm_init)
 	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
@@ -326,6 +327,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->tnum) hipFree(c->tnum);
 	if (c->lcount) hipFree(c->lcount);
 	if (c->lcand) hipFree(c->lcand);
+	if (c->comm) rccl_comm_destroy(c->comm);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -700,6 +702,53 @@ extern "C" int srh_mvs_cross_check(srh_context *c, const int32_t *slots, int nvi
 	{ Scope s(c, "mvs_cross_check_kernel");
 	  launch_mvs_cross_check(c->stream, c->d_views, c->d_slots, nviews, view_index, A.w, A.h, *p); }
 	HIP_TRY(hipGetLastError());
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU exchange
+extern "C" int srh_comm_unique_id(void *id_out) {
+	if (!id_out) return fail(SRH_E_INVALID, "null id buffer");
+	if (const char *e = rccl_unique_id_get(id_out)) return fail(SRH_E_UNSUPPORTED, "RCCL: %s", e);
+	return SRH_OK;
+}
+
+extern "C" int srh_comm_init(srh_context *c, int nranks, int rank, const void *id) {
+	if (!c || !id) return fail(SRH_E_INVALID, "null argument");
+	if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SRH_E_INVALID, "rank %d of %d", rank, nranks);
+	HIP_TRY(hipSetDevice(c->device));
+	if (c->comm) { rccl_comm_destroy(c->comm); c->comm = nullptr; }
+	if (const char *e = rccl_comm_init(&c->comm, nranks, rank, id)) return fail(SRH_E_UNSUPPORTED, "RCCL: %s", e);
+	c->comm_ranks = nranks; c->comm_rank = rank;
+	return SRH_OK;
+}
+
+extern "C" int srh_comm_gather_depth(srh_context *c, int slot, int root, void *recv_dev) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!c->comm) return fail(SRH_E_INVALID, "srh_comm_init has not been called");
+	if (root < 0 || root >= c->comm_ranks) return fail(SRH_E_INVALID, "root %d of %d", root, c->comm_ranks);
+	if (c->comm_rank == root && !recv_dev) return fail(SRH_E_INVALID, "null receive buffer on the root");
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	if (const char *e = rccl_gather_f64(c->comm, c->comm_ranks, c->comm_rank, root, v.depth, (double *)recv_dev,
+	                                    (size_t)v.w*v.h, c->stream))
+		return fail(SRH_E_DEVICE, "RCCL gather: %s", e);
+	return SRH_OK;
+}
+
+extern "C" int srh_comm_allgather_depth(srh_context *c, int slot, void *recv_dev) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!c->comm) return fail(SRH_E_INVALID, "srh_comm_init has not been called");
+	if (!recv_dev) return fail(SRH_E_INVALID, "null receive buffer");
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	if (const char *e = rccl_allgather_f64(c->comm, v.depth, (double *)recv_dev, (size_t)v.w*v.h, c->stream))
+		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
+	return SRH_OK;
+}
+
+extern "C" int srh_comm_destroy(srh_context *c) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (c->comm) { rccl_comm_destroy(c->comm); c->comm = nullptr; c->comm_ranks = 0; }
 	return SRH_OK;
 }
 

@@ -91,4 +91,12 @@ bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int
 void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, const double *cost, int cmax);
 
+// RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
+const char *rccl_unique_id_get(void *out128);
+const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);
+void rccl_comm_destroy(void *comm);
+const char *rccl_gather_f64(void *comm, int nranks, int rank, int root, const double *send, double *recv,
+                            size_t count, hipStream_t st);
+const char *rccl_allgather_f64(void *comm, const double *send, double *recv, size_t count, hipStream_t st);
+
 } // namespace srh

@@ -108,3 +108,33 @@ def test_mvs_topk_peaks_match_oracle(hip_ctx):
     assert np.allclose(got[..., 0], want_pk[..., 0], rtol=0, atol=1e-12)
     assert np.allclose(got[..., 1], want_pk[..., 1], rtol=1e-9, atol=0)
     assert (want_pk[..., 0] > 0.95).any()
+
+
+def test_rccl_exchange_single_rank(hip_ctx):
+    """The C-ABI's RCCL gather / all-gather on a one-rank communicator (all a 1-GPU box allows):
+    exercises the lazy librccl load, communicator set-up and the device-to-device paths."""
+    import torch
+    case = cases.get_twoview("adaptive_rect", w=32, h=20, D=8)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.twoview_wta(0, 1, p)
+    want = hip_ctx.download_depth(0)
+    uid = capi.Context.comm_unique_id()
+    assert len(uid) == 128
+    hip_ctx.comm_init(1, 0, uid)
+    try:
+        a = torch.zeros((1, 20, 32), dtype=torch.float64, device="cuda:0")
+        b = torch.zeros((1, 20, 32), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        hip_ctx.comm_gather_depth(0, 0, a.data_ptr())
+        hip_ctx.comm_allgather_depth(0, b.data_ptr())
+        hip_ctx.synchronize()
+        for t in (a, b):
+            got = t.cpu().numpy()[0]
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        with pytest.raises(capi.StereoHipError):
+            hip_ctx.comm_gather_depth(0, 3, a.data_ptr())          # root outside the communicator
+    finally:
+        hip_ctx.comm_destroy()
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.comm_allgather_depth(0, 1)                          # no communicator any more
