@@ -65,6 +65,7 @@ struct srh_context {
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
+	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
 	void *comm = nullptr; int comm_ranks = 0, comm_rank = 0;   // RCCL communicator (srh_comm_init)
 	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
@@ -533,38 +534,53 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		if (!dense && !c->force_walk && R <= 5 && W < 65536 && H < 65536) {
 			const size_t npix = (size_t)(y1 - y0)*W;
 			if ((rc = ensure(c->lcount, c->lcount_cap, npix))) return rc;
-			HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
-			{ Scope s(c, "twoview_count_kernel");
-			  launch_twoview_count(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->lcount, c->d_cnt, c->d_span); }
-			int maxc = 0;
-			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-			HIP_TRY(hipStreamSynchronize(c->stream));
-			const int cmax = std::max(8, (maxc + 7) & ~7);
 			ViewHost &O = c->views[oth];
 			if (O.full_r != R) {
 				Scope s(c, "full_window_kernel");
 				launch_full_window(c->stream, O.gray_tv, O.w, O.h, R, O.full);
 				O.full_r = R;
 			}
-			const size_t per_px = (size_t)T*sizeof(double) + (size_t)cmax*(sizeof(double) + sizeof(uint32_t));
-			size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
-			if (lrows < 1) lrows = 1;
-			if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
-			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
-			if ((rc = ensure(c->cost, c->cost_cap, lrows*W*(size_t)cmax))) return rc;
-			if ((rc = ensure(c->lcand, c->lcand_cap, lrows*W*(size_t)cmax))) return rc;
-			for (int by = y0; by < y1; by += (int)lrows) {
-				if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
-				const int nr = std::min((int)lrows, y1 - by);
-				const int32_t *cnt_band = c->lcount + (size_t)(by - y0)*W;
-				run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
-				{ Scope s(c, "twoview_list_kernel");
-				  launch_twoview_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax); }
-				{ Scope s(c, "twoview_list_cost_kernel");
-				  launch_twoview_list_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
-				                           cnt_band, c->lcand, c->cost, cmax, c->d_cnt); }
-				{ Scope s(c, "twoview_list_scan_kernel");
-				  launch_twoview_list_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, c->cost, cmax); }
+			// list capacity: the longest list seen so far on this context (hint), or a counting
+			// pass the first time; a run that overflows its capacity is repeated with the true maximum
+			int cmax = c->list_cmax_hint;
+			if (cmax <= 0) {
+				HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
+				{ Scope s(c, "twoview_count_kernel");
+				  launch_twoview_count(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->lcount, c->d_cnt, c->d_span); }
+				int maxc = 0;
+				HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipStreamSynchronize(c->stream));
+				cmax = std::max(8, (maxc + 7) & ~7);
+			}
+			for (int pass = 0; pass < 3; ++pass) {
+				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+				HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
+				const size_t per_px = (size_t)T*sizeof(double) + (size_t)cmax*(sizeof(double) + sizeof(uint32_t));
+				size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
+				if (lrows < 1) lrows = 1;
+				if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
+				if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
+				if ((rc = ensure(c->cost, c->cost_cap, lrows*W*(size_t)cmax))) return rc;
+				if ((rc = ensure(c->lcand, c->lcand_cap, lrows*W*(size_t)cmax))) return rc;
+				for (int by = y0; by < y1; by += (int)lrows) {
+					if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+					const int nr = std::min((int)lrows, y1 - by);
+					int32_t *cnt_band = c->lcount + (size_t)(by - y0)*W;
+					run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+					{ Scope s(c, "twoview_list_kernel");
+					  launch_twoview_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
+					                      cnt_band, c->d_cnt, c->d_span); }
+					{ Scope s(c, "twoview_list_cost_kernel");
+					  launch_twoview_list_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
+					                           cnt_band, c->lcand, c->cost, cmax, c->d_cnt); }
+					{ Scope s(c, "twoview_list_scan_kernel");
+					  launch_twoview_list_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, c->cost, cmax); }
+				}
+				int maxc = 0;
+				HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipStreamSynchronize(c->stream));
+				if (maxc <= cmax) { if (cmax > c->list_cmax_hint) c->list_cmax_hint = cmax; break; }
+				cmax = (maxc + 7) & ~7;                               // hint too small: repeat with the true maximum
 			}
 			HIP_TRY(hipGetLastError());
 			break;

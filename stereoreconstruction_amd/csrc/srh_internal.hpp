@@ -83,7 +83,7 @@ void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth,
 void launch_twoview_count(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                           int y0, int nrows, int32_t *count, Counters *cnt, int *max_count);
 void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                         int y0, int nrows, uint32_t *cand, int cmax);
+                         int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count);
 void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full);
 bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,

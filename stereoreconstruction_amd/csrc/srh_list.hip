@@ -72,26 +72,44 @@ struct ListVisitor {
 	}
 };
 
+// Writes the candidate list of every pixel (up to cmax entries), its full length count[q], the
+// longest list of the launch and the work counters: when the caller's cmax (a hint kept from an
+// earlier run on the same rig) turns out too small, it reruns with the reported maximum.
 __global__ void twoview_list_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
-                                    int y0, int nrows, uint32_t *__restrict__ cand, int cmax)
+                                    int y0, int nrows, uint32_t *__restrict__ cand, int cmax,
+                                    int32_t *__restrict__ count, Counters *__restrict__ cnt, int *__restrict__ max_count)
 {
 	const ViewDev &L = views[ref];
 	const int W = L.w;
 	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
-	if (q >= (size_t)nrows*W) return;
-	const int x = (int)(q % W), y = y0 + (int)(q / W);
-	if (L.mask[(size_t)y*W + x] != 1) return;
-	const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-	ListVisitor vis = { cand + q*(size_t)cmax, cmax, 0 };
-	walk_curve<false>(ray, L.cam, views[oth], P, vis);
+	unsigned n_eval = 0, n_pix = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), y = y0 + (int)(q / W);
+		if (L.mask[(size_t)y*W + x] == 1) {
+			n_pix = 1;
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			ListVisitor vis = { cand + q*(size_t)cmax, cmax, 0 };
+			walk_curve<false>(ray, L.cam, views[oth], P, vis);
+			n_eval = (unsigned)vis.n;
+		}
+		count[q] = (int32_t)n_eval;
+	}
+	__shared__ int s_max;
+	if (threadIdx.x == 0) s_max = 0;
+	__syncthreads();
+	if (n_eval) atomicMax(&s_max, (int)n_eval);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_max > 0) atomicMax(max_count, s_max);
+	block_count_add(&cnt->n_eval, n_eval);
+	block_count_add(&cnt->n_pixels, n_pix);
 }
 
 void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                         int y0, int nrows, uint32_t *cand, int cmax)
+                         int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count)
 {
 	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(twoview_list_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-	                   views, ref, oth, P, y0, nrows, cand, cmax);
+	                   views, ref, oth, P, y0, nrows, cand, cmax, count, cnt, max_count);
 }
 
 // ------------------------------------------------------------------ fully usable windows of a view
