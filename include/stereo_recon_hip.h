@@ -145,8 +145,13 @@ int  srh_view_depth_copy_to_device(srh_context *ctx, int slot, void *dst_dev);
 /* ---- TwoViewStereo ----
  * One pass of computeCostVolumes (twoviewstereo.cpp:260-333 with ref=left,
  * :431-501 with ref=right): depth map of `ref_slot` against `oth_slot`, rows
- * [y0,y1) (y1<=0: all).  Asynchronous on the context stream; result stays in the
- * slot's device depth map. */
+ * [y0,y1) (y1<=0: all).  The result stays in the slot's device depth map.  Kernels are
+ * enqueued on the context stream; the call returns after the run's verification / sizing
+ * read-backs (one or two stream synchronisations), results need no further synchronisation
+ * before srh_view_depth_* / srh_twoview_cross_check on the same context.
+ * Three implementations produce identical bits: dense row-aligned kernels (rectified
+ * pinhole rigs, radius 5 or 2), candidate-list kernels (any geometry, radius <= 5), and a
+ * one-thread-per-pixel curve-walk kernel (last resort). */
 int  srh_twoview_wta(srh_context *ctx, int ref_slot, int oth_slot, const srh_params *p,
                      int y0, int y1);
 /* crossCheck (twoviewstereo.cpp:596-672): left pass, then right pass reading the
