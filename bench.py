@@ -125,6 +125,8 @@ def main():
         ctx.copy_depth_to_device(0, out[0].data_ptr())
         ctx.copy_depth_to_device(1, out[1].data_ptr())
         nonlocal gathered
+        if world > 1:
+            ctx.synchronize()      # the library's stream and torch's (legacy default) stream are not ordered
         if backend == "nccl":
             gathered = gather_depth_maps(out, dst=0)   # RCCL over xGMI: per-view depth maps to rank 0
         else:

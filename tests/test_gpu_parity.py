@@ -187,3 +187,49 @@ def test_non_aligned_geometry_falls_back(hip_ctx):
     want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
     ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), want, RTOL)
     assert ok, msg
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_rigs(hip_ctx, seed):
+    """Randomised two-view rigs (rotation, baseline direction, focal lengths, distortion, masks,
+    refraction, scale, radius, weight kind): the default path against the oracle."""
+    rng = np.random.default_rng(seed)
+    w, h, D = int(rng.integers(36, 72)), int(rng.integers(24, 44)), int(rng.integers(6, 20))
+    L, R, ml, mr, _ = cases.S.rectified_pair(w, h, D, 0x5EED0D00 + seed)
+    scale = float(rng.choice([1.0, 1.0, 0.5]))
+    f = w * rng.uniform(0.8, 1.3) / scale
+    def K():
+        return np.array([[f * rng.uniform(0.97, 1.03), 0, (w / 2 + rng.uniform(-3, 3)) / scale],
+                         [0, f * rng.uniform(0.97, 1.03), (h / 2 + rng.uniform(-3, 3)) / scale], [0, 0, 1.0]])
+    def rot(sc):
+        a = rng.uniform(-sc, sc, 3)
+        return cases._rot_z(a[2]) @ cases._rot_x(a[0]) @ cases._rot_y(a[1])
+    Rl, Rr = rot(0.03), rot(0.06)
+    Cl = np.zeros(3)
+    Cr = np.array([1.0, rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1)])
+    dist = (lambda: np.array([rng.uniform(-0.2, 0.1), rng.uniform(-0.3, 0.3), rng.uniform(-5e-3, 5e-3),
+                              rng.uniform(-5e-3, 5e-3), rng.uniform(-0.5, 0.5)])) if rng.random() < 0.6 else (lambda: None)
+    plane = (np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 1.0]), 0.1, 1.333) if rng.random() < 0.35 else None
+    if rng.random() < 0.5:
+        yy, xx = np.mgrid[0:h, 0:w]
+        ml = ((xx + yy * 0.3) % 11 != 0).astype(np.uint8)
+        mr = ((xx * 0.5 + yy) % 13 != 0).astype(np.uint8)
+    zmid = (w / scale) * scale / (8 + D / 2.0)          # f*B/d with f ~ w/scale pixels of the unscaled image ...
+    zmin, zmax = cases.S.rectified_depth_range(w, D)
+    zmin, zmax = zmin * (f * scale / w), zmax * (f * scale / w)
+    params = dict(min_depth=zmin, max_depth=zmax, num_depth_levels=D, window_radius=int(rng.integers(1, 6)),
+                  weight_kind=int(rng.integers(0, 2)), image_scale=scale)
+    case = dict(name="random%d" % seed, kind="twoview",
+                views=[(L, ml, (K(), Rl, -Rl @ Cl), dist(), plane), (R, mr, (K(), Rr, -Rr @ Cr), dist(), plane)],
+                params=params)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    total_finite = 0
+    for ref, oth in ((0, 1), (1, 0)):
+        want = O.twoview_wta(imgs[ref], imgs[oth], ocams[ref], ocams[oth], op)
+        hip_ctx.twoview_wta(ref, oth, p)
+        ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(ref), want, RTOL)
+        assert ok, "seed %d ref %d: %s" % (seed, ref, msg)
+        total_finite += int(np.isfinite(want).sum())
+    assert total_finite > 0, "degenerate random rig"
