@@ -66,6 +66,10 @@ struct srh_context {
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
 	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
+	int list_smax_hint = 0;                             // most cost slots a pixel needed so far (run-blocked lists)
+	bool list_rows = true;                              // option "list_rows": evaluate lists in row runs (srh_rows.hip)
+	uint32_t *lrowinfo = nullptr; size_t lrowinfo_cap = 0;
+	int32_t *lmeta = nullptr; size_t lmeta_cap = 0;
 	void *comm = nullptr; int comm_ranks = 0, comm_rank = 0;   // RCCL communicator (srh_comm_init)
 	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
 	const volatile int *cancel = nullptr;
@@ -292,7 +296,7 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (hipMalloc((void **)&c->d_views, sizeof(ViewDev)*SRH_MAX_VIEWS) != hipSuccess ||
 	    hipMalloc((void **)&c->d_slots, sizeof(int32_t)*SRH_MAX_VIEWS) != hipSuccess ||
 	    hipMalloc((void **)&c->d_cnt, sizeof(Counters)) != hipSuccess ||
-	    hipMalloc((void **)&c->d_span, sizeof(int)) != hipSuccess) {
+	    hipMalloc((void **)&c->d_span, 4*sizeof(int)) != hipSuccess) {
 		srh_destroy(c);
 		return fail(SRH_E_DEVICE, "hipMalloc of context tables failed");
 	}
@@ -328,6 +332,8 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->tnum) hipFree(c->tnum);
 	if (c->lcount) hipFree(c->lcount);
 	if (c->lcand) hipFree(c->lcand);
+	if (c->lrowinfo) hipFree(c->lrowinfo);
+	if (c->lmeta) hipFree(c->lmeta);
 	if (c->comm) rccl_comm_destroy(c->comm);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
@@ -347,6 +353,7 @@ extern "C" int srh_set_hooks(srh_context *c, const volatile int *cancel, srh_pro
 
 extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
+	if (!strcmp(name, "list_rows")) { c->list_rows = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
@@ -552,21 +559,41 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				HIP_TRY(hipStreamSynchronize(c->stream));
 				cmax = std::max(8, (maxc + 7) & ~7);
 			}
-			for (int pass = 0; pass < 3; ++pass) {
+			bool rows_mode = c->list_rows;
+			int smax = c->list_smax_hint > 0 ? c->list_smax_hint : cmax + 64;
+			for (int pass = 0; pass < 5; ++pass) {
 				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
-				HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
-				const size_t per_px = (size_t)T*sizeof(double) + (size_t)cmax*(sizeof(double) + sizeof(uint32_t));
+				HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
+				const int ccap = rows_mode ? smax : cmax;             // cost values per pixel
+				const size_t per_px = (size_t)T*sizeof(double) + (size_t)ccap*sizeof(double) + (size_t)cmax*sizeof(uint32_t)
+				                      + (rows_mode ? (SRH_ROWS_NR + 1)*sizeof(uint32_t) : 0);
 				size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
 				if (lrows < 1) lrows = 1;
 				if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
 				if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
-				if ((rc = ensure(c->cost, c->cost_cap, lrows*W*(size_t)cmax))) return rc;
+				if ((rc = ensure(c->cost, c->cost_cap, lrows*W*(size_t)ccap))) return rc;
 				if ((rc = ensure(c->lcand, c->lcand_cap, lrows*W*(size_t)cmax))) return rc;
+				if (rows_mode) {
+					if ((rc = ensure(c->lrowinfo, c->lrowinfo_cap, lrows*W*(size_t)SRH_ROWS_NR))) return rc;
+					if ((rc = ensure(c->lmeta, c->lmeta_cap, lrows*W))) return rc;
+				}
 				for (int by = y0; by < y1; by += (int)lrows) {
 					if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 					const int nr = std::min((int)lrows, y1 - by);
 					int32_t *cnt_band = c->lcount + (size_t)(by - y0)*W;
 					run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+					if (rows_mode) {
+						{ Scope s(c, "twoview_rows_list_kernel");
+						  launch_twoview_rows_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
+						                           cnt_band, c->lrowinfo, c->lmeta, smax, c->d_cnt, c->d_span); }
+						{ Scope s(c, "twoview_rows_cost_kernel");
+						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
+						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
+						{ Scope s(c, "twoview_rows_scan_kernel");
+						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
+						                           c->lrowinfo, c->lmeta, c->cost, smax); }
+						continue;
+					}
 					{ Scope s(c, "twoview_list_kernel");
 					  launch_twoview_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
 					                      cnt_band, c->d_cnt, c->d_span); }
@@ -576,9 +603,24 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 					{ Scope s(c, "twoview_list_scan_kernel");
 					  launch_twoview_list_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, c->cost, cmax); }
 				}
-				int maxc = 0;
-				HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+				int mx[4] = { 0, 0, 0, 0 };
+				HIP_TRY(hipMemcpyAsync(mx, c->d_span, 4*sizeof(int), hipMemcpyDeviceToHost, c->stream));
 				HIP_TRY(hipStreamSynchronize(c->stream));
+				const int maxc = mx[0];
+				if (rows_mode) {
+					// a curve crossing more than SRH_ROWS_NR rows, or more slots than the 16-bit slot base
+					// holds: this pair is evaluated in list order instead
+					const int need = (mx[1] + 7) & ~7;
+					if (mx[2] || need > 65528) { rows_mode = false; if (maxc > cmax) cmax = (maxc + 7) & ~7; continue; }
+					if (maxc <= cmax && need <= smax) {
+						if (cmax > c->list_cmax_hint) c->list_cmax_hint = cmax;
+						if (smax > c->list_smax_hint) c->list_smax_hint = smax;
+						break;
+					}
+					if (maxc > cmax) { cmax = (maxc + 7) & ~7; if (need <= smax) smax = std::max(smax, cmax + 64); }
+					if (need > smax) smax = need;
+					continue;
+				}
 				if (maxc <= cmax) { if (cmax > c->list_cmax_hint) c->list_cmax_hint = cmax; break; }
 				cmax = (maxc + 7) & ~7;                               // hint too small: repeat with the true maximum
 			}

@@ -91,6 +91,18 @@ bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int
 void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, const double *cost, int cmax);
 
+// run-blocked candidate lists, srh_rows.hip
+#define SRH_ROWS_NR 32
+void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, uint32_t *rowinfo,
+                              int32_t *meta, int smax, Counters *cnt, int *maxes);
+bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
+                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt);
+void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const int32_t *count, const uint32_t *cand, int cmax,
+                              const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax);
+
 // RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
 const char *rccl_unique_id_get(void *out128);
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);

@@ -1,0 +1,484 @@
+// srh_rows.hip -- run-blocked evaluation of candidate lists (arbitrary epipolar geometry).
+//
+// The candidate-list path of srh_list.hip gathers (2R+1)^2 values of the other view per candidate
+// and pass.  But the scan only needs *a cost per list entry*, not costs computed in list order:
+// here the distinct candidates of a pixel are regrouped by image row -- a curve crosses few rows,
+// and on each row its candidates fill (almost) a contiguous column span -- and every span is
+// evaluated in blocks of 8 adjacent columns exactly like the dense row-aligned kernel: one
+// right-image row segment of 8+2R values feeds 8 candidates x (2R+1) taps.  Costs are stored by
+// (row, column) slot; the scan walks the list in the reference's order and looks each entry up.
+//
+//   twoview_rows_list_kernel  curve walk -> candidate list + per-row column spans + slot count
+//   twoview_rows_cost_kernel  blocked weighted NCC of every slot                              (8(a) #8)
+//   twoview_rows_scan_kernel  running-min WTA over the list in order, slot look-ups           (#9,#10)
+//
+// Bit-identical to tv_cost: same operations in the same order (skipped taps add +0.0).
+#include "srh_internal.hpp"
+#include "srh_geom.hpp"
+#include "srh_walk.hpp"
+
+namespace srh {
+
+#define RW_NR 32                   // image rows a pixel's curve may cross (else: plain list path)
+#define RW_LT 128                  // threads of the list / scan kernels
+
+// ------------------------------------------------------------------ list + row spans
+struct RowsListVisitor {
+	uint32_t *out;
+	int cap, n;
+	unsigned visited;
+	uint32_t prev;
+	int ymin, ymax;
+	__device__ __forceinline__ void operator()(int cx, int cy) {
+		++visited;
+		const uint32_t e = (uint32_t)cx | ((uint32_t)cy << 16);
+		if (e == prev) return;                                  // joint duplicate: can never change the WTA state
+		prev = e;
+		if (n < cap) out[n] = e;
+		++n;
+		ymin = cy < ymin ? cy : ymin; ymax = cy > ymax ? cy : ymax;
+	}
+};
+
+// rowinfo[q*RW_NR + r] = xlo | width<<16 of image row ymin+r;  meta[q] = ymin | nrows<<16 (nrows 0: no candidates)
+__global__ __launch_bounds__(RW_LT)
+void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                              int y0, int nrows_band, uint32_t *__restrict__ cand, int cmax,
+                              int32_t *__restrict__ count, uint32_t *__restrict__ rowinfo, int32_t *__restrict__ meta, int smax,
+                              Counters *__restrict__ cnt, int *__restrict__ maxes /* [0] list length, [1] slots, [2] too many rows */)
+{
+	const ViewDev &L = views[ref];
+	const int W = L.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	__shared__ short s_lo[RW_NR][RW_LT], s_hi[RW_NR][RW_LT];
+	unsigned n_eval = 0, n_pix = 0;
+	int n_kept = 0, slots = 0, toomany = 0;
+	if (q < (size_t)nrows_band*W) {
+		const int x = (int)(q % W), y = y0 + (int)(q / W);
+		int m = 0;
+		if (L.mask[(size_t)y*W + x] == 1) {
+			n_pix = 1;
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			uint32_t *mine = cand + q*(size_t)cmax;
+			RowsListVisitor vis = { mine, cmax, 0, 0, 0xffffffffu, 2147483647, -1 };
+			walk_curve<false>(ray, L.cam, views[oth], P, vis);
+			n_eval = vis.visited;
+			n_kept = vis.n;
+			const int nr = vis.n > 0 ? vis.ymax - vis.ymin + 1 : 0;
+			if (nr > RW_NR) toomany = 1;
+			else if (nr > 0 && vis.n <= cmax) {
+				for (int r = 0; r < nr; ++r) { s_lo[r][threadIdx.x] = 32767; s_hi[r][threadIdx.x] = -1; }
+				for (int k = 0; k < vis.n; ++k) {
+					const uint32_t e = mine[k];
+					const int cx = (int)(e & 0xffffu), r = (int)(e >> 16) - vis.ymin;
+					if (cx < s_lo[r][threadIdx.x]) s_lo[r][threadIdx.x] = (short)cx;
+					if (cx > s_hi[r][threadIdx.x]) s_hi[r][threadIdx.x] = (short)cx;
+				}
+				for (int r = 0; r < nr; ++r) {
+					const int lo = s_lo[r][threadIdx.x], hi = s_hi[r][threadIdx.x];
+					const int wdt = hi >= lo ? hi - lo + 1 : 0;
+					rowinfo[q*RW_NR + r] = (uint32_t)(lo & 0xffff) | ((uint32_t)wdt << 16);
+					slots += (wdt + 7) & ~7;                             // spans are stored in whole blocks of 8
+				}
+				if (slots <= smax) m = (vis.ymin & 0xffff) | (nr << 16);   // else: capacity too small, the pass is repeated
+			}
+		}
+		count[q] = n_kept;
+		meta[q] = m;
+	}
+	__shared__ int s_max[3];
+	if (threadIdx.x < 3) s_max[threadIdx.x] = 0;
+	__syncthreads();
+	if (n_kept) atomicMax(&s_max[0], n_kept);
+	if (slots) atomicMax(&s_max[1], slots);
+	if (toomany) atomicMax(&s_max[2], 1);
+	__syncthreads();
+	if (threadIdx.x < 3 && s_max[threadIdx.x] > 0) atomicMax(&maxes[threadIdx.x], s_max[threadIdx.x]);
+	block_count_add(&cnt->n_eval, n_eval);
+	block_count_add(&cnt->n_pixels, n_pix);
+}
+
+void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, uint32_t *rowinfo,
+                              int32_t *meta, int smax, Counters *cnt, int *maxes)
+{
+	const size_t n = (size_t)nrows*width;
+	hipLaunchKernelGGL(twoview_rows_list_kernel, dim3((unsigned)((n + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
+	                   views, ref, oth, P, y0, nrows, cand, cmax, count, rowinfo, meta, smax, cnt, maxes);
+}
+
+// ------------------------------------------------------------------ blocked cost
+#define RC_TP 32
+#define RC_G 8
+#define RC_NCB 8
+#define RC_THREADS (RC_TP*RC_G)
+
+template <int R>
+struct RowsSmem {
+	static constexpr int WS = 2*R + 1;
+	static constexpr int T = WS*WS;
+	static constexpr int WP = (WS + 1) & ~1;
+	static constexpr int WPIX = WS*WP;
+	static constexpr int LW = RC_TP + 2*R;
+	double w[RC_TP][WPIX];
+	double lt[WS][LW];
+	double meanL[RC_TP], totalW[RC_TP], sum2[RC_TP];
+	int lall[RC_TP];
+	int meta[RC_TP];
+	uint32_t rowinfo[RC_TP][RW_NR];
+	unsigned short blk0[RC_TP][RW_NR + 2];                    // first 8-column block (task) of each row; [nr] = total
+};
+
+template <int R>
+__global__ __launch_bounds__(RC_THREADS, 2)
+void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                              int y0, int nrows, const double *__restrict__ wbuf,
+                              const uint8_t *__restrict__ full_oth,
+                              const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
+                              double *__restrict__ cost, int smax, Counters *__restrict__ cnt)
+{
+	constexpr int WS = 2*R + 1;
+	constexpr int T = WS*WS;
+	typedef RowsSmem<R> Smem;
+	constexpr int WP = Smem::WP;
+	constexpr int NR_ = RC_NCB + 2*R;
+	extern __shared__ __align__(16) unsigned char smem_raw[];
+	Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w, H = L.h, OW = Rv.w, OH = Rv.h;
+	const int tiles_per_row = (W + RC_TP - 1)/RC_TP;
+	const int trow = blockIdx.x / tiles_per_row;
+	const int x0 = (blockIdx.x % tiles_per_row)*RC_TP;
+	const int y = y0 + trow;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int i = (tid >> 6)*8 + (lane & 7);
+	const int g = lane >> 3;
+	const int x = x0 + i;
+	const size_t qbase = (size_t)trow*W + x0;
+	const double nan = __builtin_nan("");
+
+	// ---- stage windows, reference rows, row spans (all global loads first)
+	{
+		static_assert(RC_TP == SRH_WTILE, "tile = window-buffer tile");
+		constexpr int NBW = (T*RC_TP + RC_THREADS - 1)/RC_THREADS;
+		constexpr int NBL = (WS*Smem::LW + RC_THREADS - 1)/RC_THREADS;
+		constexpr int NBI = (RC_TP*RW_NR + RC_THREADS - 1)/RC_THREADS;
+		const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
+		double tw_[NBW], tl_[NBL];
+		uint32_t ti_[NBI];
+#pragma unroll
+		for (int k = 0; k < NBW; ++k) {
+			const int idx = tid + k*RC_THREADS;
+			tw_[k] = (idx < T*RC_TP && x0 + (idx % RC_TP) < W) ? wtile[idx] : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < NBL; ++k) {
+			const int idx = tid + k*RC_THREADS;
+			const int ty = idx / Smem::LW, tx = idx % Smem::LW;
+			const int gx = x0 - R + tx, gy = y - R + ty;
+			tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
+		}
+#pragma unroll
+		for (int k = 0; k < NBI; ++k) {
+			const int idx = tid + k*RC_THREADS;
+			const int pi = idx / RW_NR;
+			ti_[k] = (idx < RC_TP*RW_NR && x0 + pi < W) ? rowinfo[(qbase + pi)*RW_NR + idx % RW_NR] : 0u;
+		}
+		const int mt = (tid < RC_TP && x0 + tid < W) ? meta[qbase + tid] : 0;
+#pragma unroll
+		for (int k = 0; k < NBW; ++k) {
+			const int idx = tid + k*RC_THREADS;
+			const int t = idx / RC_TP, pi = idx % RC_TP;
+			if (idx < T*RC_TP) S.w[pi][(t / WS)*WP + (t % WS)] = tw_[k];
+		}
+		if (WP != WS)
+			for (int idx = tid; idx < WS*RC_TP; idx += RC_THREADS) S.w[idx % RC_TP][(idx / RC_TP)*WP + WS] = 0.0;
+#pragma unroll
+		for (int k = 0; k < NBL; ++k) {
+			const int idx = tid + k*RC_THREADS;
+			if (idx < WS*Smem::LW) S.lt[idx / Smem::LW][idx % Smem::LW] = tl_[k];
+		}
+#pragma unroll
+		for (int k = 0; k < NBI; ++k) {
+			const int idx = tid + k*RC_THREADS;
+			if (idx < RC_TP*RW_NR) S.rowinfo[idx / RW_NR][idx % RW_NR] = ti_[k];
+		}
+		if (tid < RC_TP) S.meta[tid] = mt;
+	}
+	__syncthreads();
+
+	// ---- per-pixel constants of the all-taps-usable form (one lane per pixel)
+	if (g == 0) {
+		bool all = (x < W) && (S.meta[i] >> 16) > 0;
+		double mL = 0, tw = 0;
+#pragma unroll 1
+		for (int row = 0; row < WS; ++row)
+#pragma unroll
+			for (int col = 0; col < WS; ++col) {
+				const double gl = S.lt[row][i + col];
+				const double wt = S.w[i][row*WP + col];
+				if (!(gl == gl && wt > P.weight_cutoff)) all = false;
+				mL += wt*gl;
+				tw += wt;
+			}
+		double s2 = 0;
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+#pragma unroll 1
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col) {
+					const double a = S.w[i][row*WP + col]*S.lt[row][i + col] - mL;
+					s2 += a*a;
+				}
+		} else all = false;
+		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
+		const int nr = S.meta[i] >> 16;
+		int nblk = 0;
+		for (int r = 0; r < nr; ++r) {
+			S.blk0[i][r] = (unsigned short)nblk;
+			nblk += ((int)(S.rowinfo[i][r] >> 16) + RC_NCB - 1)/RC_NCB;
+		}
+		S.blk0[i][nr] = (unsigned short)nblk;
+	}
+	__syncthreads();
+
+	unsigned n_dev = 0;
+	const Smem &CS = S;
+	if (x < W) {
+		const int m = CS.meta[i];
+		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
+		double *crow = cost + (qbase + i)*(size_t)smax;
+		const bool lall = CS.lall[i] != 0;
+		const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
+		// task t = the t-th 8-column block of the pixel's spans (rows in order); lane g takes t = g, g+8, ...
+		// its costs live in slots [8t, 8t+8)
+		const int ntask = CS.blk0[i][nr];
+		int r = 0;
+		for (int task = g; task < ntask; task += RC_G) {
+			while (task >= (int)CS.blk0[i][r + 1]) ++r;
+			{
+				const uint32_t info = CS.rowinfo[i][r];
+				const int xlo = (int)(short)(info & 0xffff), wdt = (int)(info >> 16);
+				const int b = task - (int)CS.blk0[i][r];
+				const int cy = ymin + r;
+				const int c0 = xlo + b*RC_NCB;
+				const int nv = wdt - b*RC_NCB < RC_NCB ? wdt - b*RC_NCB : RC_NCB;
+				n_dev += nv;
+				bool fast = lall;
+				for (int j = 0; j < nv; ++j) fast = fast && full_oth[(size_t)cy*OW + c0 + j] != 0;
+				double *dst = crow + (size_t)task*RC_NCB;
+				if (fast) {
+					// blocked fast form (srh_dense.hip): a row segment of NCB+2R values of the other view is
+					// read once per window row and shared by the NCB candidates and 2R+1 taps
+					const int kmax = nv - 1 + 2*R;                      // last column index a valid candidate reads
+					const double *rbase = Rv.gray_tv + (size_t)(cy - R)*OW + (c0 - R);
+					double acc[RC_NCB];
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) acc[j] = 0.0;
+#pragma unroll 1
+					for (int row = 0; row < WS; ++row) {
+						double rr[NR_], wv[WS];
+#pragma unroll
+						for (int k = 0; k < NR_; ++k) rr[k] = rbase[(size_t)row*OW + (k < kmax ? k : kmax)];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) wv[col] = CS.w[i][row*WP + col];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) {
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) acc[j] += wv[col]*rr[col + j];   // meanR += weight*gray
+						}
+					}
+					double mR[RC_NCB], s1[RC_NCB], s3[RC_NCB];
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) { mR[j] = acc[j]/tw; s1[j] = 0.0; s3[j] = 0.0; }
+#pragma unroll 1
+					for (int row = 0; row < WS; ++row) {
+						double rr[NR_], wv[WS], av[WS];
+#pragma unroll
+						for (int k = 0; k < NR_; ++k) rr[k] = rbase[(size_t)row*OW + (k < kmax ? k : kmax)];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) { wv[col] = CS.w[i][row*WP + col]; av[col] = CS.lt[row][i + col]; }
+#pragma unroll
+						for (int col = 0; col < WS; ++col) {
+							const double a = wv[col]*av[col] - mL;                    // pixel_gray_l - meanL
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) {
+								const double bb = wv[col]*rr[col + j] - mR[j];        // pixel_gray_r - meanR
+								s1[j] += a*bb;
+								s3[j] += bb*bb;
+							}
+						}
+					}
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) {
+						if (j < nv) {
+							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
+							dst[j] = (v < P.max_color_diff) ? v : P.max_color_diff;
+						}
+					}
+				} else {
+					for (int j = 0; j < nv; ++j) {
+						// any validity pattern; a skipped tap adds +0.0
+						const int cx = c0 + j;
+						double meanL = 0, meanR = 0, totalWeight = 0.0;
+#pragma unroll 1
+						for (int row = 0; row < WS; ++row) {
+							double gr[WS];
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								const int gx = cx - R + col, gy = cy - R + row;
+								gr[col] = (gx >= 0 && gy >= 0 && gx < OW && gy < OH) ? Rv.gray_tv[(size_t)gy*OW + gx] : nan;
+							}
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
+								const bool ok = gl == gl && gr[col] == gr[col] && wt > P.weight_cutoff;
+								const double pl = wt*gl, pr = wt*gr[col];
+								meanL += ok ? pl : 0.0;
+								meanR += ok ? pr : 0.0;
+								totalWeight += ok ? wt : 0.0;
+							}
+						}
+						double result;
+						if (totalWeight < 1e-10) result = P.bad_ret;
+						else {
+							meanL /= totalWeight;
+							meanR /= totalWeight;
+							double sum1 = 0, sum2 = 0, sum3 = 0;
+#pragma unroll 1
+							for (int row = 0; row < WS; ++row) {
+								double gr[WS];
+#pragma unroll
+								for (int col = 0; col < WS; ++col) {
+									const int gx = cx - R + col, gy = cy - R + row;
+									gr[col] = (gx >= 0 && gy >= 0 && gx < OW && gy < OH) ? Rv.gray_tv[(size_t)gy*OW + gx] : nan;
+								}
+#pragma unroll
+								for (int col = 0; col < WS; ++col) {
+									const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
+									const bool ok = gl == gl && gr[col] == gr[col] && wt > P.weight_cutoff;
+									const double a = wt*gl - meanL, bq = wt*gr[col] - meanR;
+									const double ab = a*bq, aa = a*a, bb = bq*bq;
+									sum1 += ok ? ab : 0.0;
+									sum2 += ok ? aa : 0.0;
+									sum3 += ok ? bb : 0.0;
+								}
+							}
+							const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
+							result = (v < P.max_color_diff) ? v : P.max_color_diff;
+						}
+						dst[j] = result;
+					}
+				}
+			}
+		}
+	}
+	block_count_add(&cnt->n_eval_device, n_dev);
+}
+
+bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
+                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt)
+{
+	const int tiles = (width + RC_TP - 1)/RC_TP;
+	const dim3 grid((unsigned)(tiles*nrows));
+#define SRH_RC_LAUNCH(RR)                                                                                   \
+	{                                                                                                       \
+		static bool attr = false;                                                                           \
+		if (!attr) { (void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR>,                  \
+		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>)); attr = true; } \
+		hipLaunchKernelGGL(twoview_rows_cost_kernel<RR>, grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
+		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt);  \
+		return true;                                                                                        \
+	}
+	switch (P.window_radius) {
+	case 1: SRH_RC_LAUNCH(1)
+	case 2: SRH_RC_LAUNCH(2)
+	case 3: SRH_RC_LAUNCH(3)
+	case 4: SRH_RC_LAUNCH(4)
+	case 5: SRH_RC_LAUNCH(5)
+	default: return false;
+	}
+#undef SRH_RC_LAUNCH
+}
+
+// ------------------------------------------------------------------ scan with slot look-ups
+#define RS_QN 16
+
+__global__ __launch_bounds__(RW_LT)
+void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                              int y0, int nrows, const int32_t *__restrict__ count,
+                              const uint32_t *__restrict__ cand, int cmax,
+                              const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
+                              const double *__restrict__ cost, int smax)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	__shared__ uint32_t s_row[RW_NR][RW_LT];                     // xlo | slot base << 16
+	if (q >= (size_t)nrows*W) return;
+	const int x = (int)(q % W), y = y0 + (int)(q / W);
+	const size_t pv = (size_t)y*W + x;
+	double depth = __builtin_nan("");
+	if (L.mask[pv] == 1) {
+		const int m = meta[q];
+		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
+		int base = 0;
+		for (int r = 0; r < nr; ++r) {
+			const uint32_t info = rowinfo[q*RW_NR + r];
+			const int wdt = (int)(info >> 16);
+			s_row[r][threadIdx.x] = (info & 0xffffu) | ((uint32_t)base << 16);
+			base += (wdt + 7) & ~7;
+		}
+		const int n = nr > 0 ? (count[q] < cmax ? count[q] : cmax) : 0;
+		const uint32_t *clist = cand + q*(size_t)cmax;
+		const double *crow = cost + q*(size_t)smax;
+		double minCost = __builtin_inf(), secondBest = __builtin_inf();
+		uint32_t win = 0xffffffffu;
+		for (int k0 = 0; k0 < n; k0 += RS_QN) {
+			uint32_t e[RS_QN];
+			double c[RS_QN];
+#pragma unroll
+			for (int j = 0; j < RS_QN; ++j) e[j] = k0 + j < n ? clist[k0 + j] : 0xffffffffu;
+#pragma unroll
+			for (int j = 0; j < RS_QN; ++j) {
+				if (k0 + j < n) {
+					const int cx = (int)(e[j] & 0xffffu), r = (int)(e[j] >> 16) - ymin;
+					const uint32_t ri = s_row[r][threadIdx.x];
+					c[j] = crow[(int)(ri >> 16) + cx - (int)(short)(ri & 0xffffu)];
+				} else c[j] = __builtin_inf();
+			}
+#pragma unroll
+			for (int j = 0; j < RS_QN; ++j) {
+				if (k0 + j < n && c[j] + P.wta_margin < minCost) {     // twoviewstereo.cpp:293-301
+					secondBest = minCost;
+					minCost = c[j];
+					win = e[j];
+				}
+			}
+		}
+		if (win != 0xffffffffu) {
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			depth = candidate_depth(L.cam, Rv.cam, P, ray, (int)(win & 0xffffu), (int)(win >> 16));
+		}
+		if (minCost > P.second_best_factor*secondBest)                 // twoviewstereo.cpp:304-305
+			depth = __builtin_inf();
+	}
+	L.depth[pv] = depth;
+}
+
+void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const int32_t *count, const uint32_t *cand, int cmax,
+                              const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax)
+{
+	const size_t n = (size_t)nrows*width;
+	hipLaunchKernelGGL(twoview_rows_scan_kernel, dim3((unsigned)((n + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
+	                   views, ref, oth, P, y0, nrows, count, cand, cmax, rowinfo, meta, cost, smax);
+}
+
+} // namespace srh

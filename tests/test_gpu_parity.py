@@ -163,13 +163,16 @@ def test_dense_path_matches_oracle_and_generic(hip_ctx, name, over):
         assert st["n_eval"] == diag["n_eval"]                   # candidates the reference evaluates
         assert st["n_eval_device"] <= st["n_eval"]              # joint duplicates are evaluated once
         others = {}
-        for mode, tag in ((1, "candidate-list"), (2, "curve-walk")):       # the two general-geometry paths
+        # the general-geometry paths: candidate lists evaluated in row runs / in list order, curve walk
+        for mode, rows, tag in ((1, 1, "row-run list"), (1, 0, "ordered list"), (2, 1, "curve-walk")):
             hip_ctx.set_option("force_generic", mode)
+            hip_ctx.set_option("list_rows", rows)
             hip_ctx.twoview_wta(ref, oth, p)
             others[tag] = hip_ctx.download_depth(ref)
             st2 = hip_ctx.stats()
             assert not st2["used_dense_path"] and st2["n_eval"] == diag["n_eval"]
         hip_ctx.set_option("force_generic", 0)
+        hip_ctx.set_option("list_rows", 1)
         hip_ctx.set_option("band_budget_mb", 1536)
         ok, msg, _ = cases.compare_depth(dense, want, RTOL)
         assert ok, "dense vs oracle (ref %d): %s" % (ref, msg)
@@ -229,7 +232,41 @@ def test_random_rigs(hip_ctx, seed):
     for ref, oth in ((0, 1), (1, 0)):
         want = O.twoview_wta(imgs[ref], imgs[oth], ocams[ref], ocams[oth], op)
         hip_ctx.twoview_wta(ref, oth, p)
-        ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(ref), want, RTOL)
+        got = hip_ctx.download_depth(ref)
+        ok, msg, _ = cases.compare_depth(got, want, RTOL)
         assert ok, "seed %d ref %d: %s" % (seed, ref, msg)
+        hip_ctx.set_option("list_rows", 0)                      # list-order evaluation: same bits
+        hip_ctx.twoview_wta(ref, oth, p)
+        hip_ctx.set_option("list_rows", 1)
+        assert _same_bits(got, hip_ctx.download_depth(ref)), "seed %d ref %d: row-run and ordered lists differ" % (seed, ref)
         total_finite += int(np.isfinite(want).sum())
     assert total_finite > 0, "degenerate random rig"
+
+
+def test_steep_curves_use_ordered_lists(hip_ctx):
+    """A vertical baseline makes every epipolar curve cross more image rows than the row-run
+    evaluation holds (32): the pair is evaluated in list order, same result as the curve walk."""
+    w, h, D = 48, 96, 60
+    L, R, ml, mr, _ = cases.S.rectified_pair(h, w, D, 0x57EE9)     # build wide, then transpose to tall
+    L = np.ascontiguousarray(np.transpose(L, (1, 0, 2))); R = np.ascontiguousarray(np.transpose(R, (1, 0, 2)))
+    f = float(h)
+    K = np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1.0]])
+    I = np.eye(3)
+    zmin, zmax = cases.S.rectified_depth_range(h, D)
+    case = dict(name="vertical", kind="twoview",
+                views=[(L, None, (K, I, np.zeros(3)), None, None), (R, None, (K, I, -np.array([0.0, 1.0, 0.0])), None, None)],
+                params=dict(min_depth=zmin, max_depth=zmax, num_depth_levels=D, window_radius=2, weight_kind=0, image_scale=1.0))
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
+    hip_ctx.twoview_wta(0, 1, p)
+    got = hip_ctx.download_depth(0)
+    assert not hip_ctx.stats()["used_dense_path"]
+    ok, msg, _ = cases.compare_depth(got, want, RTOL)
+    assert ok, msg
+    assert np.isfinite(want).sum() > 0
+    hip_ctx.set_option("force_generic", 2)
+    hip_ctx.twoview_wta(0, 1, p)
+    hip_ctx.set_option("force_generic", 0)
+    assert _same_bits(got, hip_ctx.download_depth(0))
