@@ -195,10 +195,22 @@ def device_count():
     return n.value
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; this library links the
+    system ROCm.  Both can live in one process, but the bundled runtime must attach to the GPU first
+    (the other order leaves torch with "No HIP GPUs are available").  So when the process has torch
+    loaded, its runtime is initialised before the first srh_create; torch itself is never required."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and not torch.cuda.is_initialized():
+        torch.cuda.init()
+
+
 class Context:
     """One srh_context bound to one GPU."""
 
     def __init__(self, device=0):
+        _torch_runtime_first()
         self._h = C.c_void_p()
         _check(lib().srh_create(device, C.byref(self._h)))
         self._keep = []

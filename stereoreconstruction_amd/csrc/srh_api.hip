@@ -476,6 +476,10 @@ static int fetch_counters(srh_context *c, int used_dense) {
 		fprintf(stderr, "[srh dbg] phases/wave: stage_w %.0f prologue %.0f sync %.0f stage_rt %.0f compute %.0f tail %.0f\n",
 		        (double)h.dbg_phase[0]/h.dbg_waves, (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
 		        (double)h.dbg_phase[3]/h.dbg_waves, (double)h.dbg_phase[4]/h.dbg_waves, (double)h.dbg_phase[5]/h.dbg_waves);
+	if (h.dbg_phase[6])
+		fprintf(stderr, "[srh dbg] rows: tasks %llu fast %llu, rows/pixel %.2f, slots/px %.1f, wave iterations %llu all-fast %llu\n",
+		        h.dbg_phase[6], h.dbg_phase[7], (double)h.dbg_cycles/(double)h.n_pixels, 8.0*h.dbg_phase[6]/(double)h.n_pixels,
+		        h.dbg_blocks, h.dbg_total_cycles);
 	return SRH_OK;
 }
 

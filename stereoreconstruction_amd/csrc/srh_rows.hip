@@ -247,6 +247,9 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	__syncthreads();
 
 	unsigned n_dev = 0;
+#ifdef SRH_ROWS_DBG
+	unsigned d_task = 0, d_fast = 0, d_rows = 0, d_wavefast = 0, d_waveiter = 0;
+#endif
 	const Smem &CS = S;
 	if (x < W) {
 		const int m = CS.meta[i];
@@ -268,22 +271,43 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				const int c0 = xlo + b*RC_NCB;
 				const int nv = wdt - b*RC_NCB < RC_NCB ? wdt - b*RC_NCB : RC_NCB;
 				n_dev += nv;
-				bool fast = lall;
-				for (int j = 0; j < nv; ++j) fast = fast && full_oth[(size_t)cy*OW + c0 + j] != 0;
+				// a span's last, partial block is moved left to end on the span's last column, so that the fast
+				// form always works on 8 usable columns (the extra ones are recomputed and dropped)
+				const int sh = RC_NCB - nv;
+				const int c0s = c0 - sh;
+				bool fast = lall && c0s >= 0;
+				if (fast) {
+					const uint8_t *fp = full_oth + (size_t)cy*OW + c0s;
+					unsigned allfull = 1;
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) allfull &= fp[j];
+					fast = allfull != 0;
+				}
 				double *dst = crow + (size_t)task*RC_NCB;
+#ifdef SRH_ROWS_DBG
+				++d_task; d_fast += fast ? 1 : 0; if (g == 0 && task == 0) d_rows += nr;
+				if (lane == __ffsll((long long)__ballot(1)) - 1) { ++d_waveiter; }
+				if (__all(fast) && lane == __ffsll((long long)__ballot(1)) - 1) ++d_wavefast;
+#endif
 				if (fast) {
 					// blocked fast form (srh_dense.hip): a row segment of NCB+2R values of the other view is
 					// read once per window row and shared by the NCB candidates and 2R+1 taps
-					const int kmax = nv - 1 + 2*R;                      // last column index a valid candidate reads
-					const double *rbase = Rv.gray_tv + (size_t)(cy - R)*OW + (c0 - R);
+					const double *rbase = Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R);
 					double acc[RC_NCB];
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) acc[j] = 0.0;
+					// the next window row's segment is in flight while the current one is consumed
+					double rn[NR_];
+#pragma unroll
+					for (int k = 0; k < NR_; ++k) rn[k] = rbase[k];
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
 						double rr[NR_], wv[WS];
 #pragma unroll
-						for (int k = 0; k < NR_; ++k) rr[k] = rbase[(size_t)row*OW + (k < kmax ? k : kmax)];
+						for (int k = 0; k < NR_; ++k) rr[k] = rn[k];
+						const int nrow = row + 1 < WS ? row + 1 : 0;           // after the last row: row 0 for the second sweep
+#pragma unroll
+						for (int k = 0; k < NR_; ++k) rn[k] = rbase[(size_t)nrow*OW + k];
 #pragma unroll
 						for (int col = 0; col < WS; ++col) wv[col] = CS.w[i][row*WP + col];
 #pragma unroll
@@ -299,7 +323,10 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					for (int row = 0; row < WS; ++row) {
 						double rr[NR_], wv[WS], av[WS];
 #pragma unroll
-						for (int k = 0; k < NR_; ++k) rr[k] = rbase[(size_t)row*OW + (k < kmax ? k : kmax)];
+						for (int k = 0; k < NR_; ++k) rr[k] = rn[k];
+						const int nrow = row + 1 < WS ? row + 1 : row;
+#pragma unroll
+						for (int k = 0; k < NR_; ++k) rn[k] = rbase[(size_t)nrow*OW + k];
 #pragma unroll
 						for (int col = 0; col < WS; ++col) { wv[col] = CS.w[i][row*WP + col]; av[col] = CS.lt[row][i + col]; }
 #pragma unroll
@@ -315,69 +342,101 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					}
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
-						if (j < nv) {
+						if (j >= sh) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							dst[j] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							dst[j - sh] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 					}
 				} else {
-					for (int j = 0; j < nv; ++j) {
-						// any validity pattern; a skipped tap adds +0.0
-						const int cx = c0 + j;
-						double meanL = 0, meanR = 0, totalWeight = 0.0;
+					// blocked select form, any validity pattern (image border, masked taps, cut-off weights):
+					// the same sums with every tap guarded; a skipped tap adds +0.0
+					const int gx0 = c0 - R;
+					double mLs[RC_NCB], mRs[RC_NCB], tws[RC_NCB];
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
 #pragma unroll 1
-						for (int row = 0; row < WS; ++row) {
-							double gr[WS];
+					for (int row = 0; row < WS; ++row) {
+						const int gy = cy - R + row;
+						const bool rowok = gy >= 0 && gy < OH;
+						const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
+						double rr[NR_];
 #pragma unroll
-							for (int col = 0; col < WS; ++col) {
-								const int gx = cx - R + col, gy = cy - R + row;
-								gr[col] = (gx >= 0 && gy >= 0 && gx < OW && gy < OH) ? Rv.gray_tv[(size_t)gy*OW + gx] : nan;
-							}
+						for (int k = 0; k < NR_; ++k) {
+							const int gx = gx0 + k;
+							rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
+						}
 #pragma unroll
-							for (int col = 0; col < WS; ++col) {
-								const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
-								const bool ok = gl == gl && gr[col] == gr[col] && wt > P.weight_cutoff;
-								const double pl = wt*gl, pr = wt*gr[col];
-								meanL += ok ? pl : 0.0;
-								meanR += ok ? pr : 0.0;
-								totalWeight += ok ? wt : 0.0;
+						for (int col = 0; col < WS; ++col) {
+							const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
+							const bool okl = gl == gl && wt > P.weight_cutoff;
+							const double pl = wt*gl;
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) {
+								const double gr = rr[col + j];
+								const bool ok = okl && gr == gr;
+								const double pr = wt*gr;
+								mLs[j] += ok ? pl : 0.0;
+								mRs[j] += ok ? pr : 0.0;
+								tws[j] += ok ? wt : 0.0;
 							}
 						}
-						double result;
-						if (totalWeight < 1e-10) result = P.bad_ret;
-						else {
-							meanL /= totalWeight;
-							meanR /= totalWeight;
-							double sum1 = 0, sum2 = 0, sum3 = 0;
+					}
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) { mLs[j] /= tws[j]; mRs[j] /= tws[j]; }   // unused when tws < 1e-10
+					double s1[RC_NCB], s2v[RC_NCB], s3[RC_NCB];
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) { s1[j] = 0.0; s2v[j] = 0.0; s3[j] = 0.0; }
 #pragma unroll 1
-							for (int row = 0; row < WS; ++row) {
-								double gr[WS];
+					for (int row = 0; row < WS; ++row) {
+						const int gy = cy - R + row;
+						const bool rowok = gy >= 0 && gy < OH;
+						const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
+						double rr[NR_];
 #pragma unroll
-								for (int col = 0; col < WS; ++col) {
-									const int gx = cx - R + col, gy = cy - R + row;
-									gr[col] = (gx >= 0 && gy >= 0 && gx < OW && gy < OH) ? Rv.gray_tv[(size_t)gy*OW + gx] : nan;
-								}
-#pragma unroll
-								for (int col = 0; col < WS; ++col) {
-									const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
-									const bool ok = gl == gl && gr[col] == gr[col] && wt > P.weight_cutoff;
-									const double a = wt*gl - meanL, bq = wt*gr[col] - meanR;
-									const double ab = a*bq, aa = a*a, bb = bq*bq;
-									sum1 += ok ? ab : 0.0;
-									sum2 += ok ? aa : 0.0;
-									sum3 += ok ? bb : 0.0;
-								}
-							}
-							const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
-							result = (v < P.max_color_diff) ? v : P.max_color_diff;
+						for (int k = 0; k < NR_; ++k) {
+							const int gx = gx0 + k;
+							rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
 						}
-						dst[j] = result;
+#pragma unroll
+						for (int col = 0; col < WS; ++col) {
+							const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
+							const bool okl = gl == gl && wt > P.weight_cutoff;
+							const double pl = wt*gl;
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) {
+								const double gr = rr[col + j];
+								const bool ok = okl && gr == gr;
+								const double a = pl - mLs[j], bq = wt*gr - mRs[j];
+								const double ab = a*bq, aa = a*a, bb = bq*bq;
+								s1[j] += ok ? ab : 0.0;
+								s2v[j] += ok ? aa : 0.0;
+								s3[j] += ok ? bb : 0.0;
+							}
+						}
+					}
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) {
+						if (j < nv) {
+							double result = P.bad_ret;
+							if (!(tws[j] < 1e-10)) {
+								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2v[j] * s3[j]));
+								result = (v < P.max_color_diff) ? v : P.max_color_diff;
+							}
+							dst[j] = result;
+						}
 					}
 				}
 			}
 		}
 	}
 	block_count_add(&cnt->n_eval_device, n_dev);
+#ifdef SRH_ROWS_DBG
+	block_count_add(&cnt->dbg_phase[6], d_task);
+	block_count_add(&cnt->dbg_phase[7], d_fast);
+	block_count_add(&cnt->dbg_cycles, d_rows);
+	block_count_add(&cnt->dbg_blocks, d_waveiter);
+	block_count_add(&cnt->dbg_total_cycles, d_wavefast);
+#endif
 }
 
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,

@@ -23,6 +23,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def hip_ctx():
     """One srh_context on device 0 for the whole GPU session (fails loudly without a GPU)."""
+    # some GPU tests hand torch tensors to the library: torch's bundled ROCm runtime has to attach
+    # to the GPU before the library's (see capi._torch_runtime_first), so import it here
+    import torch  # noqa: F401
     from stereoreconstruction_amd import capi
     ctx = capi.Context(0)
     yield ctx
