@@ -175,6 +175,18 @@ int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *ne
 int  srh_mvs_cross_check(srh_context *ctx, const int32_t *slots, int nviews, int view_index,
                          const srh_params *p);
 
+/* ---- epipolar curves ----
+ * TwoViewStereo::epipolarCurve (public member, twoviewstereo.hpp:66-70, twoviewstereo.cpp:999-1054;
+ * the GUI's curve preview calls it, stereowidget.cpp:621-672) when mvs == 0, and
+ * MultiViewStereo::epipolarCurve (multiviewstereo.cpp:754-810: uniform depths, clipped segments,
+ * consecutive duplicates removed) when mvs != 0.  For each of the `nqueries` reference pixels
+ * xy[2q], xy[2q+1] of slot `ref_slot`: the candidate pixels in slot `oth_slot`, in the order the
+ * reference visits them, written as (x,y) int32 pairs to out_xy + q*2*max_pts; counts[q] receives
+ * the curve length (which may exceed max_pts; only max_pts points are written).  The reference
+ * pixel's own mask is not consulted (the callers do that).  All pointers are HOST memory. */
+int  srh_epipolar_curves(srh_context *ctx, int ref_slot, int oth_slot, const srh_params *p, int mvs,
+                         int nqueries, const int32_t *xy, int32_t *out_xy, int max_pts, int32_t *counts);
+
 /* ---- multi-GPU exchange (RCCL over xGMI; one process and one context per GPU) ----
  * srh_comm_unique_id: rank 0 creates the 128-byte id and hands it to the other ranks by any
  * means (MPI, files, torch.distributed ...).  srh_comm_init is collective.  librccl is loaded on

@@ -68,7 +68,7 @@ EXPORTS = [
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
-    "srh_mvs_initial_estimate", "srh_mvs_cross_check",
+    "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_epipolar_curves",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
 ]
@@ -121,6 +121,8 @@ def lib():
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
     L.srh_mvs_initial_estimate.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.c_int, C.c_int, vp]
     L.srh_mvs_cross_check.argtypes = [vp, c_int32_p, C.c_int, C.c_int, C.POINTER(Params)]
+    L.srh_epipolar_curves.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, c_int32_p,
+                                      c_int32_p, C.c_int, c_int32_p]
     L.srh_comm_unique_id.argtypes = [vp]
     L.srh_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.srh_comm_gather_depth.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -311,6 +313,21 @@ class Context:
     def mvs_cross_check(self, slots, view_index, p):
         s = np.ascontiguousarray(slots, dtype=np.int32)
         _check(lib().srh_mvs_cross_check(self._h, s.ctypes.data_as(c_int32_p), len(s), view_index, C.byref(p)))
+
+    def epipolar_curves(self, ref_slot, oth_slot, p, xy, mvs=False, max_pts=4096):
+        """Candidate pixels of each reference pixel in `xy` (n,2), in the reference's visiting order
+        -> list of (len,2) int32 arrays (TwoViewStereo/MultiViewStereo::epipolarCurve)."""
+        q = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        n = q.shape[0]
+        counts = np.zeros(max(n, 1), dtype=np.int32)
+        while True:
+            out = np.zeros((max(n, 1), max_pts, 2), dtype=np.int32)
+            _check(lib().srh_epipolar_curves(self._h, ref_slot, oth_slot, C.byref(p), int(bool(mvs)), n,
+                                             q.ctypes.data_as(c_int32_p), out.ctypes.data_as(c_int32_p), max_pts,
+                                             counts.ctypes.data_as(c_int32_p)))
+            if n == 0 or counts[:n].max() <= max_pts:
+                return [out[i, :counts[i]].copy() for i in range(n)]
+            max_pts = int(counts[:n].max())
 
     # -- multi-GPU exchange (RCCL)
     @staticmethod

@@ -767,6 +767,39 @@ extern "C" int srh_mvs_cross_check(srh_context *c, const int32_t *slots, int nvi
 	return SRH_OK;
 }
 
+// ------------------------------------------------------------------ epipolar curves on request
+extern "C" int srh_epipolar_curves(srh_context *c, int ref, int oth, const srh_params *p, int mvs,
+                                   int nq, const int32_t *xy, int32_t *out_xy, int max_pts, int32_t *counts)
+{
+	int rc;
+	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
+	if (ref == oth) return fail(SRH_E_INVALID, "ref and other view are the same slot");
+	if (nq < 0 || max_pts < 0 || (nq > 0 && (!xy || !counts)) || (nq > 0 && max_pts > 0 && !out_xy))
+		return fail(SRH_E_INVALID, "bad query buffers");
+	if (nq == 0) return SRH_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	int32_t *d_xy = nullptr, *d_out = nullptr, *d_n = nullptr;
+	const size_t out_bytes = (size_t)nq*2*(size_t)max_pts*sizeof(int32_t);
+	hipError_t e = hipMalloc((void **)&d_xy, (size_t)nq*2*sizeof(int32_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&d_n, (size_t)nq*sizeof(int32_t));
+	if (e == hipSuccess && out_bytes) e = hipMalloc((void **)&d_out, out_bytes);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_xy, xy, (size_t)nq*2*sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		Scope s(c, "epipolar_curves_kernel");
+		launch_epipolar_curves(c->stream, c->d_views, ref, oth, *p, mvs ? 1 : 0, nq, d_xy, d_out, max_pts, d_n);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(counts, d_n, (size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess && out_bytes) e = hipMemcpyAsync(out_xy, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	else (void)hipStreamSynchronize(c->stream);
+	if (d_xy) (void)hipFree(d_xy);
+	if (d_n) (void)hipFree(d_n);
+	if (d_out) (void)hipFree(d_out);
+	if (e != hipSuccess) return fail(SRH_E_DEVICE, "epipolar curves: %s", hipGetErrorString(e));
+	return SRH_OK;
+}
+
 // ------------------------------------------------------------------ multi-GPU exchange
 extern "C" int srh_comm_unique_id(void *id_out) {
 	if (!id_out) return fail(SRH_E_INVALID, "null id buffer");

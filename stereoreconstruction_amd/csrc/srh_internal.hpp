@@ -90,6 +90,8 @@ bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int
                               const int32_t *count, const uint32_t *cand, double *cost, int cmax, Counters *cnt);
 void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, const double *cost, int cmax);
+void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int mvs,
+                            int nq, const int32_t *xy, int32_t *out, int cap, int32_t *counts);
 
 // run-blocked candidate lists, srh_rows.hip
 #define SRH_ROWS_NR 32

@@ -556,4 +556,36 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 	                   views, slots_dev, nviews, view_index, P);
 }
 
+// ------------------------------------------------------------------ epipolar curves on request
+struct CurveWriter {
+	int32_t *out;
+	int cap, n;
+	__device__ __forceinline__ void operator()(int cx, int cy) {
+		if (n < cap) { out[2*n] = cx; out[2*n + 1] = cy; }
+		++n;
+	}
+};
+
+// one thread per queried pixel (the GUI asks for one curve at a time; tests for a few hundred)
+__global__ void epipolar_curves_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int mvs,
+                                       int nq, const int32_t *__restrict__ xy, int32_t *__restrict__ out, int cap,
+                                       int32_t *__restrict__ counts)
+{
+	const int q = blockIdx.x*blockDim.x + threadIdx.x;
+	if (q >= nq) return;
+	const ViewDev &L = views[ref];
+	const Ray ray = cam_unproject(L.cam, (xy[2*q] + 0.5) / P.image_scale, (xy[2*q + 1] + 0.5) / P.image_scale);
+	CurveWriter wr = { out + (size_t)q*2*cap, cap, 0 };
+	if (mvs) walk_curve<true>(ray, L.cam, views[oth], P, wr);
+	else walk_curve<false>(ray, L.cam, views[oth], P, wr);
+	counts[q] = wr.n;
+}
+
+void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int mvs,
+                            int nq, const int32_t *xy, int32_t *out, int cap, int32_t *counts)
+{
+	hipLaunchKernelGGL(epipolar_curves_kernel, dim3((unsigned)((nq + 63)/64)), dim3(64), 0, st,
+	                   views, ref, oth, P, mvs, nq, xy, out, cap, counts);
+}
+
 } // namespace srh

@@ -81,18 +81,42 @@ void TwoViewStereo::colorize(const DepthMap &d, Image &out) const {
 		}
 }
 
-void TwoViewStereo::computeDepthMaps() {
-	// twoviewstereo.cpp:150-227: cost volumes (steps 1,3), cross-check (5), colourise, finished (8)
-	if (!ctx_) { if (error_.empty()) error_ = "no device context"; return; }
-	if (!leftView || !rightView || left.isNull() || right.isNull()) { error_ = "missing view"; return; }
+bool TwoViewStereo::uploadViews() {
 	params_.min_depth = minDepth; params_.max_depth = maxDepth;
 	params_.num_depth_levels = numDepthLevels; params_.image_scale = imageScale;
 	const srh_camera lc = leftView->snapshot(), rc = rightView->snapshot();   // snapshot: the GUI may mutate cameras
 	if (srh_view_upload(ctx_, 0, left.w, left.h, left.rgba.data(), leftMask.data(), &lc) != SRH_OK ||
 	    srh_view_upload(ctx_, 1, right.w, right.h, right.rgba.data(), rightMask.data(), &rc) != SRH_OK) {
 		error_ = srh_last_error();
-		return;
+		return false;
 	}
+	return true;
+}
+
+std::vector<std::pair<int, int> > TwoViewStereo::epipolarCurve(int x, int y, bool fromLeft) {
+	std::vector<std::pair<int, int> > curve;
+	if (!ctx_ || !leftView || !rightView || left.isNull() || right.isNull() || !uploadViews()) return curve;
+	const int32_t xy[2] = { x, y };
+	int32_t n = 0;
+	std::vector<int32_t> pts(2*64);
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		const int cap = static_cast<int>(pts.size()/2);
+		if (srh_epipolar_curves(ctx_, fromLeft ? 0 : 1, fromLeft ? 1 : 0, &params_, 0, 1, xy, pts.data(), cap, &n) != SRH_OK) {
+			error_ = srh_last_error();
+			return curve;
+		}
+		if (n <= cap) break;
+		pts.resize(2*static_cast<size_t>(n));
+	}
+	for (int i = 0; i < n; ++i) curve.push_back(std::make_pair(pts[2*i], pts[2*i + 1]));
+	return curve;
+}
+
+void TwoViewStereo::computeDepthMaps() {
+	// twoviewstereo.cpp:150-227: cost volumes (steps 1,3), cross-check (5), colourise, finished (8)
+	if (!ctx_) { if (error_.empty()) error_ = "no device context"; return; }
+	if (!leftView || !rightView || left.isNull() || right.isNull()) { error_ = "missing view"; return; }
+	if (!uploadViews()) return;
 	TwoViewHooks hooks = { this, &progressUpdate, &stageUpdate };
 	srh_set_hooks(ctx_, cancelFlag(), onProgress, &hooks);
 	const int rc_ = srh_twoview_compute(ctx_, 0, 1, &params_, computedDepthLeft.data(), computedDepthRight.data());

@@ -5,6 +5,7 @@
 #pragma once
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "camera.hpp"
@@ -28,6 +29,12 @@ public:
 
 	void computeDepthMaps();
 
+	// Candidate pixels, in visiting order, of pixel (x,y) of the left (fromLeft) or right view in the
+	// other view.  The reference's public epipolarCurve (twoviewstereo.hpp:66-70) takes the unprojected
+	// ray, camera offset, plane normal, mask and view; all of them follow from the pixel and the
+	// direction, which is what StereoWidget has in hand (stereowidget.cpp:621-672).
+	std::vector<std::pair<int, int> > epipolarCurve(int x, int y, bool fromLeft = true);
+
 	Image leftDepthMap() const { return resultLeft; }
 	Image rightDepthMap() const { return resultRight; }
 
@@ -42,6 +49,7 @@ protected:
 	void runTask() { computeDepthMaps(); }
 
 private:
+	bool uploadViews();
 	void colorize(const DepthMap &d, Image &out) const;
 	void colorFromDepth(double depth, uint8_t rgb[3]) const;
 

@@ -8,7 +8,8 @@
 //
 // in.bin : int32 nviews, w, h, D, radius, weight_kind; double minDepth, maxDepth, scale, crossCheck;
 //          per view: double K[9], R[9], t[3], dist[5]; uint8 rgba[w*h*4]; uint8 mask[w*h] (twoview only)
-// out.bin: per view double depth[w*h]; then int32 nsteps, then the progress steps seen
+// out.bin: per view double depth[w*h]; then int32 nsteps, then the progress steps seen;
+//          twoview: then int32 npts and the (x,y) int32 pairs of epipolarCurve(w/2, h/2) from the left view
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,6 +52,7 @@ int main(int argc, char **argv) {
 	fclose(f);
 
 	std::vector<int> steps;
+	std::vector<std::pair<int, int> > curve;
 	std::vector<std::vector<double> > out;
 	bool started = false, finished = false;
 	if (!mvs) {
@@ -66,6 +68,8 @@ int main(int argc, char **argv) {
 		out.push_back(tvs.leftDepths()); out.push_back(tvs.rightDepths());
 		const Image lm = tvs.leftDepthMap();
 		if (lm.width() != w || lm.height() != h) return 5;
+		curve = tvs.epipolarCurve(w/2, h/2, true);     // the GUI's curve preview (stereowidget.cpp:621-672)
+		if (!tvs.lastError().empty()) { fprintf(stderr, "curve: %s\n", tvs.lastError().c_str()); return 3; }
 	} else {
 		std::shared_ptr<MultiViewStereo> m(new MultiViewStereo());
 		if (!m->lastError().empty()) { fprintf(stderr, "ctor: %s\n", m->lastError().c_str()); return 3; }
@@ -88,6 +92,11 @@ int main(int argc, char **argv) {
 	const int32_t ns = static_cast<int32_t>(steps.size());
 	fwrite(&ns, sizeof(ns), 1, o);
 	for (int s : steps) { const int32_t v = s; fwrite(&v, sizeof(v), 1, o); }
+	if (!mvs) {
+		const int32_t np = static_cast<int32_t>(curve.size());
+		fwrite(&np, sizeof(np), 1, o);
+		for (const auto &pt : curve) { const int32_t xy[2] = { pt.first, pt.second }; fwrite(xy, sizeof(int32_t), 2, o); }
+	}
 	fclose(o);
 	return 0;
 }

@@ -53,6 +53,15 @@ def _read_output(path, nmaps, w, h):
     return maps, steps
 
 
+def _read_curve(path, nmaps, w, h):
+    raw = open(path, "rb").read()
+    off = nmaps * w * h * 8
+    (ns,) = struct.unpack_from("<i", raw, off)
+    off += 4 + 4 * ns
+    (npts,) = struct.unpack_from("<i", raw, off)
+    return np.frombuffer(raw[off + 4:off + 4 + 8 * npts], np.int32).reshape(npts, 2)
+
+
 def test_host_classes_compile_without_gpu(tmp_path):
     """CPU check: the host layer and its driver build and link against the C-ABI library."""
     assert os.path.exists(_build(str(tmp_path)))
@@ -75,6 +84,8 @@ def test_twoviewstereo_class(tmp_path):
     assert ok, msg
     ok, msg, _ = cases.compare_depth(gr, cr, 1e-9)
     assert ok, msg
+    want = O.epipolar_curve(ocams[0], ocams[1], imgs[1], op, False, 36, 20)
+    assert len(want) > 0 and np.array_equal(_read_curve(outp, 2, 72, 40), want)
 
 
 @pytest.mark.gpu

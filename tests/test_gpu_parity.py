@@ -270,3 +270,28 @@ def test_steep_curves_use_ordered_lists(hip_ctx):
     hip_ctx.twoview_wta(0, 1, p)
     hip_ctx.set_option("force_generic", 0)
     assert _same_bits(got, hip_ctx.download_depth(0))
+
+
+@pytest.mark.parametrize("name,mvs", [
+    ("adaptive_rect", False), ("geodesic_verged_dist_masks", False), ("adaptive_refractive", False),
+    ("geodesic_scaled", False), ("mvs_geodesic", True), ("mvs_distorted", True),
+])
+def test_epipolar_curves_are_the_oracles_point_lists(hip_ctx, name, mvs):
+    """SURVEY 8(a) #6/#7/#14, integer work: the candidate list of a pixel -- points, order, joint
+    duplicates (TwoView) / consecutive-duplicate removal and clipping (MVS) -- is bit-exact."""
+    case = cases.get_mvs(name) if mvs else cases.get_twoview(name)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    h, w = case["views"][0][0].shape[:2]
+    rng = np.random.default_rng(7)
+    xy = np.stack([rng.integers(0, w, 96), rng.integers(0, h, 96)], axis=1)
+    xy = np.concatenate([xy, [[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1]]]).astype(np.int32)
+    nonempty = 0
+    for ref, oth in ((0, 1), (1, 0)):
+        got = hip_ctx.epipolar_curves(ref, oth, p, xy, mvs=mvs, max_pts=8)       # small cap: exercises the regrow
+        for (x, y), g in zip(xy, got):
+            want = O.epipolar_curve(ocams[ref], ocams[oth], imgs[oth], op, mvs, int(x), int(y))
+            assert g.shape == want.shape and np.array_equal(g, want), "pixel (%d,%d) ref %d" % (x, y, ref)
+            nonempty += len(want) > 0
+    assert nonempty > 50
