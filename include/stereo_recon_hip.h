@@ -141,6 +141,9 @@ int  srh_view_depth_device_ptr(srh_context *ctx, int slot, void **dev_ptr);
 /* Asynchronous device-to-device copy of the slot's depth map into caller-owned
  * DEVICE memory (e.g. a tensor that RCCL then gathers); ordered on the context stream. */
 int  srh_view_depth_copy_to_device(srh_context *ctx, int slot, void *dst_dev);
+/* The reverse: the slot's depth map is replaced by w*h doubles from DEVICE memory (a map another
+ * rank computed, received through RCCL); asynchronous, ordered on the context stream. */
+int  srh_view_depth_copy_from_device(srh_context *ctx, int slot, const void *src_dev);
 
 /* ---- TwoViewStereo ----
  * One pass of computeCostVolumes (twoviewstereo.cpp:260-333 with ref=left,

@@ -66,7 +66,7 @@ EXPORTS = [
     "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_mvs_neighbours",
     "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
-    "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device",
+    "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_epipolar_curves",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_destroy",
@@ -116,6 +116,7 @@ def lib():
     L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.srh_view_depth_copy_to_device.argtypes = [vp, C.c_int, vp]
+    L.srh_view_depth_copy_from_device.argtypes = [vp, C.c_int, vp]
     L.srh_twoview_wta.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.srh_twoview_cross_check.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params)]
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
@@ -289,6 +290,9 @@ class Context:
 
     def copy_depth_to_device(self, slot, dst_dev_ptr):
         _check(lib().srh_view_depth_copy_to_device(self._h, slot, C.c_void_p(dst_dev_ptr)))
+
+    def copy_depth_from_device(self, slot, src_dev_ptr):
+        _check(lib().srh_view_depth_copy_from_device(self._h, slot, C.c_void_p(src_dev_ptr)))
 
     # -- TwoViewStereo
     def twoview_wta(self, ref_slot, oth_slot, p, y0=0, y1=0):

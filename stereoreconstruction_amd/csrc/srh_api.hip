@@ -452,6 +452,15 @@ extern "C" int srh_view_depth_copy_to_device(srh_context *c, int slot, void *dst
 	return SRH_OK;
 }
 
+extern "C" int srh_view_depth_copy_from_device(srh_context *c, int slot, const void *src_dev) {
+	int rc = check_slot(c, slot, true); if (rc) return rc;
+	if (!src_dev) return fail(SRH_E_INVALID, "null source");
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	HIP_TRY(hipMemcpyAsync(v.depth, src_dev, (size_t)v.w*v.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+	return SRH_OK;
+}
+
 // ------------------------------------------------------------------ runs
 static int band_rows(srh_context *c, int W, int H, int T) {
 	size_t rows = c->wbuf_budget / ((size_t)T*sizeof(double)*(size_t)W);

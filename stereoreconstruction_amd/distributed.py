@@ -34,3 +34,73 @@ def all_gather_depth_maps(local):
     out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(out, local)
     return out
+
+
+class HipMultiViewEngine:
+    """The per-rank side of multiview_sharded() on a GPU: one srh_context holding all views
+    (images and cameras are replicated -- a few MB -- so that every rank can match its own views
+    against any neighbour), depth maps exchanged as device tensors."""
+
+    def __init__(self, ctx, slots, neighbours, params, device):
+        self.ctx, self.slots, self.neigh, self.p, self.device = ctx, list(slots), neighbours, params, device
+        w, h = ctx.view_size(self.slots[0])
+        self.shape = (h, w)
+
+    def initial_estimate(self, v):
+        self.ctx.mvs_initial_estimate(self.slots[v], [self.slots[n] for n in self.neigh[v]], self.p)
+
+    def depth_tensor(self, v):
+        if torch.device(self.device).type == "cpu":             # host exchange (gloo rehearsal of the N>1 path)
+            return torch.from_numpy(self.ctx.download_depth(self.slots[v]))
+        t = torch.empty(self.shape, dtype=torch.float64, device=self.device)
+        self.ctx.copy_depth_to_device(self.slots[v], t.data_ptr())
+        return t
+
+    def set_depth(self, v, t):
+        assert t.is_contiguous() and t.dtype == torch.float64 and tuple(t.shape) == self.shape
+        if t.device.type == "cpu":
+            self.ctx.upload_depth(self.slots[v], t.numpy())
+        else:
+            self.ctx.copy_depth_from_device(self.slots[v], t.data_ptr())
+
+    def cross_check(self, v):
+        self.ctx.mvs_cross_check(self.slots, v, self.p)
+
+    def fence(self):
+        # the library works on its own stream: order it against torch's streams / RCCL, both ways
+        self.ctx.synchronize()
+        if torch.device(self.device).type != "cpu":
+            torch.cuda.synchronize(self.device)
+
+
+def multiview_sharded(engine, n_views):
+    """MultiViewStereo::runTask (multiviewstereo.cpp:323-447) over the ranks of the default process
+    group.  Views are sharded (shard_units); each rank runs computeInitialEstimate for its own views;
+    ONE all-gather moves every rank's maps to every rank (the cross-check of a view reads all other
+    views' maps, multiviewstereo.cpp:694-719); then every rank runs the same sequential, order-dependent
+    cross-check chain, so the final maps are resident everywhere, rank 0 included.  Returns the list of
+    views this rank estimated.  `engine`: initial_estimate(v), depth_tensor(v), set_depth(v, tensor),
+    cross_check(v), fence()."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = list(shard_units(n_views, world, rank))
+    for v in mine:
+        engine.initial_estimate(v)
+    if world > 1:
+        per = -(-n_views // world)                               # equal-sized contributions: pad the short ranks
+        maps = [engine.depth_tensor(v) for v in mine]
+        maps += [torch.full(engine.shape, float("nan"), dtype=torch.float64, device=engine.device)
+                 for _ in range(per - len(maps))]
+        engine.fence()
+        local = torch.stack(maps)
+        everyone = all_gather_depth_maps(local)
+        for r in range(world):
+            if r == rank:
+                continue
+            for k, v in enumerate(shard_units(n_views, world, r)):
+                engine.set_depth(v, everyone[r][k].contiguous())
+        engine.fence()
+    for v in range(n_views):                                     # in view order: each view reads the earlier, filtered maps
+        engine.cross_check(v)
+    engine.fence()
+    return mine

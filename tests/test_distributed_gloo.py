@@ -83,3 +83,91 @@ def test_two_rank_gather_of_depth_maps():
         for rr in range(2):
             assert same(got["all%d" % rr][r], got["local%d" % r])
     assert not same(got["local0"], got["local1"])      # the two ranks really own different pairs
+
+
+class _OracleMultiViewEngine:
+    """CPU stand-in for HipMultiViewEngine (checker role: the exchange and the ordering of
+    multiview_sharded are what is under test)."""
+
+    def __init__(self, case):
+        import cases
+        import oracle_ffi as O
+        self.O = O
+        self.imgs, self.cams, self.p = cases.oracle_inputs(case)
+        self.neigh = O.mvs_neighbours(self.cams, self.p)
+        h, w = case["views"][0][0].shape[:2]
+        self.shape, self.device = (h, w), "cpu"
+        self.maps = [np.full((h, w), np.nan) for _ in self.cams]
+        self.log = []
+
+    def initial_estimate(self, v):
+        self.log.append(("est", v))
+        self.maps[v] = self.O.mvs_initial_estimate(self.imgs, self.cams, v, self.neigh[v], self.p)[0]
+
+    def depth_tensor(self, v):
+        return torch.from_numpy(self.maps[v].copy())
+
+    def set_depth(self, v, t):
+        self.maps[v] = t.numpy().copy()
+
+    def cross_check(self, v):
+        self.log.append(("cc", v))
+        self.O.mvs_cross_check(self.imgs, self.cams, v, self.p, self.maps)
+
+    def fence(self):
+        pass
+
+
+def _mvs_worker(rank, world, port, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cases
+    from stereoreconstruction_amd.distributed import multiview_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = cases.get_mvs("mvs_geodesic", nviews=3, w=40, h=28, D=12)
+        eng = _OracleMultiViewEngine(case)
+        mine = multiview_sharded(eng, 3)
+        q.put((rank, mine, [m.copy() for m in eng.maps], eng.log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_multiview_run_matches_single_process():
+    """3 views over 2 ranks (uneven shards: 2 + 1, padded all-gather): both ranks end with the maps
+    of a single-process run, bit for bit, including the order-dependent cross-check chain."""
+    import cases
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mvs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, mine, maps, log = q.get(timeout=300)
+        got[rank] = (mine, maps, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == [0, 1] and got[1][0] == [2]
+    assert got[0][2] == [("est", 0), ("est", 1), ("cc", 0), ("cc", 1), ("cc", 2)]
+    assert got[1][2] == [("est", 2), ("cc", 0), ("cc", 1), ("cc", 2)]
+    # single process, no process group: multiview_sharded degenerates to the reference's runTask order
+    case = cases.get_mvs("mvs_geodesic", nviews=3, w=40, h=28, D=12)
+    eng = _OracleMultiViewEngine(case)
+    from stereoreconstruction_amd.distributed import multiview_sharded
+    assert multiview_sharded(eng, 3) == [0, 1, 2]
+    same = lambda a, b: np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    changed = False
+    for v in range(3):
+        assert same(got[0][1][v], eng.maps[v]) and same(got[1][1][v], eng.maps[v])
+        changed |= bool(np.isnan(eng.maps[v]).any())
+    assert changed, "cross-check rejected nothing: the chain is not exercised"
