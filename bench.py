@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of BASELINE.json: M disparity-hypotheses/s (W x H x D) of
 the TwoView cost-volume / support-weight / WTA path on synthetic 1920x1080x256 pairs.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small|c5|c4]
 
 A "step" is one pass of the hot path over one stereo pair per GPU: WTA left->right,
 WTA right->left, cross-check, and the device-side hand-over of the two depth maps
@@ -10,6 +10,10 @@ WTA right->left, cross-check, and the device-side hand-over of the two depth map
 Rank 0 prints ONE JSON line (contract in the task description).  N>1 is launched
 by torch.distributed.run, one rank per GPU; pairs are sharded (weak scaling), there
 is no data-path collective other than the final gather.
+
+--workload c4 is the MultiViewStereo configuration (8 views 1280x960, 128 levels, r=2): a step is
+runTask over all 8 views -- initial estimates, the all-gather of the depth maps (N>1: views are
+sharded over the ranks, strong scaling), the ordered cross-check chain.
 """
 import argparse
 import json
@@ -25,7 +29,8 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 from stereoreconstruction_amd import capi, synthetic  # noqa: E402
-from stereoreconstruction_amd.distributed import gather_depth_maps, shard_units  # noqa: E402
+from stereoreconstruction_amd.distributed import (HipMultiViewEngine, gather_depth_maps,  # noqa: E402
+                                                  multiview_sharded, shard_units)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (datasheet)
@@ -42,7 +47,112 @@ WORKLOADS = {
     # curved epipolar lines -> the general curve-walk kernel
     "c5": (1920, 1080, 256, capi.WEIGHT_GEODESIC, 0x5EED0050,
            "C5: C3 geometry + refractive interface (dist 0.1, ratio 1.333), one pair per GPU"),
+    "c4": (1280, 960, 128, capi.WEIGHT_GEODESIC, 0x5EED0004,
+           "C4: 8 views on a semicircle (22.5 deg apart) around a textured sphere, 1280x960, 128 uniform depth "
+           "levels, MultiViewStereo r=2, 3 neighbours"),
 }
+C4_VIEWS = 8
+
+
+def run_c4(args, rank, world, dev, dev_index, backend):
+    """MultiViewStereo::runTask on C4; returns the JSON dict on rank 0."""
+    import torch
+    import torch.distributed as dist
+    W, H, D, wkind, seed, desc = WORKLOADS["c4"]
+    if os.environ.get("SRH_BENCH_C4_SMALL"):                   # dev: quick functional run
+        W, H, D = 320, 240, 32
+    cams3 = synthetic.semicircle_rig(C4_VIEWS, W, H, radius=10.0, step_deg=22.5, focal=float(W))
+    rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, seed, sphere_radius=2.0, tex_size=1024)
+    cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
+    zmin, zmax = 8.0, 12.0
+    p = capi.params_mvs(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind,
+                        cross_check_threshold=2 * (zmax - zmin) / (D - 1))
+    neigh = capi.mvs_neighbours(cams, p)
+    links = sum(len(n) for n in neigh)
+    ctx = capi.Context(dev_index)
+    for v in range(C4_VIEWS):                                  # every rank holds all views (a few MB): any neighbour
+        ctx.upload_view(v, rgba[v], masks[v], cams[v])
+    eng = HipMultiViewEngine(ctx, list(range(C4_VIEWS)), neigh, p, dev if backend == "nccl" else "cpu")
+
+    def fence():
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        multiview_sharded(eng, C4_VIEWS)
+    fence()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        multiview_sharded(eng, C4_VIEWS)
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    prof = ctx.profile()
+    result = None
+    if rank == 0:
+        hyp_per_step = W * H * D * links                        # nominal: every pixel x level x neighbour
+        T = (2 * p.window_radius + 1) ** 2
+        name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+        my_links = sum(len(neigh[v]) for v in shard_units(C4_VIEWS, world, rank))
+        flops = W * H * D * my_links * (15.0 * T + 8) * args.steps   # rank 0's share, what its profile timed
+        valu = flops / (ms * 1e-3) / 1e12
+        alg_bytes = 14.0 * W * H * my_links * args.steps
+        hbm = alg_bytes / (ms * 1e-3) / 1e9
+        result = {
+            "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(hyp_per_step * args.steps / dt / 1e6, 3),
+            "unit": "Mhyp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc + "; initial estimates + depth-map all-gather + ordered cross-check",
+                       "width": W, "height": H, "depth_levels": D, "views": C4_VIEWS, "view_neighbour_links": links,
+                       "window_radius": int(p.window_radius), "weights": "geodesic",
+                       "parallelism": ("views sharded, %s all-gather" % ("RCCL" if backend == "nccl" else backend))
+                       if world > 1 else "single GPU",
+                       "masked_in_fraction": round(float(np.mean([m.mean() for m in masks])), 4)},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": round(valu, 3), "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(valu / FP64_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                         "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+                         "alg_flops_per_launch": round(flops / launches), "flops_per_hyp": 15 * T + 8,
+                         "note": "nominal hypotheses (all pixels x levels x neighbours); only masked-in pixels are matched",
+                         "hbm": {"achieved": round(hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(hbm / HBM_PEAK_GBS, 6), "alg_bytes_per_launch": round(alg_bytes / launches),
+                                 "traffic_over_algorithmic": None}},
+            "kernels_ms": {k: [round(v[0], 3), v[1]] for k, v in sorted(prof.items())},
+            "cpu_baseline": None,
+        }
+        if world == 1 and args.cpu_rows > 0:
+            import oracle_ffi as O
+            ocams = [O.camera_set(K, R, t) for (K, R, t) in cams3]
+            op = O.params_mvs(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind,
+                              cross_check_threshold=2 * (zmax - zmin) / (D - 1))
+            oimgs = [O.OImage(rgba[v], masks[v]) for v in range(C4_VIEWS)]
+            rows = max(args.cpu_rows, 8)
+            y0 = H // 2 - rows // 2
+            t0 = time.perf_counter()
+            want, n_eval = O.mvs_initial_estimate(oimgs, ocams, 0, neigh[0], op, y0, y0 + rows)
+            cdt = time.perf_counter() - t0
+            ctx.mvs_initial_estimate(0, neigh[0], p)
+            got = ctx.download_depth(0)[y0:y0 + rows]
+            want = want[y0:y0 + rows]
+            fin = np.isfinite(got) & np.isfinite(want)
+            same_cls = (np.isnan(got) == np.isnan(want)) & (np.isinf(got) == np.isinf(want))
+            close = np.abs(got[fin] - want[fin]) <= 1e-9 * np.maximum(1.0, np.abs(want[fin]))
+            result["cpu_baseline"] = dict(
+                value=rows * W * D * len(neigh[0]) / cdt / 1e6, unit="Mhyp/s", cores=1, kind="port",
+                sample="oracle/sr_oracle.c sro_mvs_initial_estimate, view 0, %d centre rows x %d levels x %d neighbours "
+                       "(%d cost evaluations) in %.2f s on 1 host thread" % (rows, D, len(neigh[0]), n_eval, cdt),
+                parity_band={"pixels": int(got.size), "class_mismatch": int((~same_cls).sum()),
+                             "value_mismatch": int((~close).sum())})
+    ctx.close()
+    return result
 
 
 def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, plane=None):
@@ -95,6 +205,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.workload == "c4":
+        result = run_c4(args, rank, world, dev, dev_index, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result))
+        return
 
     W, H, D, wkind, seed, desc = WORKLOADS[args.workload]
     # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair

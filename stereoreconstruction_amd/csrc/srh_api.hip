@@ -290,6 +290,8 @@ extern "C" int srh_create(int device, srh_context **out) {
 	memset(&c->stats, 0, sizeof(c->stats));
 	if (const char *s = getenv("SRH_WBUF_MB")) { long mb = atol(s); if (mb > 0) c->wbuf_budget = (size_t)mb << 20; }
 	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
+	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
+	if (const char *s = getenv("SRH_BAND_BUDGET_MB")) { if (atol(s) > 0) c->wbuf_budget = (size_t)atol(s) << 20; }
 	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
 	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
 	c->stream = c->own_stream;
@@ -740,9 +742,12 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	if (y0 < 0) y0 = 0;
 	if (y1 <= 0 || y1 > H) y1 = H;
 	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
+	if (y1 <= y0) return SRH_OK;
+
 	const int rows = band_rows(c, W, H, T);
 	const size_t wstride = SRH_WTILE;
 	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, rows, T)))) return rc;
+	if ((rc = ensure(c->cost, c->cost_cap, (size_t)rows*W*2*3))) return rc;       // per-neighbour best (cost, depth)
 	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 	for (int by = y0; by < y1; by += rows) {
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
@@ -750,7 +755,7 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 		run_weights(c, view, W, *p, by, nr, wstride);
 		{ Scope s(c, "mvs_generic_kernel");
 		  launch_mvs_generic(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-		                     (double *)peaks_dev, c->d_cnt); }
+		                     (double *)peaks_dev, c->force_generic ? nullptr : c->cost, c->d_cnt); }
 	}
 	HIP_TRY(hipGetLastError());
 	c->stats.used_dense_path = 0;

@@ -63,7 +63,7 @@ void launch_twoview_cross_check(hipStream_t st, const ViewDev *views, int self, 
                                 const srh_params &P);
 void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                         const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
-                        double *peaks, Counters *cnt);
+                        double *peaks, double *best, Counters *cnt);
 void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t *slots_dev, int nviews,
                             int view_index, int w, int h, const srh_params &P);
 
@@ -104,7 +104,6 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, int cmax,
                               const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax);
-
 // RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
 const char *rccl_unique_id_get(void *out128);
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);

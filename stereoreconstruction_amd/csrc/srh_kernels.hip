@@ -347,6 +347,11 @@ struct MvsRegVisitor {
 	double bestCost, bestDepth;
 	double *peaks;
 	unsigned n;
+	// without a top-K list only the largest (cost, depth) pair is wanted: the depth (unproject +
+	// closestPoints, ~250 flop) is computed for the final winner and for exact cost ties only
+	int bx, by;
+	const ViewDev *bB;
+	bool pending;
 
 	__device__ __forceinline__ double cost(int cx, int cy) const {
 		const ViewDev &Bv = *B;
@@ -411,10 +416,21 @@ struct MvsRegVisitor {
 		return s1 / sqrt(s2g * s3);
 	}
 
+	__device__ __forceinline__ void finish() {
+		if (pending) { bestDepth = candidate_depth(A.cam, bB->cam, P, ray, bx, by); pending = false; }
+	}
+
 	__device__ __forceinline__ void operator()(int cx, int cy) {
 		const double c = cost(cx, cy);
 		++n;
-		if (c > P.peak_threshold) {                              // multiviewstereo.cpp:589-594
+		if (c > P.peak_threshold && !peaks) {                    // multiviewstereo.cpp:589-594, 654-660
+			if (c > bestCost) { bestCost = c; bx = cx; by = cy; bB = B; pending = true; }
+			else if (c == bestCost && !(pending && bx == cx && by == cy && bB == B)) {
+				const double z = candidate_depth(A.cam, B->cam, P, ray, cx, cy);
+				finish();
+				if (z > bestDepth) { bestDepth = z; bx = cx; by = cy; bB = B; }
+			}
+		} else if (c > P.peak_threshold) {
 			const double z = candidate_depth(A.cam, B->cam, P, ray, cx, cy);
 			if (c > bestCost || (c == bestCost && z > bestDepth)) { bestCost = c; bestDepth = z; }
 			if (peaks) {
@@ -432,11 +448,14 @@ struct MvsRegVisitor {
 	}
 };
 
+// `best` != nullptr: blockIdx.y selects ONE neighbour and the thread leaves its largest (cost, depth)
+// pair in best[(blockIdx.y*npix + q)*2 ..]; mvs_combine_kernel takes the maximum over the neighbours
+// (the non-MRF result is a maximum over all candidates, so the neighbours can run side by side).
 template <int R>
 __global__ __launch_bounds__(128)
 void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, int nneigh, srh_params P,
                     int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
-                    double *__restrict__ peaks, Counters *__restrict__ cnt)
+                    double *__restrict__ peaks, double *__restrict__ best, Counters *__restrict__ cnt)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
 	const ViewDev &A = views[ref];
@@ -483,31 +502,66 @@ void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, 
 				for (int t = 0; t < T; ++t) a[t] = 0.0;
 			}
 			const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-			MvsRegVisitor<R> vis = { A, &A, P, ray, w, a, x, y, okL, all, tw, s2, 0.0, -1.0, pk, 0 };
-			for (int ni = 0; ni < nneigh; ++ni) {
+			MvsRegVisitor<R> vis = { A, &A, P, ray, w, a, x, y, okL, all, tw, s2, 0.0, -1.0, pk, 0, 0, 0, &A, false };
+			const int nfirst = best ? (int)blockIdx.y : 0, nlast = best ? (int)blockIdx.y + 1 : nneigh;
+			for (int ni = nfirst; ni < nlast; ++ni) {
 				const int v2 = ni == 0 ? n0 : (ni == 1 ? n1 : n2);
 				vis.B = &views[v2];
 				walk_curve<true>(ray, A.cam, views[v2], P, vis);
 			}
+			vis.finish();
 			n_eval = vis.n;
 			depth = vis.bestDepth;
+			if (best) {
+				double *b = best + ((size_t)blockIdx.y*((size_t)nrows*W) + q)*2;
+				b[0] = vis.bestCost; b[1] = vis.bestDepth;
+				if (blockIdx.y != 0) n_pix = 0;
+			}
 		}
-		A.depth[pv] = depth;
+		if (!best) A.depth[pv] = depth;
 	}
 	block_count_add(&cnt->n_eval, n_eval);
 	block_count_add(&cnt->n_eval_device, n_eval);
 	block_count_add(&cnt->n_pixels, n_pix);
 }
 
+__global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, int nneigh, int y0, int nrows,
+                                   const double *__restrict__ best)
+{
+	const ViewDev &A = views[ref];
+	const int W = A.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	const size_t npix = (size_t)nrows*W;
+	if (q >= npix) return;
+	const size_t pv = (size_t)y0*W + q;
+	double depth = __builtin_inf();
+	if (A.mask[pv] == 1) {
+		double bc = 0.0, bd = -1.0;
+		for (int ni = 0; ni < nneigh; ++ni) {
+			const double c = best[((size_t)ni*npix + q)*2], z = best[((size_t)ni*npix + q)*2 + 1];
+			if (c > bc || (c == bc && z > bd)) { bc = c; bd = z; }
+		}
+		depth = bd;
+	}
+	A.depth[pv] = depth;
+}
+
 void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                         const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
-                        double *peaks, Counters *cnt)
+                        double *peaks, double *best, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
 	const int n0 = nneigh > 0 ? neigh[0] : 0, n1 = nneigh > 1 ? neigh[1] : 0, n2 = nneigh > 2 ? neigh[2] : 0;
 	if (P.window_radius == 2 && !getenv("SRH_MVS_GENERIC")) {
+		if (best && !peaks && nneigh > 1) {                         // neighbours side by side + maximum
+			hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128), (unsigned)nneigh), dim3(128), 0, st,
+			                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, best, cnt);
+			hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
+			                   views, ref, nneigh, y0, nrows, best);
+			return;
+		}
 		hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-		                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, cnt);
+		                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, (double *)nullptr, cnt);
 		return;
 	}
 	hipLaunchKernelGGL(mvs_generic_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
