@@ -67,11 +67,12 @@ struct srh_context {
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
 	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
 	int list_smax_hint = 0;                             // most cost slots a pixel needed so far (run-blocked lists)
+	int mvs_cmax_hint = 0;                              // longest MultiViewStereo candidate list seen so far
 	bool list_rows = true;                              // option "list_rows": evaluate lists in row runs (srh_rows.hip)
 	uint32_t *lrowinfo = nullptr; size_t lrowinfo_cap = 0;
 	int32_t *lmeta = nullptr; size_t lmeta_cap = 0;
 	void *comm = nullptr; int comm_ranks = 0, comm_rank = 0;   // RCCL communicator (srh_comm_init)
-	size_t wbuf_budget = (size_t)1536 << 20;            // bytes per band: support windows (+ dense cost rows)
+	size_t wbuf_budget = (size_t)8192 << 20;            // bytes per band of scratch (windows, cost rows, candidate lists); the GPU has 288 GB
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
 	void *user = nullptr;
@@ -291,7 +292,6 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (const char *s = getenv("SRH_WBUF_MB")) { long mb = atol(s); if (mb > 0) c->wbuf_budget = (size_t)mb << 20; }
 	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
 	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
-	if (const char *s = getenv("SRH_BAND_BUDGET_MB")) { if (atol(s) > 0) c->wbuf_budget = (size_t)atol(s) << 20; }
 	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
 	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
 	c->stream = c->own_stream;
@@ -744,8 +744,48 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
 	if (y1 <= y0) return SRH_OK;
 
-	const int rows = band_rows(c, W, H, T);
 	const size_t wstride = SRH_WTILE;
+	if (y1 <= y0) return SRH_OK;
+
+	// ---- default: walk kernel -> candidate lists -> cost kernel -> maximum over the neighbours.
+	// The sorted top-K list (peaks_dev) and other radii stay on the one-thread-per-pixel kernels.
+	if (!c->force_generic && !peaks_dev && nneigh > 0 && p->window_radius == 2 && W < 65536 && H < 65536) {
+		int cmax = c->mvs_cmax_hint > 0 ? c->mvs_cmax_hint : ((2*p->num_depth_levels + 7) & ~7);
+		for (int pass = 0; pass < 3; ++pass) {
+			HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+			HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
+			const size_t per_px = (size_t)T*sizeof(double) + (size_t)nneigh*((size_t)cmax*sizeof(uint32_t) + sizeof(int32_t) + 2*sizeof(double));
+			size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
+			if (lrows < 1) lrows = 1;
+			if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
+			const size_t units = lrows*W*(size_t)nneigh;
+			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
+			if ((rc = ensure(c->cost, c->cost_cap, units*2))) return rc;
+			if ((rc = ensure(c->lcand, c->lcand_cap, ((units + 63) & ~(size_t)63)*(size_t)cmax))) return rc;   // wave-tiled lists
+			if ((rc = ensure(c->lcount, c->lcount_cap, units))) return rc;
+			for (int by = y0; by < y1; by += (int)lrows) {
+				if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+				const int nr = std::min((int)lrows, y1 - by);
+				run_weights(c, view, W, *p, by, nr, wstride);
+				{ Scope s(c, "mvs_walk_kernel");
+				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->lcand, cmax, c->lcount,
+				                  c->d_cnt, c->d_span); }
+				{ Scope s(c, "mvs_list_cost_kernel");
+				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
+				                       c->lcand, cmax, c->lcount, c->cost); }
+			}
+			int maxc = 0;
+			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (maxc <= cmax) { if (cmax > c->mvs_cmax_hint) c->mvs_cmax_hint = cmax; break; }
+			cmax = (maxc + 7) & ~7;                                   // a list was cut: repeat with the true maximum
+		}
+		HIP_TRY(hipGetLastError());
+		c->stats.used_dense_path = 0;
+		return SRH_OK;
+	}
+
+	const int rows = band_rows(c, W, H, T);
 	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, rows, T)))) return rc;
 	if ((rc = ensure(c->cost, c->cost_cap, (size_t)rows*W*2*3))) return rc;       // per-neighbour best (cost, depth)
 	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));

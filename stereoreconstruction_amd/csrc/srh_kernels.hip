@@ -526,6 +526,298 @@ void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, 
 }
 
 __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, int nneigh, int y0, int nrows,
+                                   const double *__restrict__ best);
+
+// ---- MultiViewStereo, two-stage form --------------------------------------------------------
+// mvs_reg_kernel keeps the curve walk, 25 weights, 25 a_t and a 25-tap window live in one thread:
+// >300 VGPRs, one wave per SIMD, every mask byte and every gather waited for in turn.  The default
+// path splits the work:
+//   mvs_walk_kernel   (pixel, neighbour) -> the candidate list of MultiViewStereo::epipolarCurve
+//                     (multiviewstereo.cpp:754-810).  Few registers, many waves; raster points are
+//                     queued in LDS and their mask bytes fetched in batches at wave-uniform flushes.
+//   mvs_list_cost_kernel  the free cost_ncc (multiviewstereo.cpp:113-189) of every listed candidate,
+//                     weights and a_t in registers, the next candidate's window in flight while the
+//                     current one is reduced; keeps the largest (cost, depth) pair (:589-604, 654-660).
+// Lists are stored wave-tiled, entry k of unit u at ((u/64)*cmax + k)*64 + u%64: a wave reads and
+// writes its 64 lists coalesced, and they are contiguous in memory.
+#define MQ_T 128
+#define MQ_QN 32
+#define MQ_FLUSH 24
+
+__global__ __launch_bounds__(MQ_T)
+void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
+                     int y0, int nrows, uint32_t *__restrict__ cand, int cmax, int32_t *__restrict__ count,
+                     Counters *__restrict__ cnt, int *__restrict__ max_count)
+{
+	__shared__ uint32_t s_q[MQ_QN][MQ_T];
+	__shared__ int s_max;
+	const ViewDev &A = views[ref];
+	const ViewDev &B = views[blockIdx.y == 0 ? n0 : (blockIdx.y == 1 ? n1 : n2)];
+	const int W = A.w, OW = B.w, OH = B.h;
+	const int tid = threadIdx.x;
+	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
+	const size_t npix = (size_t)nrows*W;
+	const size_t units = npix*gridDim.y;
+	const size_t unit = (size_t)blockIdx.y*npix + q;
+	const int x = (int)(q % W), y = y0 + (int)(q / W);
+	const bool active = q < npix && A.mask[(size_t)y*W + x] == 1;
+	int nk = 0;                                                     // candidates kept so far
+	if (tid == 0) s_max = 0;
+
+	if (__any(active)) {
+		Ray ray = {};
+		if (active) ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		int qn = 0;
+		uint32_t last = 0xffffffffu;                                // std::unique state (last kept point)
+
+		auto flush = [&]() {
+			for (int k0 = 0; __any(k0 < qn); k0 += 8) {
+				uint32_t e[8];
+				uint8_t m[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) e[j] = k0 + j < qn ? s_q[k0 + j][tid] : 0u;
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					m[j] = k0 + j < qn ? B.mask[(size_t)(e[j] >> 16)*OW + (e[j] & 0xffffu)] : (uint8_t)0;
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					if (m[j] == 1 && e[j] != last) {                // mask == WHITE, then std::unique (:786-807)
+						last = e[j];
+						if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = e[j];
+						++nk;
+					}
+			}
+			qn = 0;
+		};
+
+		const Vec3 camC = load3(A.cam.C);
+		const Vec3 normal = load3(A.cam.pdir);
+		double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+		for (int d = 0; d < P.num_depth_levels; ++d) {
+			bool seg = false;
+			LineWalk lw;
+			lw.x = 1; lw.xend = 0; lw.y = 0; lw.error = 0; lw.ystep = 0; lw.deltax = 0; lw.deltay = 0; lw.steep = false;
+			if (active) {
+				Vec3 point = camC;
+				const double depth = depth_from_label(P, true, d);
+				if (point_from_depth(ray, normal, depth, point) && cam_project(B.cam, point)) {
+					const double x2 = point.x*P.image_scale, y2 = point.y*P.image_scale;
+					if (isnan_d(x1)) { x1 = x2; y1 = y2; }
+					else {
+						const double dx = x2 - x1, dy = y2 - y1;
+						if (dx*dx + dy*dy >= 1) {
+							int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+							if (clip_line(ix0, iy0, ix1, iy1, OW, OH)) {  // 6-arg LineIterator, multiviewstereo.cpp:783
+								lw.begin(ix0, iy0, ix1, iy1, 0, 0);
+								seg = true;
+							}
+							x1 = x2; y1 = y2;
+						}
+					}
+				}
+			}
+			for (;;) {
+				while (seg && lw.has_next() && qn < MQ_QN) {
+					int tx, ty;
+					lw.current(tx, ty);
+					if (tx >= 0 && ty >= 0 && tx < OW && ty < OH) { s_q[qn][tid] = (uint32_t)tx | ((uint32_t)ty << 16); ++qn; }
+					lw.next();
+				}
+				const bool more = seg && lw.has_next();
+				if (__any(more || qn >= MQ_FLUSH)) flush();
+				if (!__any(more)) break;
+			}
+		}
+		flush();
+	}
+	if (q < npix) count[unit] = nk;
+	__syncthreads();
+	if (nk) atomicMax(&s_max, nk);
+	__syncthreads();
+	if (tid == 0 && s_max) atomicMax(max_count, s_max);
+	block_count_add(&cnt->n_eval, (unsigned)nk);
+	block_count_add(&cnt->n_eval_device, (unsigned)nk);
+	block_count_add(&cnt->n_pixels, (active && blockIdx.y == 0) ? 1u : 0u);
+}
+
+// cost of one candidate for any validity pattern (window over an image border, cut-off weights):
+// the reference's two sweeps with every tap guarded (multiviewstereo.cpp:113-189).  Rare, so it is
+// kept out of line and reads everything from memory.
+template <int R>
+__device__ __noinline__ double mvs_cost_general(const ViewDev &A, const ViewDev &B, const double *__restrict__ wq,
+                                                size_t wstride, double cutoff, int x, int y, int cx, int cy)
+{
+	constexpr int WS = 2*R + 1;
+	double mL = 0, mR = 0, twg = 0.0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row)
+#pragma unroll 1
+		for (int col = 0; col < WS; ++col) {
+			const double gl = mvs_tap(A, x - R + col, y - R + row), gr = mvs_tap(B, cx - R + col, cy - R + row);
+			const double wt = wq[(size_t)(row*WS + col)*wstride];
+			if (gl == gl && gr == gr && wt > cutoff) { mL += wt*gl; mR += wt*gr; twg += wt; }
+		}
+	if (twg < 1e-10) return 0;
+	mL /= twg;
+	mR /= twg;
+	double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row)
+#pragma unroll 1
+		for (int col = 0; col < WS; ++col) {
+			const double gl = mvs_tap(A, x - R + col, y - R + row), gr = mvs_tap(B, cx - R + col, cy - R + row);
+			const double wt = wq[(size_t)(row*WS + col)*wstride];
+			if (gl == gl && gr == gr && wt > cutoff) {
+				const double aa = wt*gl - mL, bb = wt*gr - mR;
+				s1 += aa*bb; s2 += aa*aa; s3 += bb*bb;
+			}
+		}
+	if (s2 * s3 < 1e-10) return 0;
+	return s1 / sqrt(s2 * s3);
+}
+
+template <int R>
+__global__ __launch_bounds__(MQ_T, 3)
+void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
+                          int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
+                          const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
+                          double *__restrict__ best)
+{
+	constexpr int WS = 2*R + 1, T = WS*WS;
+	__shared__ double s_w[T][MQ_T], s_a[T][MQ_T];                  // per-thread columns: conflict-free
+	const ViewDev &A = views[ref];
+	const ViewDev &B = views[blockIdx.y == 0 ? n0 : (blockIdx.y == 1 ? n1 : n2)];
+	const int W = A.w, OW = B.w, OH = B.h;
+	const int tid = threadIdx.x;
+	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
+	const size_t npix = (size_t)nrows*W;
+	const size_t units = npix*gridDim.y;
+	const size_t unit = (size_t)blockIdx.y*npix + q;
+	if (q >= npix) return;
+	const int x = (int)(q % W), y = y0 + (int)(q / W);
+	if (A.mask[(size_t)y*W + x] != 1) return;                      // mvs_combine_kernel does not read masked pixels
+	double *bout = best + unit*2;
+	const int n = count[unit] < cmax ? count[unit] : cmax;
+	if (n <= 0) { bout[0] = 0.0; bout[1] = -1.0; return; }
+
+	// ---- per-pixel constants: weights and a_t = w_t*gl_t - meanL in this thread's LDS column
+	const double *wq = wbuf + wbuf_offset(W, T, (int)(q / W), x);
+	bool all = true;
+	double tw = 0, s2 = 0;
+	{
+		double mL = 0;
+#pragma unroll
+		for (int row = 0; row < WS; ++row)
+#pragma unroll
+			for (int col = 0; col < WS; ++col) {
+				const int t = row*WS + col;
+				const double wt = wq[(size_t)t*wstride];
+				const double gl = mvs_tap(A, x - R + col, y - R + row);
+				all = all && gl == gl && wt > P.weight_cutoff;
+				s_w[t][tid] = wt;
+				s_a[t][tid] = gl;
+				mL += wt*gl;
+				tw += wt;
+			}
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+#pragma unroll
+			for (int t = 0; t < T; ++t) { const double at = s_w[t][tid]*s_a[t][tid] - mL; s_a[t][tid] = at; s2 += at*at; }
+		} else all = false;
+	}
+
+	double bestCost = 0.0, bestDepth = -1.0;
+	uint32_t be = 0;
+	bool pending = false;
+	const uint32_t *cl = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);
+
+	// the next candidate's window is in flight while the current one is reduced
+	double gn[T];
+	uint32_t en = cl[0];
+	bool inn;
+	{
+		const int cx = (int)(en & 0xffffu), cy = (int)(en >> 16);
+		inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
+		const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);
+#pragma unroll
+		for (int row = 0; row < WS; ++row)
+#pragma unroll
+			for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
+	}
+	uint32_t e2 = n > 1 ? cl[64] : 0u;                           // list entry k+2 travels one step ahead of the window
+	for (int k = 0; k < n; ++k) {
+		double pr[T];
+		const uint32_t e = en;
+		const bool fast = inn;
+		// p_t = weight*gray of the other view (multiviewstereo.cpp:150-151, 171); meanR is their sum / totalWeight
+		double mR = 0;
+#pragma unroll
+		for (int t = 0; t < T; ++t) { pr[t] = s_w[t][tid]*gn[t]; mR += pr[t]; }
+		if (k + 1 < n) {
+			en = e2;
+			if (k + 2 < n) e2 = cl[(size_t)(k + 2)*64];
+			const int cx = (int)(en & 0xffffu), cy = (int)(en >> 16);
+			inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
+			const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);   // not usable: any valid address
+#pragma unroll
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
+		}
+		double c;
+		if (fast) {
+			mR /= tw;
+			double s1 = 0, s3 = 0;
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
+				const double b = pr[t] - mR;
+				s1 += s_a[t][tid]*b;
+				s3 += b*b;
+			}
+			c = (s2 * s3 < 1e-10) ? 0.0 : s1 / sqrt(s2 * s3);
+		} else {
+			c = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, (int)(e & 0xffffu), (int)(e >> 16));
+		}
+		if (c > P.peak_threshold) {                                  // multiviewstereo.cpp:589-594, 654-660
+			if (c > bestCost) { bestCost = c; be = e; pending = true; }
+			else if (c == bestCost && !(pending && be == e)) {
+				// exact tie of two different candidates: the larger depth wins (sorted pairs, :600-602)
+				const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+				const double z = candidate_depth(A.cam, B.cam, P, ray, (int)(e & 0xffffu), (int)(e >> 16));
+				if (pending) { bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16)); pending = false; }
+				if (z > bestDepth) { bestDepth = z; be = e; }
+			}
+		}
+	}
+	if (pending) {
+		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16));
+	}
+	bout[0] = bestCost; bout[1] = bestDepth;
+}
+
+void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
+                     const srh_params &P, int y0, int nrows, uint32_t *cand, int cmax, int32_t *count,
+                     Counters *cnt, int *max_count)
+{
+	const size_t n = (size_t)nrows*width;
+	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
+	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, neigh[0], nneigh > 1 ? neigh[1] : 0,
+	                   nneigh > 2 ? neigh[2] : 0, P, y0, nrows, cand, cmax, count, cnt, max_count);
+}
+
+void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
+                          const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
+                          const uint32_t *cand, int cmax, const int32_t *count, double *best)
+{
+	const size_t n = (size_t)nrows*width;
+	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
+	hipLaunchKernelGGL(mvs_list_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, neigh[0], nneigh > 1 ? neigh[1] : 0,
+	                   nneigh > 2 ? neigh[2] : 0, P, y0, nrows, wbuf, wstride, cand, cmax, count, best);
+	hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, ref, nneigh, y0, nrows, best);
+}
+
+__global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, int nneigh, int y0, int nrows,
                                    const double *__restrict__ best)
 {
 	const ViewDev &A = views[ref];

@@ -64,7 +64,7 @@ def test_c3_full_size_band_invariance(hip_ctx):
     split (4 bands at the default budget vs 40+ bands at 128 MB), left->right pass."""
     W, H, D = 1920, 1080, 256
     _, _, p, _ = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
-    hip_ctx.set_option("band_budget_mb", 1536)
+    hip_ctx.set_option("band_budget_mb", 8192)
     hip_ctx.twoview_wta(0, 1, p)
     a = hip_ctx.download_depth(0)
     st_a = hip_ctx.stats()
@@ -72,7 +72,7 @@ def test_c3_full_size_band_invariance(hip_ctx):
     hip_ctx.twoview_wta(0, 1, p)
     b = hip_ctx.download_depth(0)
     st_b = hip_ctx.stats()
-    hip_ctx.set_option("band_budget_mb", 1536)
+    hip_ctx.set_option("band_budget_mb", 8192)
     assert st_a["used_dense_path"] and st_b["used_dense_path"]
     assert _same_bits(a, b)
     assert st_a["n_eval"] == st_b["n_eval"] and st_a["n_pixels"] == W * H
