@@ -677,14 +677,15 @@ __device__ __noinline__ double mvs_cost_general(const ViewDev &A, const ViewDev 
 }
 
 template <int R>
-__global__ __launch_bounds__(MQ_T, 3)
+__global__ __launch_bounds__(MQ_T, 2)
 void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
                           int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                           const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
                           double *__restrict__ best)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
-	__shared__ double s_w[T][MQ_T], s_a[T][MQ_T];                  // per-thread columns: conflict-free
+	__shared__ double s_w[T][MQ_T];                                 // per-thread columns: conflict-free
+	double a[T];
 	const ViewDev &A = views[ref];
 	const ViewDev &B = views[blockIdx.y == 0 ? n0 : (blockIdx.y == 1 ? n1 : n2)];
 	const int W = A.w, OW = B.w, OH = B.h;
@@ -715,14 +716,14 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 				const double gl = mvs_tap(A, x - R + col, y - R + row);
 				all = all && gl == gl && wt > P.weight_cutoff;
 				s_w[t][tid] = wt;
-				s_a[t][tid] = gl;
+				a[t] = gl;
 				mL += wt*gl;
 				tw += wt;
 			}
 		if (all && !(tw < 1e-10)) {
 			mL /= tw;
 #pragma unroll
-			for (int t = 0; t < T; ++t) { const double at = s_w[t][tid]*s_a[t][tid] - mL; s_a[t][tid] = at; s2 += at*at; }
+			for (int t = 0; t < T; ++t) { a[t] = s_w[t][tid]*a[t] - mL; s2 += a[t]*a[t]; }
 		} else all = false;
 	}
 
@@ -746,6 +747,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 	}
 	uint32_t e2 = n > 1 ? cl[64] : 0u;                           // list entry k+2 travels one step ahead of the window
 	for (int k = 0; k < n; ++k) {
+		asm volatile("" ::: "memory");                               // keep the LDS columns in LDS (no hoisting into 100 VGPRs)
 		double pr[T];
 		const uint32_t e = en;
 		const bool fast = inn;
@@ -753,6 +755,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 		double mR = 0;
 #pragma unroll
 		for (int t = 0; t < T; ++t) { pr[t] = s_w[t][tid]*gn[t]; mR += pr[t]; }
+#ifndef SRH_MVS_NOPREFETCH
 		if (k + 1 < n) {
 			en = e2;
 			if (k + 2 < n) e2 = cl[(size_t)(k + 2)*64];
@@ -764,6 +767,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 #pragma unroll
 				for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
 		}
+#endif
 		double c;
 		if (fast) {
 			mR /= tw;
@@ -771,7 +775,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 #pragma unroll
 			for (int t = 0; t < T; ++t) {
 				const double b = pr[t] - mR;
-				s1 += s_a[t][tid]*b;
+				s1 += a[t]*b;
 				s3 += b*b;
 			}
 			c = (s2 * s3 < 1e-10) ? 0.0 : s1 / sqrt(s2 * s3);
@@ -788,6 +792,20 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 				if (z > bestDepth) { bestDepth = z; be = e; }
 			}
 		}
+#ifdef SRH_MVS_NOPREFETCH
+		asm volatile("" ::: "memory");
+		if (k + 1 < n) {
+			en = e2;
+			if (k + 2 < n) e2 = cl[(size_t)(k + 2)*64];
+			const int cx = (int)(en & 0xffffu), cy = (int)(en >> 16);
+			inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
+			const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);   // not usable: any valid address
+#pragma unroll
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
+		}
+#endif
 	}
 	if (pending) {
 		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
