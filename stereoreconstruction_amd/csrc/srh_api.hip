@@ -645,7 +645,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		if (dense) {
 			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
 			Scope s(c, "pinhole_label_table_kernel");
-			launch_pinhole_label_table(c->stream, c->d_views, ref, *p, c->tnum);
+			launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum);
 		}
 		size_t per_pixel = (size_t)T*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
 		size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
@@ -751,6 +751,14 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	// The sorted top-K list (peaks_dev) and other radii stay on the one-thread-per-pixel kernels.
 	if (!c->force_generic && !peaks_dev && nneigh > 0 && p->window_radius == 2 && W < 65536 && H < 65536) {
 		int cmax = c->mvs_cmax_hint > 0 ? c->mvs_cmax_hint : ((2*p->num_depth_levels + 7) & ~7);
+		// without a refractive interface every ray of the view starts at the camera centre: the per-label
+		// part of pointFromDepth is tabulated once (same operands and operations, see srh_walk.hpp)
+		const bool table = !A.cam.is_refractive;
+		if (table) {
+			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
+			Scope s(c, "pinhole_label_table_kernel");
+			launch_pinhole_label_table(c->stream, c->d_views, view, *p, true, c->tnum);
+		}
 		for (int pass = 0; pass < 3; ++pass) {
 			HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 			HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
@@ -768,7 +776,7 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 				const int nr = std::min((int)lrows, y1 - by);
 				run_weights(c, view, W, *p, by, nr, wstride);
 				{ Scope s(c, "mvs_walk_kernel");
-				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->lcand, cmax, c->lcount,
+				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
 				                  c->d_cnt, c->d_span); }
 				{ Scope s(c, "mvs_list_cost_kernel");
 				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,

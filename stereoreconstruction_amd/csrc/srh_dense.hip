@@ -192,16 +192,16 @@ bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int widt
 }
 
 // ------------------------------------------------------------------ per-label table of the pinhole walk
-__global__ void pinhole_label_table_kernel(const ViewDev *__restrict__ views, int ref, srh_params P,
+__global__ void pinhole_label_table_kernel(const ViewDev *__restrict__ views, int ref, srh_params P, int mvs,
                                            double *__restrict__ tnum)
 {
 	const int d = blockIdx.x*blockDim.x + threadIdx.x;
-	if (d < P.num_depth_levels) tnum[d] = pinhole_label_tnum(views[ref].cam, P, false, d);
+	if (d < P.num_depth_levels) tnum[d] = pinhole_label_tnum(views[ref].cam, P, mvs != 0, d);
 }
 
-void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, double *tnum) {
+void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum) {
 	hipLaunchKernelGGL(pinhole_label_table_kernel, dim3((unsigned)((P.num_depth_levels + 63)/64)), dim3(64), 0, st,
-	                   views, ref, P, tnum);
+	                   views, ref, P, mvs ? 1 : 0, tnum);
 }
 
 // ------------------------------------------------------------------ dense cost

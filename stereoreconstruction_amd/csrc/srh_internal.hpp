@@ -71,7 +71,7 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride);
-void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, double *tnum);
+void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
                                const double *tnum, double *cost, int cstride, Counters *cnt);
@@ -91,7 +91,7 @@ bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int
 void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, const double *cost, int cmax);
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
-                     const srh_params &P, int y0, int nrows, uint32_t *cand, int cmax, int32_t *count,
+                     const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
                      Counters *cnt, int *max_count);
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,

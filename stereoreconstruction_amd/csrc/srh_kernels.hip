@@ -546,7 +546,8 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 
 __global__ __launch_bounds__(MQ_T)
 void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
-                     int y0, int nrows, uint32_t *__restrict__ cand, int cmax, int32_t *__restrict__ count,
+                     int y0, int nrows, const double *__restrict__ tnum, uint32_t *__restrict__ cand, int cmax,
+                     int32_t *__restrict__ count,
                      Counters *__restrict__ cnt, int *__restrict__ max_count)
 {
 	__shared__ uint32_t s_q[MQ_QN][MQ_T];
@@ -592,6 +593,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1,
 
 		const Vec3 camC = load3(A.cam.C);
 		const Vec3 normal = load3(A.cam.pdir);
+		const double nd = dot(normalized(normal), ray.dir);           // intersect(): n . dir, the same for every label
 		double x1 = __builtin_nan(""), y1 = __builtin_nan("");
 		for (int d = 0; d < P.num_depth_levels; ++d) {
 			bool seg = false;
@@ -599,8 +601,16 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1,
 			lw.x = 1; lw.xend = 0; lw.y = 0; lw.error = 0; lw.ystep = 0; lw.deltax = 0; lw.deltay = 0; lw.steep = false;
 			if (active) {
 				Vec3 point = camC;
-				const double depth = depth_from_label(P, true, d);
-				if (point_from_depth(ray, normal, depth, point) && cam_project(B.cam, point)) {
+				bool hit;
+				if (tnum) {
+					// label table (pinhole_label_tnum): the operands and operations of pointFromDepth / intersect
+					const double t = tnum[d] / nd;
+					hit = !(fabs(nd) < 1e-10) && !(t < 1e-10);
+					point = ray.src + t*ray.dir;
+				} else {
+					hit = point_from_depth(ray, normal, depth_from_label(P, true, d), point);
+				}
+				if (hit && cam_project(B.cam, point)) {
 					const double x2 = point.x*P.image_scale, y2 = point.y*P.image_scale;
 					if (isnan_d(x1)) { x1 = x2; y1 = y2; }
 					else {
@@ -815,13 +825,13 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 }
 
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
-                     const srh_params &P, int y0, int nrows, uint32_t *cand, int cmax, int32_t *count,
+                     const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
                      Counters *cnt, int *max_count)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, neigh[0], nneigh > 1 ? neigh[1] : 0,
-	                   nneigh > 2 ? neigh[2] : 0, P, y0, nrows, cand, cmax, count, cnt, max_count);
+	                   nneigh > 2 ? neigh[2] : 0, P, y0, nrows, tnum, cand, cmax, count, cnt, max_count);
 }
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
