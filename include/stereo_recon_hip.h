@@ -112,6 +112,13 @@ int  srh_camera_from_krt(const double K[9], const double R[9], const double t[3]
                          const double dist[5],
                          const double plane_normal[3], double plane_dist, double refr_index,
                          srh_camera *out);
+/* Camera::setP (project/camera.cpp:251-288, the path project files take: project.cpp:118-135): P is the
+ * row-major 3x4 projection matrix; it is scaled by 1/|P[2,0:3]|^2, its left 3x3 block RQ-factorised
+ * (Householder QR of the row-reversed transpose, as Eigen's HouseholderQR does it) into K (positive
+ * diagonal) and R, t = K^-1 P[:,3]; then as srh_camera_from_krt. */
+int  srh_camera_from_p(const double P[12], const double dist[5],
+                       const double plane_normal[3], double plane_dist, double refr_index,
+                       srh_camera *out);
 /* MultiViewStereo::runTask neighbour selection (multiviewstereo.cpp:335-360):
  * neigh[v*p->num_neighbours + k], count[v]. */
 int  srh_mvs_neighbours(int nviews, const srh_camera *cams, const srh_params *p,

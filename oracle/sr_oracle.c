@@ -7,6 +7,7 @@
  */
 #include "sr_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -90,6 +91,89 @@ static void inverse3(const double m[9], double out[9]) {
 	out[6] = c02*invdet;
 	out[7] = (m[1]*m[6] - m[0]*m[7])*invdet;
 	out[8] = (m[0]*m[4] - m[1]*m[3])*invdet;
+}
+
+/* Eigen::HouseholderQR<Matrix3d> (unblocked path, Eigen/src/QR/HouseholderQR.h + Householder/Householder.h):
+ * a is row-major 3x3, overwritten with R above/on the diagonal and the essential parts below; tau[k] out */
+static void householder_qr3(double a[9], double tau[3])
+{
+	for (int k = 0; k < 3; ++k) {
+		/* makeHouseholderInPlace on column k, rows k..2 */
+		const double c0 = a[k*3+k];
+		double tail = 0;
+		for (int i = k + 1; i < 3; ++i) tail += a[i*3+k]*a[i*3+k];
+		double beta;
+		if (tail <= DBL_MIN) {
+			tau[k] = 0; beta = c0;
+			for (int i = k + 1; i < 3; ++i) a[i*3+k] = 0;
+		} else {
+			beta = sqrt(c0*c0 + tail);
+			if (c0 >= 0) beta = -beta;
+			for (int i = k + 1; i < 3; ++i) a[i*3+k] /= (c0 - beta);
+			tau[k] = (beta - c0)/beta;
+		}
+		a[k*3+k] = beta;
+		/* applyHouseholderOnTheLeft to the block rows k..2, cols k+1..2 */
+		for (int j = k + 1; j < 3; ++j) {
+			double tmp = 0;
+			for (int i = k + 1; i < 3; ++i) tmp += a[i*3+k]*a[i*3+j];
+			tmp += a[k*3+j];
+			a[k*3+j] -= tau[k]*tmp;
+			for (int i = k + 1; i < 3; ++i) a[i*3+j] -= tau[k]*a[i*3+k]*tmp;
+		}
+	}
+}
+
+/* householderQ(): Q = H0 H1 H2, H_k = I - tau_k v_k v_k^T, v_k = (0.., 1, essential_k) */
+static void householder_q3(const double a[9], const double tau[3], double q[9])
+{
+	for (int i = 0; i < 9; ++i) q[i] = (i % 4 == 0) ? 1.0 : 0.0;
+	for (int k = 2; k >= 0; --k) {
+		for (int j = k; j < 3; ++j) {
+			double tmp = 0;
+			for (int i = k + 1; i < 3; ++i) tmp += a[i*3+k]*q[i*3+j];
+			tmp += q[k*3+j];
+			q[k*3+j] -= tau[k]*tmp;
+			for (int i = k + 1; i < 3; ++i) q[i*3+j] -= tau[k]*a[i*3+k]*tmp;
+		}
+	}
+}
+
+void sro_camera_set_p(sro_camera *cam, const double Pin[12], const double dist[5],
+                      const double plane_normal[3], double plane_dist, double refr_index)
+{
+	/* Camera::updateOthers, camera.cpp:251-288 */
+	double P[12];
+	const double n2 = (Pin[8]*Pin[8] + Pin[9]*Pin[9]) + Pin[10]*Pin[10];
+	for (int i = 0; i < 12; ++i) P[i] = Pin[i] / n2;
+	/* qrMatrix = (reverseRows * M)^T : element (i,j) = M(2-j, i) */
+	double a[9], tau[3], q[9];
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j)
+			a[i*3+j] = P[(2-j)*4 + i];
+	householder_qr3(a, tau);
+	householder_q3(a, tau, q);
+	/* R_ = reverseRows * Q^T ; K_ = reverseRows * Rtri^T * reverseRows */
+	double R[9], K[9];
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			R[i*3+j] = q[j*3 + (2-i)];
+			const int ri = 2 - j, rj = 2 - i;             /* Rtri^T(2-i, 2-j) = Rtri(2-j, 2-i) */
+			K[i*3+j] = (ri <= rj) ? a[ri*3+rj] : 0.0;
+		}
+	for (int axis = 2; axis >= 0; --axis) {
+		if (K[axis*3+axis] < 0) {
+			K[axis*3+axis] = -K[axis*3+axis];
+			for (int j = 0; j < 3; ++j) R[axis*3+j] = -R[axis*3+j];
+		}
+		if (K[axis*3+2] < 0) K[axis*3+2] = -K[axis*3+2];
+	}
+	/* orthonormalize(R_), Kinv_, Rinv_, t_ = Kinv_ * P_.col(3), C_ = -Rinv_ * t_: the tail of sro_camera_set,
+	 * which orthonormalises R itself; t needs the inverse of K first */
+	double Kinv[9], p3[3] = { P[3], P[7], P[11] }, t[3];
+	inverse3(K, Kinv);
+	matvec3(Kinv, p3, t);
+	sro_camera_set(cam, K, R, t, dist, plane_normal, plane_dist, refr_index);
 }
 
 void sro_camera_set(sro_camera *cam, const double K[9], const double R[9], const double t[3],

@@ -88,6 +88,12 @@ void sro_params_mvs_defaults(sro_params *p);
 
 /* Camera::set(K,R,t) (camera.cpp:225-240) + setLensDistortion (:302-313) +
  * setPlane/setRefractiveIndex (:326-344).  dist may be NULL. */
+/* Camera::setP -> updateOthers (project/camera.cpp:251-288): P /= |P[2,0:3]|^2, RQ factorisation of the left
+ * 3x3 block through Eigen's HouseholderQR of (reverseRows*M)^T (restated: Eigen is a third-party dependency
+ * absent from this image -- parity unpinned), positive-diagonal fix, then the Camera::set
+ * tail (orthonormalize, inverses, C, principal ray).  P is row-major 3x4. */
+void sro_camera_set_p(sro_camera *cam, const double P[12], const double dist[5],
+                      const double plane_normal[3], double plane_dist, double refr_index);
 void sro_camera_set(sro_camera *cam, const double K[9], const double R[9], const double t[3],
                     const double dist[5],
                     const double plane_normal[3], double plane_dist, double refr_index);

@@ -63,7 +63,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 # every symbol include/stereo_recon_hip.h declares
 EXPORTS = [
     "srh_abi_version", "srh_last_error", "srh_device_count",
-    "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_mvs_neighbours",
+    "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_camera_from_p",
+    "srh_mvs_neighbours",
     "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
@@ -102,6 +103,7 @@ def lib():
     L.srh_params_mvs_defaults.restype = None
     L.srh_camera_from_krt.argtypes = [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                       C.c_double, C.c_double, C.POINTER(Camera)]
+    L.srh_camera_from_p.argtypes = [c_double_p, c_double_p, c_double_p, C.c_double, C.c_double, C.POINTER(Camera)]
     L.srh_mvs_neighbours.argtypes = [C.c_int, C.POINTER(Camera), C.POINTER(Params), c_int32_p, c_int32_p]
     L.srh_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.srh_destroy.argtypes = [vp]
@@ -179,6 +181,17 @@ def camera_from_krt(K, R, t, dist=None, plane_normal=None, plane_dist=0.0, refr_
                                      _dptr(d) if d is not None else None,
                                      _dptr(n) if n is not None else None,
                                      plane_dist, refr_index, C.byref(cam)))
+    return cam
+
+
+def camera_from_p(P, dist=None, plane_normal=None, plane_dist=0.0, refr_index=1.0):
+    """Camera::setP (3x4 projection matrix, the project-file path) -> srh_camera snapshot."""
+    cam = Camera()
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(12)
+    d = None if dist is None else np.ascontiguousarray(dist, dtype=np.float64).reshape(5)
+    n = None if plane_normal is None else np.ascontiguousarray(plane_normal, dtype=np.float64).reshape(3)
+    _check(lib().srh_camera_from_p(_dptr(P), _dptr(d) if d is not None else None,
+                                   _dptr(n) if n is not None else None, plane_dist, refr_index, C.byref(cam)))
     return cam
 
 

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <limits>
 #include <vector>
 
 using namespace srh;
@@ -245,6 +246,73 @@ extern "C" int srh_camera_from_krt(const double K[9], const double Rin[9], const
 	c.is_refractive = (!near_zero(c.refr_index - 1) && !near_zero(c.plane_dist));   // camera.cpp:326-344
 	*out = c;
 	return SRH_OK;
+}
+
+extern "C" int srh_camera_from_p(const double Pin[12], const double dist[5], const double plane_normal[3],
+                                 double plane_dist, double refr_index, srh_camera *out)
+{
+	if (!Pin || !out) return fail(SRH_E_INVALID, "null argument");
+	// Camera::updateOthers (camera.cpp:251-288)
+	const double n2 = (Pin[8]*Pin[8] + Pin[9]*Pin[9]) + Pin[10]*Pin[10];
+	if (!(n2 > 0)) return fail(SRH_E_INVALID, "projection matrix with a zero third row");
+	double P[3][4];
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) P[i][j] = Pin[i*4 + j] / n2;
+	// A = (reverseRows * M)^T, Householder QR (Eigen::HouseholderQR, unblocked): A = Q * Rt
+	double A[3][3], tau[3];
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = P[2 - j][i];
+	for (int k = 0; k < 3; ++k) {
+		const double c0 = A[k][k];
+		double tailSq = 0;
+		for (int i = k + 1; i < 3; ++i) tailSq += A[i][k]*A[i][k];
+		double beta;
+		if (tailSq <= std::numeric_limits<double>::min()) {       // makeHouseholder: nothing to annihilate
+			tau[k] = 0; beta = c0;
+			for (int i = k + 1; i < 3; ++i) A[i][k] = 0;
+		} else {
+			beta = sqrt(c0*c0 + tailSq);
+			if (c0 >= 0) beta = -beta;
+			for (int i = k + 1; i < 3; ++i) A[i][k] /= (c0 - beta);   // essential part, stored below the diagonal
+			tau[k] = (beta - c0)/beta;
+		}
+		A[k][k] = beta;
+		for (int j = k + 1; j < 3; ++j) {                             // H_k applied to the remaining columns
+			double tmp = 0;
+			for (int i = k + 1; i < 3; ++i) tmp += A[i][k]*A[i][j];
+			tmp += A[k][j];
+			A[k][j] -= tau[k]*tmp;
+			for (int i = k + 1; i < 3; ++i) A[i][j] -= tau[k]*A[i][k]*tmp;
+		}
+	}
+	double Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+	for (int k = 2; k >= 0; --k)                                     // householderQ(): H0 H1 H2
+		for (int j = k; j < 3; ++j) {
+			double tmp = 0;
+			for (int i = k + 1; i < 3; ++i) tmp += A[i][k]*Q[i][j];
+			tmp += Q[k][j];
+			Q[k][j] -= tau[k]*tmp;
+			for (int i = k + 1; i < 3; ++i) Q[i][j] -= tau[k]*A[i][k]*tmp;
+		}
+	double K[9], R[9];
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			R[i*3 + j] = Q[j][2 - i];                                  // reverseRows * Q^T
+			K[i*3 + j] = (2 - j <= 2 - i) ? A[2 - j][2 - i] : 0.0;     // reverseRows * Rt^T * reverseRows
+		}
+	for (int axis = 2; axis >= 0; --axis) {                          // positive diagonal of K (camera.cpp:266-275)
+		if (K[axis*3 + axis] < 0) {
+			K[axis*3 + axis] = -K[axis*3 + axis];
+			for (int j = 0; j < 3; ++j) R[axis*3 + j] = -R[axis*3 + j];
+		}
+		if (K[axis*3 + 2] < 0) K[axis*3 + 2] = -K[axis*3 + 2];
+	}
+	// t_ = Kinv_ * P_.col(3): Kinv is the cofactor inverse srh_camera_from_krt computes again below
+	srh_camera tmpc;
+	const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+	int rc = srh_camera_from_krt(K, I3, z3, nullptr, nullptr, 0.0, 1.0, &tmpc);
+	if (rc) return rc;
+	const Vec3 t = matvec(tmpc.Kinv, v3(P[0][3], P[1][3], P[2][3]));
+	const double tt[3] = { t.x, t.y, t.z };
+	return srh_camera_from_krt(K, R, tt, dist, plane_normal, plane_dist, refr_index, out);
 }
 
 extern "C" int srh_mvs_neighbours(int nviews, const srh_camera *cams, const srh_params *p,

@@ -197,6 +197,16 @@ def camera_set(K, R, t, dist=None, plane_normal=None, plane_dist=0.0, refr_index
     return cam
 
 
+def camera_set_p(P, dist=None, plane_normal=None, plane_dist=0.0, refr_index=1.0):
+    cam = Camera()
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(12)
+    d = None if dist is None else np.ascontiguousarray(dist, dtype=np.float64).reshape(5)
+    n = None if plane_normal is None else np.ascontiguousarray(plane_normal, dtype=np.float64).reshape(3)
+    lib().sro_camera_set_p(C.byref(cam), dptr(P), dptr(d) if d is not None else None,
+                           dptr(n) if n is not None else None, C.c_double(plane_dist), C.c_double(refr_index))
+    return cam
+
+
 def weights(img, cx, cy, p):
     ws = 2 * p.window_radius + 1
     out = np.empty((ws, ws), dtype=np.float64)

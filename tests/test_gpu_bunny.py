@@ -62,3 +62,34 @@ def test_bunny_pair_twoview(hip_ctx):
     assert ok, "left cross-check: " + msg
     ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(1), cr, 1e-9)
     assert ok, "right cross-check: " + msg
+
+
+def test_bunny_pair_from_the_project_file(hip_ctx):
+    """The same pair with its cameras taken from the project XML fixture through Camera::setP
+    (srh_camera_from_p on the product side, sro_camera_set_p on the oracle side): SURVEY 8(f) rank 1."""
+    import xml.etree.ElementTree as ET
+    g = np.load(GOLD)
+    root = ET.parse(os.path.join(os.path.dirname(GOLD), "project_fixture.xml")).getroot()
+    ocams, cams = [], []
+    for cid in ("7310085", "7310087"):
+        cam = [c for c in root.find("cameras") if c.get("id") == cid][0]
+        pm, ld = cam.find("projectionMatrix"), cam.find("lensDistortion")
+        P = np.array([[float(pm.get("m%d%d" % (i, j))) for j in (1, 2, 3, 4)] for i in (1, 2, 3)])
+        dist = np.array([float(ld.get(k, "0")) for k in ("k1", "k2", "p1", "p2", "k3")])
+        ocams.append(O.camera_set_p(P, dist))
+        cams.append(capi.camera_from_p(P, dist))
+        for f in ("K", "R", "t", "C", "pdir", "dist"):
+            assert np.array_equal(np.array(getattr(ocams[-1], f)), np.array(getattr(cams[-1], f))), (cid, f)
+    params = dict(min_depth=30.0, max_depth=80.0, num_depth_levels=100, image_scale=float(g["scale"][0]),
+                  window_radius=5, weight_kind=1)
+    op, p = O.params_twoview(**params), capi.params_twoview(**params)
+    imgs = [O.OImage(g["left_rgba"], g["left_mask"]), O.OImage(g["right_rgba"], g["right_mask"])]
+    hip_ctx.upload_view(0, g["left_rgba"], g["left_mask"], cams[0])
+    hip_ctx.upload_view(1, g["right_rgba"], g["right_mask"], cams[1])
+    y0, y1 = 90, 102
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op, y0, y1)
+    hip_ctx.upload_depth(0, np.full(want.shape, np.nan))
+    hip_ctx.twoview_wta(0, 1, p, y0, y1)
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0)[y0:y1], want[y0:y1], 1e-9)
+    assert ok, msg
+    assert np.isfinite(want[y0:y1]).sum() > 100
