@@ -236,7 +236,8 @@ def main():
     W, H, D, wkind, seed, desc = WORKLOADS[args.workload]
     # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair
     (unit,) = list(shard_units(world, world, rank))
-    L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + 0x10000 * unit)
+    # C5: the 8 pairs of SURVEY 8(d) are seeds ...50-...57; other workloads: one independent pair per rank
+    L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + (unit if args.workload == "c5" else 0x10000 * unit))
     cams3 = synthetic.rectified_cameras(W, H)
     zmin, zmax = synthetic.rectified_depth_range(W, D)
     (Kl, Rl, tl), (Kr, Rr, tr) = cams3

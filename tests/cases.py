@@ -80,18 +80,29 @@ def get_twoview(name, **over):
 
 
 def mvs_case(name="mvs_sphere", nviews=4, w=56, h=40, D=24, seed=0x5EED0B00, weight_kind=1, radius=2,
-             distortion=False, step_deg=12.0):
-    cams = S.semicircle_rig(nviews, w, h, radius=10.0, step_deg=step_deg, focal=1.4 * w)
-    rgba, masks, depth = S.render_sphere_views(cams, w, h, seed, sphere_radius=2.0, tex_size=256)
-    views = []
+             distortion=False, step_deg=12.0, scale=1.0, refractive=False, mixed_sizes=False):
+    sizes = [(w, h)] * nviews
+    if mixed_sizes:                                      # every view its own raster (and calibration)
+        sizes = [(w - 8 * (v % 3), h - 4 * (v % 2)) for v in range(nviews)]
+    views, depth = [], []
     for v in range(nviews):
+        wv, hv = sizes[v]
+        cams = S.semicircle_rig(nviews, wv, hv, radius=10.0, step_deg=step_deg, focal=1.4 * wv)
+        rgba, masks, dep = S.render_sphere_views([cams[v]], wv, hv, seed, sphere_radius=2.0, tex_size=256)
+        K, R, t = cams[v]
+        if scale != 1.0:
+            # the images handed over are ALREADY scaled: cameras describe the full-size image
+            K = K.copy()
+            K[:2] /= scale
         dist = None
         if distortion:
             dist = np.array([-0.1 + 0.01 * v, 0.2, 0.002, -0.001 * v, 0.0])
-        views.append((rgba[v], masks[v], cams[v], dist, None))
+        plane = (np.array([0.01 * v, -0.02, 1.0]), 0.1, 1.333) if refractive else None
+        views.append((rgba[0], masks[0], (K, R, t), dist, plane))
+        depth.append(dep[0])
     zmin, zmax = 7.5, 10.5
     params = dict(min_depth=zmin, max_depth=zmax, num_depth_levels=D, window_radius=radius,
-                  weight_kind=weight_kind, image_scale=1.0,
+                  weight_kind=weight_kind, image_scale=scale,
                   cross_check_threshold=2.0 * (zmax - zmin) / (D - 1))
     return dict(name=name, kind="mvs", views=views, params=params, gt_depth=depth)
 
@@ -101,6 +112,9 @@ MVS_CASES = {
     "mvs_adaptive": dict(weight_kind=0),
     "mvs_distorted": dict(weight_kind=1, distortion=True, nviews=3),
     "mvs_five_views": dict(weight_kind=1, nviews=5, w=48, h=32, D=16),
+    "mvs_mixed_sizes": dict(weight_kind=1, nviews=3, mixed_sizes=True, D=16),
+    "mvs_scaled": dict(weight_kind=0, nviews=3, scale=0.5, w=48, h=36, D=16),
+    "mvs_refractive": dict(weight_kind=1, nviews=3, refractive=True, w=48, h=32, D=14),
 }
 
 
