@@ -642,7 +642,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				HIP_TRY(hipStreamSynchronize(c->stream));
 				cmax = std::max(8, (maxc + 7) & ~7);
 			}
-			bool rows_mode = c->list_rows;
+			bool rows_mode = c->list_rows && W < 32768 && H < 32768;       // spans and row origins are stored as 16-bit signed
 			int smax = c->list_smax_hint > 0 ? c->list_smax_hint : cmax + 64;
 			for (int pass = 0; pass < 5; ++pass) {
 				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));

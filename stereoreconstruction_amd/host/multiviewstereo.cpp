@@ -51,6 +51,29 @@ void MultiViewStereo::initialize(const std::vector<CameraPtr> &views_, const std
 	neighbours.assign(views.size(), std::vector<int>());
 }
 
+void MultiViewStereo::initialize(ProjectPtr project_, ImageSetPtr imageSet__, const std::vector<CameraPtr> &views_,
+                                 double minDepth_, double maxDepth_, int numDepthLevels_,
+                                 double crossCheckThreshold_, double imageScale_, const ImageLoader &load)
+{
+	// multiviewstereo.cpp:193-247 with the file access handed to `load`
+	std::vector<CameraPtr> kept;
+	std::vector<Image> imgs, maskSrc;
+	for (size_t i = 0; i < views_.size(); ++i) if (views_[i] && imageSet__) {
+		const ProjectImagePtr pi = imageSet__->defaultImageForCamera(views_[i]);
+		Image im, ms;
+		if (!pi || !load || !load(pi->file(), imageScale_, im, ms) || im.isNull()) continue;
+		kept.push_back(views_[i]); imgs.push_back(im); maskSrc.push_back(ms);
+	}
+	initialize(kept, imgs, minDepth_, maxDepth_, numDepthLevels_, crossCheckThreshold_, imageScale_);
+	project = project_;
+	imageSet_ = imageSet__;
+	for (size_t v = 0; v < views.size(); ++v) {
+		// mask: alpha == 255 on the fast-scaled copy; no alpha channel => WHITE everywhere (:225-237)
+		if (maskSrc[v].isNull()) masks[v].assign(masks[v].size(), 1);
+		else if (maskSrc[v].w == images[v].w && maskSrc[v].h == images[v].h) masks[v] = maskFromAlpha(maskSrc[v]);
+	}
+}
+
 int MultiViewStereo::numSteps() const { return 2*static_cast<int>(views.size()); }
 
 void MultiViewStereo::colorize(size_t v) {

@@ -5,12 +5,14 @@
 // camera parameters and pixels -- feed this path.
 #pragma once
 
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "camera.hpp"
 #include "image.hpp"
+#include "project.hpp"
 #include "task.hpp"
 
 struct PLYPoint { double p[3]; uint8_t rgb[3]; };
@@ -31,6 +33,20 @@ public:
 	                double crossCheckThreshold,
 	                double imageScale = 1.0);
 
+	// The reference's own signature (multiviewstereo.hpp:46-52): views are looked up in `imageSet` (default image
+	// per camera; cameras without one, or whose file `load` cannot produce, are skipped, :218-220).  Decoding and
+	// the two Qt scalings stay with the caller: load(file, imageScale, image, maskSource) returns the
+	// smooth-scaled image and -- when the file has an alpha channel -- the fast-scaled copy the mask is taken from
+	// (maskSource left null: all pixels WHITE, :225-237).
+	typedef std::function<bool(const std::string &file, double imageScale, Image &image, Image &maskSource)> ImageLoader;
+	void initialize(ProjectPtr project, ImageSetPtr imageSet, const std::vector<CameraPtr> &views,
+	                double minDepth, double maxDepth,
+	                int numDepthLevels,
+	                double crossCheckThreshold,
+	                double imageScale,
+	                const ImageLoader &load);
+	ImageSetPtr imageSet() const { return imageSet_; }   // the image set of the last initialize (multiviewstereo.hpp:62)
+
 	std::string title() const { return "Multi-View Stereo"; }
 	int numSteps() const;                              // 2 * views (multiviewstereo.cpp:319-321)
 
@@ -47,6 +63,8 @@ protected:
 private:
 	void colorize(size_t v);
 
+	ProjectPtr project;
+	ImageSetPtr imageSet_;
 	std::vector<CameraPtr> views;
 	std::vector<Image> images;
 	std::vector<std::vector<uint8_t> > masks;

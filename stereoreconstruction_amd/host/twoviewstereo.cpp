@@ -112,6 +112,34 @@ std::vector<std::pair<int, int> > TwoViewStereo::epipolarCurve(int x, int y, boo
 	return curve;
 }
 
+void TwoViewStereo::computeCostVolumes(CameraPtr leftView_, CameraPtr rightView_) {
+	if (!ctx_ || !leftView_ || !rightView_) return;
+	leftView = leftView_; rightView = rightView_;
+	if (!uploadViews()) return;
+	if (srh_twoview_wta(ctx_, 0, 1, &params_, 0, 0) != SRH_OK || srh_twoview_wta(ctx_, 1, 0, &params_, 0, 0) != SRH_OK ||
+	    srh_view_depth_download(ctx_, 0, computedDepthLeft.data()) != SRH_OK ||
+	    srh_view_depth_download(ctx_, 1, computedDepthRight.data()) != SRH_OK)
+		error_ = srh_last_error();
+}
+
+void TwoViewStereo::crossCheck(CameraPtr leftView_, CameraPtr rightView_) {
+	if (!ctx_ || !leftView_ || !rightView_) return;
+	leftView = leftView_; rightView = rightView_;
+	if (!uploadViews()) return;
+	if (srh_view_depth_upload(ctx_, 0, computedDepthLeft.data()) != SRH_OK ||
+	    srh_view_depth_upload(ctx_, 1, computedDepthRight.data()) != SRH_OK ||
+	    srh_twoview_cross_check(ctx_, 0, 1, &params_) != SRH_OK ||
+	    srh_view_depth_download(ctx_, 0, computedDepthLeft.data()) != SRH_OK ||
+	    srh_view_depth_download(ctx_, 1, computedDepthRight.data()) != SRH_OK)
+		error_ = srh_last_error();
+}
+
+double TwoViewStereo::depthFromLabel(int label) const {
+	double t = static_cast<double>(label) / (numDepthLevels - 1);
+	t /= (5.0 - 4.0*t);
+	return minDepth*(1.0 - t) + maxDepth*t;
+}
+
 void TwoViewStereo::computeDepthMaps() {
 	// twoviewstereo.cpp:150-227: cost volumes (steps 1,3), cross-check (5), colourise, finished (8)
 	if (!ctx_) { if (error_.empty()) error_ = "no device context"; return; }

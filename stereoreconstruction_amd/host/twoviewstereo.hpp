@@ -48,6 +48,16 @@ public:
 protected:
 	void runTask() { computeDepthMaps(); }
 
+	// the reference's protected stages (twoviewstereo.hpp:72-84), for subclasses that re-sequence them:
+	// WTA of both directions into computedDepthLeft/Right (twoviewstereo.cpp:233-501, non-MRF body) ...
+	void computeCostVolumes(CameraPtr leftView, CameraPtr rightView);
+	// ... and the mutual consistency filter on them (:596-672)
+	void crossCheck(CameraPtr leftView, CameraPtr rightView);
+	// label -> depth, non-uniform (:981-985)
+	double depthFromLabel(int label) const;
+	// cost_sad, filterInvalidPixels and weightedMedian are unreachable in the reference (never called /
+	// call site under `#if 0`, twoviewstereo.cpp:200) and have no counterpart here.
+
 private:
 	bool uploadViews();
 	void colorize(const DepthMap &d, Image &out) const;

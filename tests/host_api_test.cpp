@@ -5,6 +5,9 @@
 //
 //   host_api_test twoview in.bin out.bin
 //   host_api_test mvs     in.bin out.bin
+//   host_api_test mvsproject project.xml out.bin setId minDepth maxDepth D crossCheck scale
+//        (the reference's own initialize(project, imageSet, views, ...) signature; image files are raw
+//         "int32 w, h; uint8 rgba[w*h*4]" blobs read by the ImageLoader callback)
 //
 // in.bin : int32 nviews, w, h, D, radius, weight_kind; double minDepth, maxDepth, scale, crossCheck;
 //          per view: double K[9], R[9], t[3], dist[5]; uint8 rgba[w*h*4]; uint8 mask[w*h] (twoview only)
@@ -14,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "multiviewstereo.hpp"
@@ -21,7 +26,50 @@
 
 template <class T> static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
 
+static bool loadRaw(const std::string &file, double, Image &image, Image &maskSource) {
+	FILE *f = fopen(file.c_str(), "rb");
+	if (!f) return false;                              // QFileInfo(file).exists() == false: the view is skipped
+	int32_t wh[2];
+	rd(f, wh, 2);
+	image = Image(wh[0], wh[1]);
+	rd(f, image.rgba.data(), image.rgba.size());
+	fclose(f);
+	maskSource = image;                                // has an alpha channel: mask = alpha == 255
+	return true;
+}
+
+static int runProject(int argc, char **argv) {
+	if (argc != 10) { fprintf(stderr, "usage: %s mvsproject project.xml out setId minDepth maxDepth D crossCheck scale\n", argv[0]); return 2; }
+	ProjectPtr prj;
+	try { prj.reset(new Project(argv[2])); } catch (const std::runtime_error &e) { fprintf(stderr, "%s\n", e.what()); return 3; }
+	ImageSetPtr set = prj->imageSet(argv[4]);
+	if (!set) { fprintf(stderr, "no image set %s\n", argv[4]); return 3; }
+	std::vector<CameraPtr> cams;
+	for (const auto &kv : prj->cameras()) cams.push_back(kv.second);          // id order
+	std::shared_ptr<MultiViewStereo> m(new MultiViewStereo());
+	if (!m->lastError().empty()) { fprintf(stderr, "ctor: %s\n", m->lastError().c_str()); return 3; }
+	m->initialize(prj, set, cams, atof(argv[5]), atof(argv[6]), atoi(argv[7]), atof(argv[8]), atof(argv[9]), loadRaw);
+	if (m->imageSet() != set) return 5;
+	m->run();
+	if (!m->lastError().empty()) { fprintf(stderr, "run: %s\n", m->lastError().c_str()); return 3; }
+	FILE *o = fopen(argv[3], "wb");
+	if (!o) { perror(argv[3]); return 2; }
+	int32_t n = 0;
+	for (size_t v = 0; v < cams.size(); ++v) if (m->depths(cams[v])) ++n;
+	fwrite(&n, sizeof(n), 1, o);
+	for (size_t v = 0; v < cams.size(); ++v) {
+		const std::vector<double> *d = m->depths(cams[v]);
+		if (!d) continue;                                  // camera without an image: not part of the run
+		const int32_t len = static_cast<int32_t>(cams[v]->id().size()), cnt = static_cast<int32_t>(d->size());
+		fwrite(&len, sizeof(len), 1, o); fwrite(cams[v]->id().data(), 1, len, o);
+		fwrite(&cnt, sizeof(cnt), 1, o); fwrite(d->data(), sizeof(double), d->size(), o);
+	}
+	fclose(o);
+	return 0;
+}
+
 int main(int argc, char **argv) {
+	if (argc >= 2 && !strcmp(argv[1], "mvsproject")) return runProject(argc, argv);
 	if (argc != 4) { fprintf(stderr, "usage: %s twoview|mvs in out\n", argv[0]); return 2; }
 	const bool mvs = !strcmp(argv[1], "mvs");
 	FILE *f = fopen(argv[2], "rb");

@@ -114,3 +114,56 @@ def test_multiviewstereo_class(tmp_path):
     for v in range(nv):
         ok, msg, _ = cases.compare_depth(got[v], ref[v], 1e-9)
         assert ok, "view %d: %s" % (v, msg)
+
+
+@pytest.mark.gpu
+def test_multiviewstereo_from_a_project_file(tmp_path):
+    """The reference's own entry: initialize(project, imageSet, views, ...) on a project XML (cameras as 3x4
+    projection matrices -> Camera::setP, image set -> default image per camera; the camera without an image
+    file is skipped, multiviewstereo.cpp:218-220), then run()."""
+    exe = _build(str(tmp_path))
+    case = cases.get_mvs("mvs_geodesic", w=48, h=32, D=14, nviews=3)
+    p = case["params"]
+    xml = ['<project><cameras>']
+    Ps, ims = {}, {}
+    for v, (rgba, mask, (K, R, t), dist, plane) in enumerate(case["views"]):
+        cid = "cam%d" % v
+        P = K @ np.column_stack([R, t])
+        Ps[cid] = P
+        attrs = " ".join('m%d%d="%r"' % (i + 1, j + 1, float(P[i, j])) for i in range(3) for j in range(4))
+        xml.append('<camera id="%s"><projectionMatrix %s/></camera>' % (cid, attrs))
+        im = rgba.copy()
+        im[..., 3] = np.where(mask == 1, 255, 51)
+        ims[cid] = (im, mask)
+        with open(str(tmp_path / (cid + ".raw")), "wb") as f:
+            f.write(struct.pack("<2i", im.shape[1], im.shape[0]))
+            f.write(np.ascontiguousarray(im).tobytes())
+    xml.append('<camera id="zz_noimage"><projectionMatrix %s/></camera>' % attrs)
+    xml.append('</cameras><imageSets><imageSet id="s0">')
+    xml += ['<image for="cam%d" file="cam%d.raw"/>' % (v, v) for v in range(3)]
+    xml.append('<image for="zz_noimage" file="missing.raw"/></imageSet></imageSets></project>')
+    prj = str(tmp_path / "project.xml")
+    open(prj, "w").write("\n".join(xml))
+    outp = str(tmp_path / "out.bin")
+    subprocess.check_call([exe, "mvsproject", prj, outp, "s0", repr(p["min_depth"]), repr(p["max_depth"]),
+                           str(p["num_depth_levels"]), repr(p["cross_check_threshold"]), "1.0"])
+    raw = open(outp, "rb").read()
+    (n,) = struct.unpack_from("<i", raw, 0)
+    off, got = 4, {}
+    for _ in range(n):
+        (ln,) = struct.unpack_from("<i", raw, off); off += 4
+        cid = raw[off:off + ln].decode(); off += ln
+        (cnt,) = struct.unpack_from("<i", raw, off); off += 4
+        got[cid] = np.frombuffer(raw[off:off + 8 * cnt], np.float64).reshape(32, 48); off += 8 * cnt
+    assert sorted(got) == ["cam0", "cam1", "cam2"]
+    ids = sorted(Ps)
+    ocams = [O.camera_set_p(Ps[c]) for c in ids]
+    imgs = [O.OImage(ims[c][0], ims[c][1]) for c in ids]
+    op = O.params_mvs(**p)
+    neigh = O.mvs_neighbours(ocams, op)
+    ref = [O.mvs_initial_estimate(imgs, ocams, v, neigh[v], op)[0] for v in range(3)]
+    for v in range(3):
+        O.mvs_cross_check(imgs, ocams, v, op, ref)
+    for v, c in enumerate(ids):
+        ok, msg, _ = cases.compare_depth(got[c], ref[v], 1e-9)
+        assert ok, "%s: %s" % (c, msg)
