@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of BASELINE.json: M disparity-hypotheses/s (W x H x D) of
 the TwoView cost-volume / support-weight / WTA path on synthetic 1920x1080x256 pairs.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small|c5|c4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small|c5|c4|c1]
 
 A "step" is one pass of the hot path over one stereo pair per GPU: WTA left->right,
 WTA right->left, cross-check, and the device-side hand-over of the two depth maps
@@ -47,6 +47,11 @@ WORKLOADS = {
     # curved epipolar lines -> the general curve-walk kernel
     "c5": (1920, 1080, 256, capi.WEIGHT_GEODESIC, 0x5EED0050,
            "C5: C3 geometry + refractive interface (dist 0.1, ratio 1.333), one pair per GPU"),
+    # C1: the example project's bunny pair as the reference ingests it (tests/golden/bunny_pair.npz: Qt smooth
+    # scaling 0.25, alpha masks, lens distortion; cameras 7310085/7310087), 100 levels -> general-geometry kernels
+    "c1": (256, 192, 100, capi.WEIGHT_GEODESIC, 0,
+           "C1: example 'bunny' pair 1024x768 at scale 0.25 (256x192), 100 depth levels 30-80, GeodesicWeight r=5, "
+           "distorted verged cameras"),
     "c4": (1280, 960, 128, capi.WEIGHT_GEODESIC, 0x5EED0004,
            "C4: 8 views on a semicircle (22.5 deg apart) around a textured sphere, 1280x960, 128 uniform depth "
            "levels, MultiViewStereo r=2, 3 neighbours"),
@@ -173,15 +178,15 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     return result
 
 
-def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, plane=None):
+def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, plane=None, scale=1.0, dists=(None, None)):
     """Time the oracle (CPU restatement, one thread) on a centre row band of the same pair."""
     import oracle_ffi as O
     (Kl, Rl, tl), (Kr, Rr, tr) = cam_triples
     if plane is None:
-        cl, cr = O.camera_set(Kl, Rl, tl), O.camera_set(Kr, Rr, tr)
+        cl, cr = O.camera_set(Kl, Rl, tl, dists[0]), O.camera_set(Kr, Rr, tr, dists[1])
     else:
         cl, cr = O.camera_set(Kl, Rl, tl, None, *plane), O.camera_set(Kr, Rr, tr, None, *plane)
-    p = O.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=weight_kind)
+    p = O.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=weight_kind, image_scale=scale)
     li, ri = O.OImage(L, ml), O.OImage(R, mr)
     h, w = L.shape[:2]
     y0 = h // 2 - rows // 2
@@ -237,17 +242,25 @@ def main():
     # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair
     (unit,) = list(shard_units(world, world, rank))
     # C5: the 8 pairs of SURVEY 8(d) are seeds ...50-...57; other workloads: one independent pair per rank
-    L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + (unit if args.workload == "c5" else 0x10000 * unit))
-    cams3 = synthetic.rectified_cameras(W, H)
-    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    scale, dist_l, dist_r = 1.0, None, None
+    if args.workload == "c1":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "bunny_pair.npz"))
+        L, R, ml, mr = g["left_rgba"], g["right_rgba"], g["left_mask"], g["right_mask"]
+        cams3 = ((g["left_K"], g["left_R"], g["left_t"]), (g["right_K"], g["right_R"], g["right_t"]))
+        zmin, zmax, scale = 30.0, 80.0, float(g["scale"][0])
+        dist_l, dist_r = g["left_dist"], g["right_dist"]
+    else:
+        L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + (unit if args.workload == "c5" else 0x10000 * unit))
+        cams3 = synthetic.rectified_cameras(W, H)
+        zmin, zmax = synthetic.rectified_depth_range(W, D)
     (Kl, Rl, tl), (Kr, Rr, tr) = cams3
     if args.workload == "c5":
         plane = (np.array([0.0, 0.0, 1.0]), 0.1, 1.333)
         cl = capi.camera_from_krt(Kl, Rl, tl, None, *plane)
         cr = capi.camera_from_krt(Kr, Rr, tr, None, *plane)
     else:
-        cl, cr = capi.camera_from_krt(Kl, Rl, tl), capi.camera_from_krt(Kr, Rr, tr)
-    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
+        cl, cr = capi.camera_from_krt(Kl, Rl, tl, dist_l), capi.camera_from_krt(Kr, Rr, tr, dist_r)
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind, image_scale=scale)
 
     ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -344,8 +357,12 @@ def main():
             "kernels_ms": {k: [round(v[0], 3), v[1]] for k, v in sorted(prof.items())},
         }
         if world == 1 and args.cpu_rows > 0:
-            base, cpu_depth, y0 = cpu_baseline(L, R, ml, mr, cams3, zmin, zmax, D, wkind, args.cpu_rows,
-                                                (np.array([0.0, 0.0, 1.0]), 0.1, 1.333) if args.workload == "c5" else None)
+            base, cpu_depth, y0 = cpu_baseline(L, R, ml, mr, cams3, zmin, zmax, D, wkind,
+                                                args.cpu_rows if args.workload != "c1" else max(args.cpu_rows, 24),
+                                                (np.array([0.0, 0.0, 1.0]), 0.1, 1.333) if args.workload == "c5" else None,
+                                                scale, (dist_l, dist_r))
+            if args.workload == "c1":
+                args.cpu_rows = max(args.cpu_rows, 24)
             # the timed CPU band doubles as a full-size parity spot check of the WTA pass
             ctx.twoview_wta(0, 1, p, y0, y0 + args.cpu_rows)
             got = ctx.download_depth(0)[y0:y0 + args.cpu_rows]

@@ -45,6 +45,9 @@ struct ViewHost {
 	double   *edges = nullptr;     // 4 planes of neighbour colour distances (geodesic windows)
 	uint8_t  *full = nullptr;      // 1 where the whole (2*full_r+1)^2 TwoView window is usable
 	int       full_r = 0;
+	// how the candidate lists of this view against slot j are best evaluated, learnt from the last run:
+	// 0 unknown, 1 row runs (srh_rows.hip), 2 list order (srh_list.hip: steep curves)
+	uint8_t   list_mode[SRH_MAX_VIEWS] = {0};
 	srh_camera cam;
 };
 
@@ -464,6 +467,7 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	}
 	v.cam = *cam;
 	v.full_r = 0;                                               // recomputed on demand for the new pixels
+	for (int j = 0; j < SRH_MAX_VIEWS; ++j) { v.list_mode[j] = 0; c->views[j].list_mode[slot] = 0; }   // new geometry
 	HIP_TRY(hipMemcpyAsync(v.rgba, rgba, n*4, hipMemcpyHostToDevice, c->stream));
 	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
 	else      HIP_TRY(hipMemsetAsync(v.mask, 1, n, c->stream));
@@ -643,6 +647,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				cmax = std::max(8, (maxc + 7) & ~7);
 			}
 			bool rows_mode = c->list_rows && W < 32768 && H < 32768;       // spans and row origins are stored as 16-bit signed
+			if (c->views[ref].list_mode[oth] == 2) rows_mode = false;      // learnt: steep curves, list order is cheaper
 			int smax = c->list_smax_hint > 0 ? c->list_smax_hint : cmax + 64;
 			for (int pass = 0; pass < 5; ++pass) {
 				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
@@ -694,10 +699,20 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 					// a curve crossing more than SRH_ROWS_NR rows, or more slots than the 16-bit slot base
 					// holds: this pair is evaluated in list order instead
 					const int need = (mx[1] + 7) & ~7;
-					if (mx[2] || need > 65528) { rows_mode = false; if (maxc > cmax) cmax = (maxc + 7) & ~7; continue; }
+					if (mx[2] || need > 65528) {
+						rows_mode = false; c->views[ref].list_mode[oth] = 2;
+						if (maxc > cmax) cmax = (maxc + 7) & ~7;
+						continue;
+					}
 					if (maxc <= cmax && need <= smax) {
 						if (cmax > c->list_cmax_hint) c->list_cmax_hint = cmax;
 						if (smax > c->list_smax_hint) c->list_smax_hint = smax;
+						// short spans (steep curves) fill their 8-column blocks badly: a slot costs ~0.4 of a
+						// candidate evaluated in list order, so beyond 2.2 slots per candidate the other path wins
+						Counters hc;
+						HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+						HIP_TRY(hipStreamSynchronize(c->stream));
+						c->views[ref].list_mode[oth] = (hc.n_slots > 2.2*(double)hc.n_listed) ? 2 : 1;
 						break;
 					}
 					if (maxc > cmax) { cmax = (maxc + 7) & ~7; if (need <= smax) smax = std::max(smax, cmax + 64); }

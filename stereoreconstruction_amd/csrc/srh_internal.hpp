@@ -44,6 +44,7 @@ struct Counters {
 	unsigned long long n_eval;
 	unsigned long long n_eval_device;
 	unsigned long long not_row_aligned;   // pixels whose curve leaves their own row
+	unsigned long long n_listed, n_slots; // row-run lists: distinct candidates / cost slots (8-column blocks) they occupy
 	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
 	unsigned long long dbg_phase[8];
 };

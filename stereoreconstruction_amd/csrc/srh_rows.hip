@@ -96,6 +96,8 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	if (threadIdx.x < 3 && s_max[threadIdx.x] > 0) atomicMax(&maxes[threadIdx.x], s_max[threadIdx.x]);
 	block_count_add(&cnt->n_eval, n_eval);
 	block_count_add(&cnt->n_pixels, n_pix);
+	block_count_add(&cnt->n_listed, (unsigned)n_kept);
+	block_count_add(&cnt->n_slots, (unsigned)slots);
 }
 
 void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
