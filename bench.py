@@ -329,7 +329,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if args.workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
             "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
                        "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
