@@ -659,10 +659,12 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				if (lrows < 1) lrows = 1;
 				if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
 				if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
-				if ((rc = ensure(c->cost, c->cost_cap, lrows*W*(size_t)ccap))) return rc;
-				if ((rc = ensure(c->lcand, c->lcand_cap, lrows*W*(size_t)cmax))) return rc;
+				// row runs: lists and row tables are tiled per 64 pixels, cost slots per 32-pixel tile of a row
+				const size_t px64 = (lrows*W + 63) & ~(size_t)63, px32 = lrows*(size_t)((W + 31)/32)*32;
+				if ((rc = ensure(c->cost, c->cost_cap, (rows_mode ? px32 : lrows*W)*(size_t)ccap))) return rc;
+				if ((rc = ensure(c->lcand, c->lcand_cap, (rows_mode ? px64 : lrows*W)*(size_t)cmax))) return rc;
 				if (rows_mode) {
-					if ((rc = ensure(c->lrowinfo, c->lrowinfo_cap, lrows*W*(size_t)SRH_ROWS_NR))) return rc;
+					if ((rc = ensure(c->lrowinfo, c->lrowinfo_cap, px64*(size_t)SRH_ROWS_NR))) return rc;
 					if ((rc = ensure(c->lmeta, c->lmeta_cap, lrows*W))) return rc;
 				}
 				for (int by = y0; by < y1; by += (int)lrows) {

@@ -34,13 +34,18 @@ struct RowsListVisitor {
 		const uint32_t e = (uint32_t)cx | ((uint32_t)cy << 16);
 		if (e == prev) return;                                  // joint duplicate: can never change the WTA state
 		prev = e;
-		if (n < cap) out[n] = e;
+		if (n < cap) out[(size_t)n*64] = e;                     // wave-tiled list
 		++n;
 		ymin = cy < ymin ? cy : ymin; ymax = cy > ymax ? cy : ymax;
 	}
 };
 
-// rowinfo[q*RW_NR + r] = xlo | width<<16 of image row ymin+r;  meta[q] = ymin | nrows<<16 (nrows 0: no candidates)
+// rowinfo(q, r) = xlo | width<<16 of image row ymin+r;  meta[q] = ymin | nrows<<16 (nrows 0: no candidates).
+// Per-pixel arrays are wave-tiled so that the 64 pixels of a wave read and write them coalesced:
+//   list entry k of pixel q   at cand   [((q/64)*cmax  + k)*64 + q%64]
+//   row r of pixel q          at rowinfo[((q/64)*RW_NR + r)*64 + q%64]
+//   cost slot s of pixel x of tile t (32 pixels of one image row, the cost kernel's workgroup)
+//                             at cost   [((t*smax) + s)*32 + x%32]
 __global__ __launch_bounds__(RW_LT)
 void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                               int y0, int nrows_band, uint32_t *__restrict__ cand, int cmax,
@@ -59,7 +64,7 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		if (L.mask[(size_t)y*W + x] == 1) {
 			n_pix = 1;
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-			uint32_t *mine = cand + q*(size_t)cmax;
+			uint32_t *mine = cand + (q >> 6)*(size_t)cmax*64 + (q & 63);
 			RowsListVisitor vis = { mine, cmax, 0, 0, 0xffffffffu, 2147483647, -1 };
 			walk_curve<false>(ray, L.cam, views[oth], P, vis);
 			n_eval = vis.visited;
@@ -69,7 +74,7 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			else if (nr > 0 && vis.n <= cmax) {
 				for (int r = 0; r < nr; ++r) { s_lo[r][threadIdx.x] = 32767; s_hi[r][threadIdx.x] = -1; }
 				for (int k = 0; k < vis.n; ++k) {
-					const uint32_t e = mine[k];
+					const uint32_t e = mine[(size_t)k*64];
 					const int cx = (int)(e & 0xffffu), r = (int)(e >> 16) - vis.ymin;
 					if (cx < s_lo[r][threadIdx.x]) s_lo[r][threadIdx.x] = (short)cx;
 					if (cx > s_hi[r][threadIdx.x]) s_hi[r][threadIdx.x] = (short)cx;
@@ -77,7 +82,7 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				for (int r = 0; r < nr; ++r) {
 					const int lo = s_lo[r][threadIdx.x], hi = s_hi[r][threadIdx.x];
 					const int wdt = hi >= lo ? hi - lo + 1 : 0;
-					rowinfo[q*RW_NR + r] = (uint32_t)(lo & 0xffff) | ((uint32_t)wdt << 16);
+					rowinfo[((q >> 6)*RW_NR + r)*64 + (q & 63)] = (uint32_t)(lo & 0xffff) | ((uint32_t)wdt << 16);
 					slots += (wdt + 7) & ~7;                             // spans are stored in whole blocks of 8
 				}
 				if (slots <= smax) m = (vis.ymin & 0xffff) | (nr << 16);   // else: capacity too small, the pass is repeated
@@ -187,7 +192,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		for (int k = 0; k < NBI; ++k) {
 			const int idx = tid + k*RC_THREADS;
 			const int pi = idx / RW_NR;
-			ti_[k] = (idx < RC_TP*RW_NR && x0 + pi < W) ? rowinfo[(qbase + pi)*RW_NR + idx % RW_NR] : 0u;
+			const size_t qq = qbase + pi;
+			ti_[k] = (idx < RC_TP*RW_NR && x0 + pi < W) ? rowinfo[((qq >> 6)*RW_NR + idx % RW_NR)*64 + (qq & 63)] : 0u;
 		}
 		const int mt = (tid < RC_TP && x0 + tid < W) ? meta[qbase + tid] : 0;
 #pragma unroll
@@ -256,7 +262,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	if (x < W) {
 		const int m = CS.meta[i];
 		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
-		double *crow = cost + (qbase + i)*(size_t)smax;
+		double *crow = cost + (size_t)blockIdx.x*smax*RC_TP + i;      // tile-transposed: slot s at crow[s*32]
 		const bool lall = CS.lall[i] != 0;
 		const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
 		// task t = the t-th 8-column block of the pixel's spans (rows in order); lane g takes t = g, g+8, ...
@@ -285,7 +291,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					for (int j = 0; j < RC_NCB; ++j) allfull &= fp[j];
 					fast = allfull != 0;
 				}
-				double *dst = crow + (size_t)task*RC_NCB;
+				double *dst = crow + (size_t)task*RC_NCB*RC_TP;
 #ifdef SRH_ROWS_DBG
 				++d_task; d_fast += fast ? 1 : 0; if (g == 0 && task == 0) d_rows += nr;
 				if (lane == __ffsll((long long)__ballot(1)) - 1) { ++d_waveiter; }
@@ -346,7 +352,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					for (int j = 0; j < RC_NCB; ++j) {
 						if (j >= sh) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							dst[j - sh] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							dst[(j - sh)*RC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 					}
 				} else {
@@ -424,7 +430,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2v[j] * s3[j]));
 								result = (v < P.max_color_diff) ? v : P.max_color_diff;
 							}
-							dst[j] = result;
+							dst[j*RC_TP] = result;
 						}
 					}
 				}
@@ -491,27 +497,28 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
 		int base = 0;
 		for (int r = 0; r < nr; ++r) {
-			const uint32_t info = rowinfo[q*RW_NR + r];
+			const uint32_t info = rowinfo[((q >> 6)*RW_NR + r)*64 + (q & 63)];
 			const int wdt = (int)(info >> 16);
 			s_row[r][threadIdx.x] = (info & 0xffffu) | ((uint32_t)base << 16);
 			base += (wdt + 7) & ~7;
 		}
 		const int n = nr > 0 ? (count[q] < cmax ? count[q] : cmax) : 0;
-		const uint32_t *clist = cand + q*(size_t)cmax;
-		const double *crow = cost + q*(size_t)smax;
+		const uint32_t *clist = cand + (q >> 6)*(size_t)cmax*64 + (q & 63);
+		const int tiles_per_row = (W + 31) >> 5;
+		const double *crow = cost + ((size_t)(q / W)*tiles_per_row + (x >> 5))*(size_t)smax*32 + (x & 31);
 		double minCost = __builtin_inf(), secondBest = __builtin_inf();
 		uint32_t win = 0xffffffffu;
 		for (int k0 = 0; k0 < n; k0 += RS_QN) {
 			uint32_t e[RS_QN];
 			double c[RS_QN];
 #pragma unroll
-			for (int j = 0; j < RS_QN; ++j) e[j] = k0 + j < n ? clist[k0 + j] : 0xffffffffu;
+			for (int j = 0; j < RS_QN; ++j) e[j] = k0 + j < n ? clist[(size_t)(k0 + j)*64] : 0xffffffffu;
 #pragma unroll
 			for (int j = 0; j < RS_QN; ++j) {
 				if (k0 + j < n) {
 					const int cx = (int)(e[j] & 0xffffu), r = (int)(e[j] >> 16) - ymin;
 					const uint32_t ri = s_row[r][threadIdx.x];
-					c[j] = crow[(int)(ri >> 16) + cx - (int)(short)(ri & 0xffffu)];
+					c[j] = crow[(size_t)((int)(ri >> 16) + cx - (int)(short)(ri & 0xffffu))*32];
 				} else c[j] = __builtin_inf();
 			}
 #pragma unroll
