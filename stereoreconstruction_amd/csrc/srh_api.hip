@@ -738,7 +738,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
 		const size_t wstride = SRH_WTILE;
 		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
-		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*W*(size_t)cstride))) return rc;
+		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*(size_t)((W + 31)/32)*32*(size_t)cstride))) return rc;   // 32-pixel tiles
 
 		for (int by = y0; by < y1; by += (int)rows) {
 			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");

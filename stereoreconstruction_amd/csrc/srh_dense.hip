@@ -488,7 +488,9 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			const int hi = e.xmax < cs + DC_CHUNK - 1 ? e.xmax : cs + DC_CHUNK - 1;
 			const int lo_e = lo & ~1;                               // blocks start on even columns (>= cs)
 			const int nblocks = hi >= lo ? (hi - lo_e + DC_NCB)/DC_NCB : 0;
-			double *crow = cost + (qbase + i)*(size_t)cstride;
+			// cost rows are tile-transposed: column k (relative to the pixel's xmin) of pixel i of this tile at
+			// ((tile*cstride) + k)*DC_TP + i -- the 32 pixels' k-th costs are contiguous for the scan's wave loads
+			double *crow = cost + (size_t)blockIdx.x*cstride*DC_TP + i;
 			// phase 1: blocks of DC_NCB candidates in the fast form.  Candidates whose window is
 			// not fully usable still ride along in the block but are not stored; phase 2 below
 			// evaluates them (and every candidate of a pixel that has unusable taps itself).
@@ -598,7 +600,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
 							if (!(dbg & 4) || v == -12345.0)
-							crow[c - e.xmin] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							crow[(size_t)(c - e.xmin)*DC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
@@ -627,7 +629,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			for (int q = tid; q < nl; q += DC_THREADS) {
 				const int pi = S.glist[q] >> 9, k = S.glist[q] & 511;
 				++n_dev;
-				cost[(qbase + pi)*(size_t)cstride + (cs + k - S.pxmin[pi])] =
+				cost[((size_t)blockIdx.x*cstride + (cs + k - S.pxmin[pi]))*DC_TP + pi] =
 					dense_cost_general<R, DC_NCB, DC_CHUNK>(CS, pi, k, P.weight_cutoff, P.bad_ret, P.max_color_diff);
 			}
 		}
@@ -749,7 +751,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	double depth = __builtin_nan("");
 	if (active) {
 		n_pix = 1;
-		const double *crow = cost + q*(size_t)cstride;
+		const double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 		const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
 		const double *wq = wbuf + wbuf_offset(W, T, trow, x);
 		TwoViewScanState st = { __builtin_inf(), __builtin_inf(), -1 };
@@ -763,7 +765,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 			for (int k = 0; k < SC_QN; ++k) col[k] = queue[k][tid];
 #pragma unroll
 			for (int k = 0; k < SC_QN; ++k)
-				c[k] = (k < count && lo + col[k] <= cover_hi) ? crow[col[k]] : __builtin_inf();
+				c[k] = (k < count && lo + col[k] <= cover_hi) ? crow[(size_t)col[k]*DC_TP] : __builtin_inf();
 #pragma unroll
 			for (int k = 0; k < SC_QN; ++k) {
 				if (k < count) {
