@@ -29,8 +29,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 from stereoreconstruction_amd import capi, synthetic  # noqa: E402
-from stereoreconstruction_amd.distributed import (HipMultiViewEngine, gather_depth_maps,  # noqa: E402
-                                                  multiview_sharded, shard_units)
+from stereoreconstruction_amd.distributed import HipMultiViewEngine, multiview_sharded, shard_units  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (datasheet)
@@ -266,24 +265,44 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
-    out = torch.empty((2, H, W), dtype=torch.float64, device=dev)
-    gathered = None
+    # Depth hand-over: both maps are copied device-to-device into a staging tensor; with N > 1 ranks they are
+    # gathered on rank 0 (RCCL over xGMI).  The gather of step k runs while step k+1 computes (two staging
+    # buffers, async collective); everything is drained inside the timed region by fence().
+    NBUF = 2
+    outs = [torch.empty((2, H, W), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    on_dev = backend == "nccl"
+    recv = None
+    if world > 1 and rank == 0:
+        recv = [[torch.empty((2, H, W), dtype=torch.float64, device=dev if on_dev else "cpu") for _ in range(world)]
+                for _ in range(NBUF)]
+    pending = [None] * NBUF
+    host_src = [None] * NBUF
+    state = {"n": 0}
 
     def step():
+        b = state["n"] % NBUF
+        state["n"] += 1
+        if pending[b] is not None:                     # the gather that last used this staging buffer
+            pending[b].wait()
+            if on_dev:
+                torch.cuda.current_stream().synchronize()   # the library writes the buffer from its own stream
+            pending[b] = None
         ctx.twoview_wta(0, 1, p)
         ctx.twoview_wta(1, 0, p)
         ctx.twoview_cross_check(0, 1, p)
-        ctx.copy_depth_to_device(0, out[0].data_ptr())
-        ctx.copy_depth_to_device(1, out[1].data_ptr())
-        nonlocal gathered
+        ctx.copy_depth_to_device(0, outs[b][0].data_ptr())
+        ctx.copy_depth_to_device(1, outs[b][1].data_ptr())
         if world > 1:
-            ctx.synchronize()      # the library's stream and torch's (legacy default) stream are not ordered
-        if backend == "nccl":
-            gathered = gather_depth_maps(out, dst=0)   # RCCL over xGMI: per-view depth maps to rank 0
-        else:
-            gathered = gather_depth_maps(out.cpu(), dst=0)
+            ctx.synchronize()      # the library's stream and torch's / RCCL's streams are not ordered
+            src = outs[b] if on_dev else outs[b].cpu()
+            host_src[b] = src
+            pending[b] = dist.gather(src, recv[b] if rank == 0 else None, dst=0, async_op=True)
 
     def fence():
+        for b in range(NBUF):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
