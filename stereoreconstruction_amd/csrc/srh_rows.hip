@@ -19,7 +19,7 @@
 
 namespace srh {
 
-#define RW_NR 32                   // image rows a pixel's curve may cross (else: plain list path)
+#define RW_NR 32                   // image rows a pixel's curve may cross (else: plain list path); a power of two
 #define RW_LT 128                  // threads of the list / scan kernels
 
 // ------------------------------------------------------------------ list + row spans
@@ -29,6 +29,7 @@ struct RowsListVisitor {
 	unsigned visited;
 	uint32_t prev;
 	int ymin, ymax;
+	short *lo, *hi;                                             // this thread's LDS columns (stride RW_LT): span of row cy at cy % RW_NR
 	__device__ __forceinline__ void operator()(int cx, int cy) {
 		++visited;
 		const uint32_t e = (uint32_t)cx | ((uint32_t)cy << 16);
@@ -37,6 +38,11 @@ struct RowsListVisitor {
 		if (n < cap) out[(size_t)n*64] = e;                     // wave-tiled list
 		++n;
 		ymin = cy < ymin ? cy : ymin; ymax = cy > ymax ? cy : ymax;
+		// column span per image row, kept in a ring of RW_NR rows: unambiguous while the curve crosses at most
+		// RW_NR rows (otherwise the pixel is flagged and the spans are not used)
+		const int r = (cy & (RW_NR - 1))*RW_LT;
+		if (cx < lo[r]) lo[r] = (short)cx;
+		if (cx > hi[r]) hi[r] = (short)cx;
 	}
 };
 
@@ -65,22 +71,17 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			n_pix = 1;
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 			uint32_t *mine = cand + (q >> 6)*(size_t)cmax*64 + (q & 63);
-			RowsListVisitor vis = { mine, cmax, 0, 0, 0xffffffffu, 2147483647, -1 };
+			for (int r = 0; r < RW_NR; ++r) { s_lo[r][threadIdx.x] = 32767; s_hi[r][threadIdx.x] = -1; }
+			RowsListVisitor vis = { mine, cmax, 0, 0, 0xffffffffu, 2147483647, -1, &s_lo[0][threadIdx.x], &s_hi[0][threadIdx.x] };
 			walk_curve<false>(ray, L.cam, views[oth], P, vis);
 			n_eval = vis.visited;
 			n_kept = vis.n;
 			const int nr = vis.n > 0 ? vis.ymax - vis.ymin + 1 : 0;
 			if (nr > RW_NR) toomany = 1;
 			else if (nr > 0 && vis.n <= cmax) {
-				for (int r = 0; r < nr; ++r) { s_lo[r][threadIdx.x] = 32767; s_hi[r][threadIdx.x] = -1; }
-				for (int k = 0; k < vis.n; ++k) {
-					const uint32_t e = mine[(size_t)k*64];
-					const int cx = (int)(e & 0xffffu), r = (int)(e >> 16) - vis.ymin;
-					if (cx < s_lo[r][threadIdx.x]) s_lo[r][threadIdx.x] = (short)cx;
-					if (cx > s_hi[r][threadIdx.x]) s_hi[r][threadIdx.x] = (short)cx;
-				}
 				for (int r = 0; r < nr; ++r) {
-					const int lo = s_lo[r][threadIdx.x], hi = s_hi[r][threadIdx.x];
+					const int ring = (vis.ymin + r) & (RW_NR - 1);
+					const int lo = s_lo[ring][threadIdx.x], hi = s_hi[ring][threadIdx.x];
 					const int wdt = hi >= lo ? hi - lo + 1 : 0;
 					rowinfo[((q >> 6)*RW_NR + r)*64 + (q & 63)] = (uint32_t)(lo & 0xffff) | ((uint32_t)wdt << 16);
 					slots += (wdt + 7) & ~7;                             // spans are stored in whole blocks of 8
