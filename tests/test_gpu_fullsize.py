@@ -35,15 +35,19 @@ def test_c2_full_size_dense_equals_general(hip_ctx):
     W, H, D = 640, 480, 64
     (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0002, capi.WEIGHT_ADAPTIVE)
     out = {}
-    for mode in ("dense", "general"):
-        hip_ctx.set_option("force_generic", 2 if mode == "general" else 0)
+    # dense row-aligned kernels; candidate lists in row runs; lists in list order; one thread per pixel
+    for mode, generic, rows in (("dense", 0, 1), ("rows", 1, 1), ("ordered", 1, 0), ("general", 2, 1)):
+        hip_ctx.set_option("force_generic", generic)
+        hip_ctx.set_option("list_rows", rows)
         dl, dr = hip_ctx.twoview_compute(0, 1, p)
         st = hip_ctx.stats()
         assert st["used_dense_path"] == (mode == "dense")
         out[mode] = (dl, dr, st["n_eval"], st["n_pixels"])
     hip_ctx.set_option("force_generic", 0)
-    assert _same_bits(out["dense"][0], out["general"][0]) and _same_bits(out["dense"][1], out["general"][1])
-    assert out["dense"][2] == out["general"][2] and out["dense"][3] == out["general"][3] == W * H   # counters of the last pass
+    hip_ctx.set_option("list_rows", 1)
+    for mode in ("rows", "ordered", "general"):
+        assert _same_bits(out["dense"][0], out[mode][0]) and _same_bits(out["dense"][1], out[mode][1]), mode
+        assert out["dense"][2] == out[mode][2] and out["dense"][3] == out[mode][3] == W * H   # counters of the last pass
     # sanity of the content: a good share of pixels survive the ratio test and the cross-check,
     # and surviving left depths reproduce the ground-truth disparity f*B/z for most of them
     dl = out["dense"][0]
@@ -57,6 +61,35 @@ def test_c2_full_size_dense_equals_general(hip_ctx):
     hip_ctx.twoview_wta(0, 1, p, y, y + 1)
     got = hip_ctx.download_depth(0)
     assert _same_bits(got[y], want[y]) or np.allclose(got[y], want[y], rtol=1e-9, equal_nan=True)
+
+
+def test_c5_refractive_rows_equal_ordered_lists(hip_ctx):
+    """C5 geometry (refractive interface, curved epipolar lines) at 960x540x128: the row-run evaluation and
+    the list-order evaluation give the same bits, at two band budgets; one row agrees with the oracle."""
+    W, H, D = 960, 540, 128
+    L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, 0x5EED0050)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    plane = (np.array([0.0, 0.0, 1.0]), 0.1, 1.333)
+    hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl, None, *plane))
+    hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr, None, *plane))
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
+    res = {}
+    for tag, rows, budget in (("rows", 1, 8192), ("rows_bands", 1, 96), ("ordered", 0, 8192)):
+        hip_ctx.set_option("list_rows", rows)
+        hip_ctx.set_option("band_budget_mb", budget)
+        hip_ctx.twoview_wta(1, 0, p)
+        res[tag] = hip_ctx.download_depth(1)
+        assert not hip_ctx.stats()["used_dense_path"]
+    hip_ctx.set_option("list_rows", 1)
+    hip_ctx.set_option("band_budget_mb", 8192)
+    assert _same_bits(res["rows"], res["rows_bands"]) and _same_bits(res["rows"], res["ordered"])
+    assert np.isfinite(res["rows"]).mean() > 0.2
+    op = O.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
+    y = H // 2
+    want = O.twoview_wta(O.OImage(R, mr), O.OImage(L, ml), O.camera_set(Kr, Rr, tr, None, *plane),
+                         O.camera_set(Kl, Rl, tl, None, *plane), op, y, y + 1)
+    assert np.allclose(res["rows"][y], want[y], rtol=1e-9, equal_nan=True)
 
 
 def test_c3_full_size_band_invariance(hip_ctx):
