@@ -112,3 +112,45 @@ def test_c3_full_size_band_invariance(hip_ctx):
     # every reference pixel got a verdict: finite depth or +INF (ratio test); NaN only without candidates
     assert np.isnan(a).mean() < 0.01
     assert np.isfinite(a).mean() > 0.3
+
+
+def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
+    """C4 geometry at 640x480x64, 4 views: walk -> list cost -> combine equals the one-thread-per-pixel kernel bit
+    for bit, independently of the band split; one row of view 1 agrees with the oracle; cross-check chain runs."""
+    W, H, D, NV = 640, 480, 64, 4
+    cams3 = synthetic.semicircle_rig(NV, W, H, radius=10.0, step_deg=22.5, focal=float(W))
+    rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, 0x5EED0004, sphere_radius=2.0, tex_size=512)
+    cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
+    kw = dict(min_depth=8.0, max_depth=12.0, num_depth_levels=D, cross_check_threshold=2 * 4.0 / (D - 1))
+    p = capi.params_mvs(**kw)
+    neigh = capi.mvs_neighbours(cams, p)
+    for v in range(NV):
+        hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
+    res = {}
+    for tag, generic, budget in (("two_stage", 0, 8192), ("two_stage_bands", 0, 64), ("inline", 1, 8192)):
+        hip_ctx.set_option("force_generic", generic)
+        hip_ctx.set_option("band_budget_mb", budget)
+        maps, evals = [], []
+        for v in range(NV):
+            hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+            maps.append(hip_ctx.download_depth(v))
+            evals.append(hip_ctx.stats()["n_eval"])
+        res[tag] = (maps, evals)
+    hip_ctx.set_option("force_generic", 0)
+    hip_ctx.set_option("band_budget_mb", 8192)
+    for v in range(NV):
+        for tag in ("two_stage_bands", "inline"):
+            assert _same_bits(res["two_stage"][0][v], res[tag][0][v]), (tag, v)
+            assert res["two_stage"][1][v] == res[tag][1][v], (tag, v)
+        m = masks[v] == 1
+        assert np.isposinf(res["two_stage"][0][v][~m]).all()          # masked-out pixels keep +INF
+        assert (res["two_stage"][0][v][m] > 0).mean() > 0.5           # most sphere pixels have a >0.95 peak
+    ocams = [O.camera_set(K, R, t) for (K, R, t) in cams3]
+    op = O.params_mvs(**kw)
+    imgs = [O.OImage(rgba[v], masks[v]) for v in range(NV)]
+    y = H // 2
+    want, n_eval = O.mvs_initial_estimate(imgs, ocams, 1, neigh[1], op, y, y + 1)
+    assert np.allclose(res["two_stage"][0][1][y], want[y], rtol=1e-9, equal_nan=True)
+    for v in range(NV):
+        hip_ctx.mvs_cross_check(list(range(NV)), v, p)
+    assert np.isnan(hip_ctx.download_depth(0)[masks[0] == 1]).any()   # the cross-check rejects something
