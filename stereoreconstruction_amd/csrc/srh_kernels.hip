@@ -543,6 +543,7 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 #define MQ_T 128
 #define MQ_QN 32
 #define MQ_FLUSH 24
+#define SRH_MVS_WAVES 2
 
 __global__ __launch_bounds__(MQ_T)
 void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
@@ -686,8 +687,31 @@ __device__ __noinline__ double mvs_cost_general(const ViewDev &A, const ViewDev 
 	return s1 / sqrt(s2 * s3);
 }
 
+// The rare units the lean loop below cannot finish -- a window over an image border or an unusable tap somewhere
+// (the guarded form of the cost is needed), or two different candidates tied exactly for the largest cost (their
+// depths decide, multiviewstereo.cpp:600-602) -- are redone here from their candidate list, the reference's
+// streaming rule applied in list order.  The out-of-line cost gives the same bits as the fast form.
 template <int R>
-__global__ __launch_bounds__(MQ_T, 2)
+__device__ __noinline__ void mvs_unit_general(const ViewDev &A, const ViewDev &B, const srh_params &P,
+                                              const double *__restrict__ wq, size_t wstride, int x, int y,
+                                              const uint32_t *__restrict__ cl, int n, double *__restrict__ bout)
+{
+	const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+	double bestCost = 0.0, bestDepth = -1.0;
+	for (int k = 0; k < n; ++k) {
+		const uint32_t e = cl[(size_t)k*64];
+		const int cx = (int)(e & 0xffffu), cy = (int)(e >> 16);
+		const double c = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, cx, cy);
+		if (c > P.peak_threshold && c >= bestCost) {                 // multiviewstereo.cpp:589-594, 654-660
+			const double z = candidate_depth(A.cam, B.cam, P, ray, cx, cy);
+			if (c > bestCost || z > bestDepth) { bestCost = c; bestDepth = z; }
+		}
+	}
+	bout[0] = bestCost; bout[1] = bestDepth;
+}
+
+template <int R>
+__global__ __launch_bounds__(MQ_T, SRH_MVS_WAVES)
 void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
                           int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                           const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
@@ -737,87 +761,63 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 		} else all = false;
 	}
 
-	double bestCost = 0.0, bestDepth = -1.0;
-	uint32_t be = 0;
-	bool pending = false;
+	double bestCost = 0.0;
+	uint32_t be = 0xffffffffu;
+	bool redo = !all;                                               // this unit needs mvs_unit_general
 	const uint32_t *cl = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);
 
-	// the next candidate's window is in flight while the current one is reduced
-	double gn[T];
+	// one candidate per iteration: its 25-tap window arrives in g[], is turned in place into p_t = w_t*g_t
+	// (the products both sweeps need), and the next candidate's window is requested as soon as the second
+	// sweep has consumed p_t.  Two waves per SIMD (a_t, p_t and the addresses need more than the 168 VGPRs of three).
+	double g[T];
 	uint32_t en = cl[0];
 	bool inn;
-	{
-		const int cx = (int)(en & 0xffffu), cy = (int)(en >> 16);
+	auto request = [&](uint32_t ee) {
+		const int cx = (int)(ee & 0xffffu), cy = (int)(ee >> 16);
 		inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
-		const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);
+		const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);   // not usable: any valid address
 #pragma unroll
 		for (int row = 0; row < WS; ++row)
 #pragma unroll
-			for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
-	}
+			for (int col = 0; col < WS; ++col) g[row*WS + col] = bp[(size_t)row*OW + col];
+	};
+	request(en);
 	uint32_t e2 = n > 1 ? cl[64] : 0u;                           // list entry k+2 travels one step ahead of the window
 	for (int k = 0; k < n; ++k) {
-		asm volatile("" ::: "memory");                               // keep the LDS columns in LDS (no hoisting into 100 VGPRs)
-		double pr[T];
+		asm volatile("" ::: "memory");                               // keep the LDS column in LDS (no hoisting into 50 VGPRs)
 		const uint32_t e = en;
 		const bool fast = inn;
 		// p_t = weight*gray of the other view (multiviewstereo.cpp:150-151, 171); meanR is their sum / totalWeight
 		double mR = 0;
 #pragma unroll
-		for (int t = 0; t < T; ++t) { pr[t] = s_w[t][tid]*gn[t]; mR += pr[t]; }
-#ifndef SRH_MVS_NOPREFETCH
+		for (int row = 0; row < WS; ++row) {
+#pragma unroll
+			for (int col = 0; col < WS; ++col) { const int t = row*WS + col; g[t] = s_w[t][tid]*g[t]; mR += g[t]; }
+			__builtin_amdgcn_sched_barrier(0);                       // one window row of weights in flight at a time
+		}
+		mR /= tw;
+		double s1 = 0, s3 = 0;
+#pragma unroll
+		for (int t = 0; t < T; ++t) {
+			const double b = g[t] - mR;
+			s1 += a[t]*b;
+			s3 += b*b;
+		}
+		const double c = (s2 * s3 < 1e-10) ? 0.0 : s1 / sqrt(s2 * s3);
+		redo = redo || !fast;                                        // (c is meaningless then)
 		if (k + 1 < n) {
 			en = e2;
 			if (k + 2 < n) e2 = cl[(size_t)(k + 2)*64];
-			const int cx = (int)(en & 0xffffu), cy = (int)(en >> 16);
-			inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
-			const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);   // not usable: any valid address
-#pragma unroll
-			for (int row = 0; row < WS; ++row)
-#pragma unroll
-				for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
-		}
-#endif
-		double c;
-		if (fast) {
-			mR /= tw;
-			double s1 = 0, s3 = 0;
-#pragma unroll
-			for (int t = 0; t < T; ++t) {
-				const double b = pr[t] - mR;
-				s1 += a[t]*b;
-				s3 += b*b;
-			}
-			c = (s2 * s3 < 1e-10) ? 0.0 : s1 / sqrt(s2 * s3);
-		} else {
-			c = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, (int)(e & 0xffffu), (int)(e >> 16));
+			request(en);
 		}
 		if (c > P.peak_threshold) {                                  // multiviewstereo.cpp:589-594, 654-660
-			if (c > bestCost) { bestCost = c; be = e; pending = true; }
-			else if (c == bestCost && !(pending && be == e)) {
-				// exact tie of two different candidates: the larger depth wins (sorted pairs, :600-602)
-				const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-				const double z = candidate_depth(A.cam, B.cam, P, ray, (int)(e & 0xffffu), (int)(e >> 16));
-				if (pending) { bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16)); pending = false; }
-				if (z > bestDepth) { bestDepth = z; be = e; }
-			}
+			if (c > bestCost) { bestCost = c; be = e; }
+			else if (c == bestCost && e != be) redo = true;              // exact tie of two candidates: depths decide
 		}
-#ifdef SRH_MVS_NOPREFETCH
-		asm volatile("" ::: "memory");
-		if (k + 1 < n) {
-			en = e2;
-			if (k + 2 < n) e2 = cl[(size_t)(k + 2)*64];
-			const int cx = (int)(en & 0xffffu), cy = (int)(en >> 16);
-			inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
-			const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);   // not usable: any valid address
-#pragma unroll
-			for (int row = 0; row < WS; ++row)
-#pragma unroll
-				for (int col = 0; col < WS; ++col) gn[row*WS + col] = bp[(size_t)row*OW + col];
-		}
-#endif
 	}
-	if (pending) {
+	if (redo) { mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout); return; }
+	double bestDepth = -1.0;                                        // no peak above the threshold
+	if (be != 0xffffffffu) {
 		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 		bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16));
 	}
