@@ -559,7 +559,6 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1,
 	const int tid = threadIdx.x;
 	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
 	const size_t npix = (size_t)nrows*W;
-	const size_t units = npix*gridDim.y;
 	const size_t unit = (size_t)blockIdx.y*npix + q;
 	const int x = (int)(q % W), y = y0 + (int)(q / W);
 	const bool active = q < npix && A.mask[(size_t)y*W + x] == 1;
@@ -726,7 +725,6 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 	const int tid = threadIdx.x;
 	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
 	const size_t npix = (size_t)nrows*W;
-	const size_t units = npix*gridDim.y;
 	const size_t unit = (size_t)blockIdx.y*npix + q;
 	if (q >= npix) return;
 	const int x = (int)(q % W), y = y0 + (int)(q / W);
@@ -775,7 +773,8 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 	auto request = [&](uint32_t ee) {
 		const int cx = (int)(ee & 0xffffu), cy = (int)(ee >> 16);
 		inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
-		const double *bp = B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R);   // not usable: any valid address
+		typedef const __attribute__((address_space(1))) double *gptr;     // global_load, not flat_load
+		gptr bp = (gptr)(B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R));   // not usable: any valid address
 #pragma unroll
 		for (int row = 0; row < WS; ++row)
 #pragma unroll
