@@ -192,9 +192,23 @@ def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, pl
     t0 = time.perf_counter()
     depth, diag = O.twoview_wta(li, ri, cl, cr, p, y0, y0 + rows, want_diag=True)
     dt = time.perf_counter() - t0
-    return dict(value=rows * w * D / dt / 1e6, unit="Mhyp/s", cores=1, kind="port",
+    base = dict(value=rows * w * D / dt / 1e6, unit="Mhyp/s", cores=1, kind="port",
                 sample="oracle/sr_oracle.c sro_twoview_wta, left->right, %d full-width centre rows x %d levels "
-                       "(%d cost evaluations) in %.2f s on 1 host thread" % (rows, D, diag["n_eval"], dt)), depth, y0
+                       "(%d cost evaluations) in %.2f s on 1 host thread" % (rows, D, diag["n_eval"], dt))
+    # the same band on every host core of this box's share (the oracle is re-entrant; ctypes drops the GIL):
+    # what the reference's own OpenMP-over-rows build could reach at best -- reported beside, not instead of,
+    # the single-thread figure the metric names ("tbb/openmp off")
+    from concurrent.futures import ThreadPoolExecutor
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    if cores > 1:
+        ys = [max(0, min(h - rows, y0 + (i - cores // 2) * rows)) for i in range(cores)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda yy: O.twoview_wta(li, ri, cl, cr, p, yy, yy + rows), ys))
+        dta = time.perf_counter() - t0
+        base["all_cores"] = dict(value=cores * rows * w * D / dta / 1e6, unit="Mhyp/s", cores=cores,
+                                 sample="%d threads x %d rows each in %.2f s" % (cores, rows, dta))
+    return base, depth, y0
 
 
 def main():
@@ -203,7 +217,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-rows", type=int, default=2, help="rows of the CPU-baseline band (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the CPU-baseline band (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
