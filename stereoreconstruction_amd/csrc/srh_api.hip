@@ -832,9 +832,9 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	const size_t wstride = SRH_WTILE;
 	if (y1 <= y0) return SRH_OK;
 
-	// ---- default: walk kernel -> candidate lists -> cost kernel -> maximum over the neighbours.
-	// The sorted top-K list (peaks_dev) and other radii stay on the one-thread-per-pixel kernels.
-	if (!c->force_generic && !peaks_dev && nneigh > 0 && p->window_radius == 2 && W < 65536 && H < 65536) {
+	// ---- default: walk kernel -> candidate lists -> cost kernel -> maximum (and merged top-K lists) over the
+	// neighbours.  Other radii stay on the one-thread-per-pixel kernels.
+	if (!c->force_generic && nneigh > 0 && p->window_radius == 2 && W < 65536 && H < 65536) {
 		int cmax = c->mvs_cmax_hint > 0 ? c->mvs_cmax_hint : ((2*p->num_depth_levels + 7) & ~7);
 		// without a refractive interface every ray of the view starts at the camera centre: the per-label
 		// part of pointFromDepth is tabulated once (same operands and operations, see srh_walk.hpp)
@@ -847,13 +847,14 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 		for (int pass = 0; pass < 3; ++pass) {
 			HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 			HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
-			const size_t per_px = (size_t)T*sizeof(double) + (size_t)nneigh*((size_t)cmax*sizeof(uint32_t) + sizeof(int32_t) + 2*sizeof(double));
+			const size_t per_px = (size_t)T*sizeof(double) + (size_t)nneigh*((size_t)cmax*sizeof(uint32_t) + sizeof(int32_t) + 2*sizeof(double)
+			                      + (peaks_dev ? (size_t)p->top_k*2*sizeof(double) : 0));
 			size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
 			if (lrows < 1) lrows = 1;
 			if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
 			const size_t units = lrows*W*(size_t)nneigh;
 			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
-			if ((rc = ensure(c->cost, c->cost_cap, units*2))) return rc;
+			if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K
 			if ((rc = ensure(c->lcand, c->lcand_cap, ((units + 63) & ~(size_t)63)*(size_t)cmax))) return rc;   // wave-tiled lists
 			if ((rc = ensure(c->lcount, c->lcount_cap, units))) return rc;
 			for (int by = y0; by < y1; by += (int)lrows) {
@@ -865,7 +866,8 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 				                  c->d_cnt, c->d_span); }
 				{ Scope s(c, "mvs_list_cost_kernel");
 				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-				                       c->lcand, cmax, c->lcount, c->cost); }
+				                       c->lcand, cmax, c->lcount, c->cost, peaks_dev ? c->cost + units*2 : nullptr,
+				                       (double *)peaks_dev); }
 			}
 			int maxc = 0;
 			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));

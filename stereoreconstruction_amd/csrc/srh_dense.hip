@@ -323,7 +323,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	const int i = (tid >> 6)*8 + (lane & 7);   // pixel within the tile (pixel-fastest inside a wave)
 	const int g = lane >> 3;                   // lane within the pixel
 	const int x = x0 + i;
-	const size_t qbase = (size_t)trow*W + x0;  // band-relative index of the tile's first pixel
+
 	const double nan = __builtin_nan("");
 
 	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};

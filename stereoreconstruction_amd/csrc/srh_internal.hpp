@@ -96,7 +96,8 @@ void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_
                      Counters *cnt, int *max_count);
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
-                          const uint32_t *cand, int cmax, const int32_t *count, double *best);
+                          const uint32_t *cand, int cmax, const int32_t *count, double *best,
+                          double *unit_peaks, double *peaks);
 void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int mvs,
                             int nq, const int32_t *xy, int32_t *out, int cap, int32_t *counts);
 

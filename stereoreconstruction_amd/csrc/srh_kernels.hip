@@ -526,7 +526,8 @@ void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, 
 }
 
 __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, int nneigh, int y0, int nrows,
-                                   const double *__restrict__ best);
+                                   const double *__restrict__ best, const double *__restrict__ upk,
+                                   double *__restrict__ peaks, int K);
 
 // ---- MultiViewStereo, two-stage form --------------------------------------------------------
 // mvs_reg_kernel keeps the curve walk, 25 weights, 25 a_t and a 25-tap window live in one thread:
@@ -690,31 +691,49 @@ __device__ __noinline__ double mvs_cost_general(const ViewDev &A, const ViewDev 
 // (the guarded form of the cost is needed), or two different candidates tied exactly for the largest cost (their
 // depths decide, multiviewstereo.cpp:600-602) -- are redone here from their candidate list, the reference's
 // streaming rule applied in list order.  The out-of-line cost gives the same bits as the fast form.
+// The K largest (cost, depth) pairs seen so far, ascending (multiviewstereo.cpp:600-602: sort, keep the last K);
+// pk[0] is the smallest kept pair.
+__device__ __forceinline__ void mvs_peaks_insert(double *__restrict__ pk, int K, double c, double z)
+{
+	if (!(c > pk[0] || (c == pk[0] && z > pk[1]))) return;
+	int k = 0;
+	while (k + 1 < K && (pk[2*(k + 1)] < c || (pk[2*(k + 1)] == c && pk[2*(k + 1) + 1] < z))) {
+		pk[2*k] = pk[2*(k + 1)]; pk[2*k + 1] = pk[2*(k + 1) + 1];
+		++k;
+	}
+	pk[2*k] = c; pk[2*k + 1] = z;
+}
+
 template <int R>
 __device__ __noinline__ void mvs_unit_general(const ViewDev &A, const ViewDev &B, const srh_params &P,
                                               const double *__restrict__ wq, size_t wstride, int x, int y,
-                                              const uint32_t *__restrict__ cl, int n, double *__restrict__ bout)
+                                              const uint32_t *__restrict__ cl, int n, double *__restrict__ bout,
+                                              double *__restrict__ pk)
 {
 	const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 	double bestCost = 0.0, bestDepth = -1.0;
+	if (pk) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }
 	for (int k = 0; k < n; ++k) {
 		const uint32_t e = cl[(size_t)k*64];
 		const int cx = (int)(e & 0xffffu), cy = (int)(e >> 16);
 		const double c = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, cx, cy);
-		if (c > P.peak_threshold && c >= bestCost) {                 // multiviewstereo.cpp:589-594, 654-660
+		if (c > P.peak_threshold && (pk || c >= bestCost)) {         // multiviewstereo.cpp:589-594, 654-660
 			const double z = candidate_depth(A.cam, B.cam, P, ray, cx, cy);
-			if (c > bestCost || z > bestDepth) { bestCost = c; bestDepth = z; }
+			if (c > bestCost || (c == bestCost && z > bestDepth)) { bestCost = c; bestDepth = z; }
+			if (pk) mvs_peaks_insert(pk, P.top_k, c, z);
 		}
 	}
 	bout[0] = bestCost; bout[1] = bestDepth;
 }
 
-template <int R>
+// PEAKS: every pair above the threshold also goes into the unit's sorted top-K list upk[unit][K][2] (its depth is
+// then needed at once); mvs_combine_kernel merges the neighbours' lists into the caller's buffer.
+template <int R, bool PEAKS>
 __global__ __launch_bounds__(MQ_T, SRH_MVS_WAVES)
 void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
                           int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                           const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
-                          double *__restrict__ best)
+                          double *__restrict__ best, double *__restrict__ upk)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
 	__shared__ double s_w[T][MQ_T];                                 // per-thread columns: conflict-free
@@ -730,6 +749,8 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 	const int x = (int)(q % W), y = y0 + (int)(q / W);
 	if (A.mask[(size_t)y*W + x] != 1) return;                      // mvs_combine_kernel does not read masked pixels
 	double *bout = best + unit*2;
+	double *pk = PEAKS ? upk + unit*(size_t)P.top_k*2 : nullptr;
+	if (PEAKS) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }
 	const int n = count[unit] < cmax ? count[unit] : cmax;
 	if (n <= 0) { bout[0] = 0.0; bout[1] = -1.0; return; }
 
@@ -810,11 +831,17 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 			request(en);
 		}
 		if (c > P.peak_threshold) {                                  // multiviewstereo.cpp:589-594, 654-660
-			if (c > bestCost) { bestCost = c; be = e; }
+			if (PEAKS) {
+				if (fast) {
+					const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+					mvs_peaks_insert(pk, P.top_k, c, candidate_depth(A.cam, B.cam, P, ray, (int)(e & 0xffffu), (int)(e >> 16)));
+				}
+			} else if (c > bestCost) { bestCost = c; be = e; }
 			else if (c == bestCost && e != be) redo = true;              // exact tie of two candidates: depths decide
 		}
 	}
-	if (redo) { mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout); return; }
+	if (redo) { mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout, pk); return; }
+	if (PEAKS) { bout[0] = pk[2*(P.top_k - 1)]; bout[1] = pk[2*(P.top_k - 1) + 1]; return; }
 	double bestDepth = -1.0;                                        // no peak above the threshold
 	if (be != 0xffffffffu) {
 		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
@@ -835,17 +862,25 @@ void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
-                          const uint32_t *cand, int cmax, const int32_t *count, double *best)
+                          const uint32_t *cand, int cmax, const int32_t *count, double *best,
+                          double *unit_peaks, double *peaks)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
-	hipLaunchKernelGGL(mvs_list_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, neigh[0], nneigh > 1 ? neigh[1] : 0,
-	                   nneigh > 2 ? neigh[2] : 0, P, y0, nrows, wbuf, wstride, cand, cmax, count, best);
-	hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, ref, nneigh, y0, nrows, best);
+	const int n1 = nneigh > 1 ? neigh[1] : 0, n2 = nneigh > 2 ? neigh[2] : 0;
+	if (peaks)
+		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, neigh[0], n1, n2, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, unit_peaks);
+	else
+		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, neigh[0], n1, n2, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr);
+	hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, ref, nneigh, y0, nrows, best,
+	                   unit_peaks, peaks, P.top_k);
 }
 
 __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, int nneigh, int y0, int nrows,
-                                   const double *__restrict__ best)
+                                   const double *__restrict__ best, const double *__restrict__ upk,
+                                   double *__restrict__ peaks, int K)
 {
 	const ViewDev &A = views[ref];
 	const int W = A.w;
@@ -854,11 +889,18 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 	if (q >= npix) return;
 	const size_t pv = (size_t)y0*W + q;
 	double depth = __builtin_inf();
+	double *pk = peaks ? peaks + pv*(size_t)K*2 : nullptr;
+	if (pk) for (int k = 0; k < K; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }   // K x (0, -1), multiviewstereo.cpp:553
 	if (A.mask[pv] == 1) {
 		double bc = 0.0, bd = -1.0;
 		for (int ni = 0; ni < nneigh; ++ni) {
 			const double c = best[((size_t)ni*npix + q)*2], z = best[((size_t)ni*npix + q)*2 + 1];
 			if (c > bc || (c == bc && z > bd)) { bc = c; bd = z; }
+			if (pk) {
+				// the neighbour's K largest pairs; fillers (0, -1) never displace anything
+				const double *u = upk + ((size_t)ni*npix + q)*(size_t)K*2;
+				for (int k = 0; k < K; ++k) mvs_peaks_insert(pk, K, u[2*k], u[2*k + 1]);
+			}
 		}
 		depth = bd;
 	}
@@ -876,7 +918,7 @@ void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int
 			hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128), (unsigned)nneigh), dim3(128), 0, st,
 			                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, best, cnt);
 			hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
-			                   views, ref, nneigh, y0, nrows, best);
+			                   views, ref, nneigh, y0, nrows, best, (const double *)nullptr, (double *)nullptr, 0);
 			return;
 		}
 		hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,

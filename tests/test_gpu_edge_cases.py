@@ -108,6 +108,18 @@ def test_mvs_topk_peaks_match_oracle(hip_ctx):
     assert np.allclose(got[..., 0], want_pk[..., 0], rtol=0, atol=1e-12)
     assert np.allclose(got[..., 1], want_pk[..., 1], rtol=1e-9, atol=0)
     assert (want_pk[..., 0] > 0.95).any()
+    # several real peaks per pixel somewhere, i.e. the lists are not just the best pair
+    assert ((want_pk[..., 0] > 0.95).sum(axis=-1) >= 3).any()
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), want_d, 1e-9)
+    assert ok, msg
+    # the one-thread-per-pixel kernel (lists kept inline) gives the same bits as walk -> list cost -> merge
+    hip_ctx.set_option("force_generic", 1)
+    pk2 = torch.full((28, 40, p.top_k, 2), 7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    hip_ctx.mvs_initial_estimate(0, neigh[0], p, peaks_dev=pk2.data_ptr())
+    hip_ctx.synchronize()
+    hip_ctx.set_option("force_generic", 0)
+    assert np.array_equal(got.view(np.uint64), pk2.cpu().numpy().view(np.uint64))
 
 
 def test_rccl_exchange_single_rank(hip_ctx):
