@@ -20,6 +20,9 @@
  *     MVS top-K: the reference sources need Eigen (absent from this image), so
  *     they cannot be compiled here without writing a stand-in library;
  *     PARITY UNPINNED for these rows beyond line-by-line restatement.
+ *   - Camera::setP (project-file cameras): the reference factorises with Eigen's
+ *     HouseholderQR (absent): PARITY UNPINNED at the last ulp; Eigen's unblocked
+ *     Householder algorithm is restated and cross-checked against LAPACK.
  *   - refractive projection: reference calls GSL gsl_poly_complex_solve
  *     (gsl 1.14, absent): PARITY UNPINNED; restated as the physical root of the
  *     same quartic on [0, r].
