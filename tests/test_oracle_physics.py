@@ -144,3 +144,28 @@ def test_depth_sampling_of_the_labels():
     pts = O.epipolar_curve(ocams[0], ocams[1], imgs[1], op, False, 40, 12)
     assert pts[:, 1].min() == pts[:, 1].max() == 12                            # rectified: the curve is the row
     assert pts[:, 0].max() == 40 - 8 and pts[:, 0].min() in (40 - 8 - D + 1, 40 - 8 - D + 2)   # d0 = 8; last fragment dropped
+
+
+def test_refractive_root_is_the_companion_matrix_root_on_0_r():
+    """camera.cpp:95-138 solves (n^2-1)x^4 - 2r(n^2-1)x^3 + (r^2(n^2-1) + d^2 n^2 - (z-d)^2)x^2 - 2 d^2 n^2 r x
+    + d^2 n^2 r^2 = 0 with GSL's companion-matrix solver and keeps the root with 0 <= x <= r.  numpy.roots is the
+    same method (eigenvalues of the companion matrix): exactly one real root lies in [0, r], and the oracle's
+    Newton iteration lands on it."""
+    nrm, d, n = np.array([0.0, 0.0, 1.0]), 0.1, 1.333
+    cam = O.camera_set(np.eye(3), np.eye(3), np.zeros(3), None, nrm, d, n)
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        X = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.5, 12)])
+        z, r = X[2], np.hypot(X[0], X[1])
+        co = [n * n - 1, -2 * r * (n * n - 1), r * r * (n * n - 1) + d * d * n * n - (z - d) ** 2,
+              -2 * d * d * n * n * r, d * d * n * n * r * r]
+        roots = np.roots(co)
+        real = roots[np.abs(roots.imag) <= 1e-10].real
+        inside = real[(real >= -1e-12) & (real <= r + 1e-12)]
+        assert len(inside) == 1, (X, roots)
+        ok, p = _project(cam, X)
+        assert ok
+        # with K = R = I the "pixel" is the crossing point of the interface divided by its depth d
+        cross = np.array([p[0], p[1]]) * d
+        want = inside[0] * np.array([X[0], X[1]]) / r
+        assert np.allclose(cross, want, rtol=1e-9, atol=1e-12), (X, cross, want)
