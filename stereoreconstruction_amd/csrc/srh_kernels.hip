@@ -572,6 +572,8 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1,
 		int qn = 0;
 		uint32_t last = 0xffffffffu;                                // std::unique state (last kept point)
 
+		typedef const __attribute__((address_space(1))) uint8_t *gmask;   // global_load: not coupled to the LDS queue's counter
+		const gmask bmask = (gmask)B.mask;
 		auto flush = [&]() {
 			for (int k0 = 0; __any(k0 < qn); k0 += 8) {
 				uint32_t e[8];
@@ -580,7 +582,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1,
 				for (int j = 0; j < 8; ++j) e[j] = k0 + j < qn ? s_q[k0 + j][tid] : 0u;
 #pragma unroll
 				for (int j = 0; j < 8; ++j)
-					m[j] = k0 + j < qn ? B.mask[(size_t)(e[j] >> 16)*OW + (e[j] & 0xffffu)] : (uint8_t)0;
+					m[j] = k0 + j < qn ? bmask[(size_t)(e[j] >> 16)*OW + (e[j] & 0xffffu)] : (uint8_t)0;
 #pragma unroll
 				for (int j = 0; j < 8; ++j)
 					if (m[j] == 1 && e[j] != last) {                // mask == WHITE, then std::unique (:786-807)
