@@ -94,7 +94,7 @@ def test_c5_refractive_rows_equal_ordered_lists(hip_ctx):
 
 def test_c3_full_size_band_invariance(hip_ctx):
     """C3: 1920x1080, 256 levels, GeodesicWeight r=5: the depth map must not depend on the band
-    split (4 bands at the default budget vs 40+ bands at 128 MB), left->right pass."""
+    split (one band at the default 8 GB budget vs ~50 bands at 128 MB), left->right pass."""
     W, H, D = 1920, 1080, 256
     _, _, p, _ = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
     hip_ctx.set_option("band_budget_mb", 8192)
