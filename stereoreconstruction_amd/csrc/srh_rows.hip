@@ -135,6 +135,10 @@ struct RowsSmem {
 	int meta[RC_TP];
 	uint32_t rowinfo[RC_TP][RW_NR];
 	unsigned short blk0[RC_TP][RW_NR + 2];                    // first 8-column block (task) of each row; [nr] = total
+	// phase 2 work list: blocks that need the select form, (pixel << 16) | task, compacted over the tile
+	static constexpr int GL_CAP = 2048;
+	unsigned int glist[GL_CAP];
+	int glist_n;
 };
 
 template <int R>
@@ -253,6 +257,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		}
 		S.blk0[i][nr] = (unsigned short)nblk;
 	}
+	if (tid == 0) S.glist_n = 0;
 	__syncthreads();
 
 	unsigned n_dev = 0;
@@ -260,6 +265,99 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	unsigned d_task = 0, d_fast = 0, d_rows = 0, d_wavefast = 0, d_waveiter = 0;
 #endif
 	const Smem &CS = S;
+	// one 8-column block of pixel `pi` (task = index of the block among the pixel's spans) in the blocked select
+	// form: any validity pattern (image border, masked taps, cut-off weights); the same sums as the fast form with
+	// every tap guarded -- a skipped tap adds +0.0
+	auto general_block = [&](int pi, int task) {
+		const int m = CS.meta[pi];
+		const int ymin = (int)(short)(m & 0xffff);
+		int r = 0;
+		while (task >= (int)CS.blk0[pi][r + 1]) ++r;
+		const uint32_t info = CS.rowinfo[pi][r];
+		const int xlo = (int)(short)(info & 0xffff), wdt = (int)(info >> 16);
+		const int b = task - (int)CS.blk0[pi][r];
+		const int cy = ymin + r;
+		const int c0 = xlo + b*RC_NCB;
+		const int nv = wdt - b*RC_NCB < RC_NCB ? wdt - b*RC_NCB : RC_NCB;
+		double *dst = cost + (size_t)blockIdx.x*smax*RC_TP + pi + (size_t)task*RC_NCB*RC_TP;
+			// blocked select form, any validity pattern (image border, masked taps, cut-off weights):
+			// the same sums with every tap guarded; a skipped tap adds +0.0
+			const int gx0 = c0 - R;
+			double mLs[RC_NCB], mRs[RC_NCB], tws[RC_NCB];
+#pragma unroll
+			for (int j = 0; j < RC_NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
+#pragma unroll 1
+			for (int row = 0; row < WS; ++row) {
+				const int gy = cy - R + row;
+				const bool rowok = gy >= 0 && gy < OH;
+				const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
+				double rr[NR_];
+#pragma unroll
+				for (int k = 0; k < NR_; ++k) {
+					const int gx = gx0 + k;
+					rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
+				}
+#pragma unroll
+				for (int col = 0; col < WS; ++col) {
+					const double gl = CS.lt[row][pi + col], wt = CS.w[pi][row*WP + col];
+					const bool okl = gl == gl && wt > P.weight_cutoff;
+					const double pl = wt*gl;
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) {
+						const double gr = rr[col + j];
+						const bool ok = okl && gr == gr;
+						const double pr = wt*gr;
+						mLs[j] += ok ? pl : 0.0;
+						mRs[j] += ok ? pr : 0.0;
+						tws[j] += ok ? wt : 0.0;
+					}
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < RC_NCB; ++j) { mLs[j] /= tws[j]; mRs[j] /= tws[j]; }   // unused when tws < 1e-10
+			double s1[RC_NCB], s2v[RC_NCB], s3[RC_NCB];
+#pragma unroll
+			for (int j = 0; j < RC_NCB; ++j) { s1[j] = 0.0; s2v[j] = 0.0; s3[j] = 0.0; }
+#pragma unroll 1
+			for (int row = 0; row < WS; ++row) {
+				const int gy = cy - R + row;
+				const bool rowok = gy >= 0 && gy < OH;
+				const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
+				double rr[NR_];
+#pragma unroll
+				for (int k = 0; k < NR_; ++k) {
+					const int gx = gx0 + k;
+					rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
+				}
+#pragma unroll
+				for (int col = 0; col < WS; ++col) {
+					const double gl = CS.lt[row][pi + col], wt = CS.w[pi][row*WP + col];
+					const bool okl = gl == gl && wt > P.weight_cutoff;
+					const double pl = wt*gl;
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) {
+						const double gr = rr[col + j];
+						const bool ok = okl && gr == gr;
+						const double a = pl - mLs[j], bq = wt*gr - mRs[j];
+						const double ab = a*bq, aa = a*a, bb = bq*bq;
+						s1[j] += ok ? ab : 0.0;
+						s2v[j] += ok ? aa : 0.0;
+						s3[j] += ok ? bb : 0.0;
+					}
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < RC_NCB; ++j) {
+				if (j < nv) {
+					double result = P.bad_ret;
+					if (!(tws[j] < 1e-10)) {
+						const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2v[j] * s3[j]));
+						result = (v < P.max_color_diff) ? v : P.max_color_diff;
+					}
+					dst[j*RC_TP] = result;
+				}
+			}
+	};
 	if (x < W) {
 		const int m = CS.meta[i];
 		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
@@ -357,86 +455,20 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						}
 					}
 				} else {
-					// blocked select form, any validity pattern (image border, masked taps, cut-off weights):
-					// the same sums with every tap guarded; a skipped tap adds +0.0
-					const int gx0 = c0 - R;
-					double mLs[RC_NCB], mRs[RC_NCB], tws[RC_NCB];
-#pragma unroll
-					for (int j = 0; j < RC_NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
-#pragma unroll 1
-					for (int row = 0; row < WS; ++row) {
-						const int gy = cy - R + row;
-						const bool rowok = gy >= 0 && gy < OH;
-						const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
-						double rr[NR_];
-#pragma unroll
-						for (int k = 0; k < NR_; ++k) {
-							const int gx = gx0 + k;
-							rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
-						}
-#pragma unroll
-						for (int col = 0; col < WS; ++col) {
-							const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
-							const bool okl = gl == gl && wt > P.weight_cutoff;
-							const double pl = wt*gl;
-#pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) {
-								const double gr = rr[col + j];
-								const bool ok = okl && gr == gr;
-								const double pr = wt*gr;
-								mLs[j] += ok ? pl : 0.0;
-								mRs[j] += ok ? pr : 0.0;
-								tws[j] += ok ? wt : 0.0;
-							}
-						}
-					}
-#pragma unroll
-					for (int j = 0; j < RC_NCB; ++j) { mLs[j] /= tws[j]; mRs[j] /= tws[j]; }   // unused when tws < 1e-10
-					double s1[RC_NCB], s2v[RC_NCB], s3[RC_NCB];
-#pragma unroll
-					for (int j = 0; j < RC_NCB; ++j) { s1[j] = 0.0; s2v[j] = 0.0; s3[j] = 0.0; }
-#pragma unroll 1
-					for (int row = 0; row < WS; ++row) {
-						const int gy = cy - R + row;
-						const bool rowok = gy >= 0 && gy < OH;
-						const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
-						double rr[NR_];
-#pragma unroll
-						for (int k = 0; k < NR_; ++k) {
-							const int gx = gx0 + k;
-							rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
-						}
-#pragma unroll
-						for (int col = 0; col < WS; ++col) {
-							const double gl = CS.lt[row][i + col], wt = CS.w[i][row*WP + col];
-							const bool okl = gl == gl && wt > P.weight_cutoff;
-							const double pl = wt*gl;
-#pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) {
-								const double gr = rr[col + j];
-								const bool ok = okl && gr == gr;
-								const double a = pl - mLs[j], bq = wt*gr - mRs[j];
-								const double ab = a*bq, aa = a*a, bb = bq*bq;
-								s1[j] += ok ? ab : 0.0;
-								s2v[j] += ok ? aa : 0.0;
-								s3[j] += ok ? bb : 0.0;
-							}
-						}
-					}
-#pragma unroll
-					for (int j = 0; j < RC_NCB; ++j) {
-						if (j < nv) {
-							double result = P.bad_ret;
-							if (!(tws[j] < 1e-10)) {
-								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2v[j] * s3[j]));
-								result = (v < P.max_color_diff) ? v : P.max_color_diff;
-							}
-							dst[j*RC_TP] = result;
-						}
-					}
+					// needs the select form: handed to phase 2, where such blocks of the whole tile are spread
+					// over all lanes (a wave dragged through the select form for a few lanes costs ~3.5 fast blocks)
+					const int slot = atomicAdd(&S.glist_n, 1);
+					if (slot < Smem::GL_CAP) S.glist[slot] = ((unsigned)i << 16) | (unsigned)task;
+					else general_block(i, task);                       // list full (cannot happen below 64 blocks per pixel)
 				}
 			}
 		}
+	}
+	// ---- phase 2: the listed blocks in the select form, one per lane
+	__syncthreads();
+	{
+		const int nl = S.glist_n < Smem::GL_CAP ? S.glist_n : Smem::GL_CAP;
+		for (int k = tid; k < nl; k += RC_THREADS) general_block((int)(S.glist[k] >> 16), (int)(S.glist[k] & 0xffffu));
 	}
 	block_count_add(&cnt->n_eval_device, n_dev);
 #ifdef SRH_ROWS_DBG
