@@ -38,6 +38,7 @@ passes (one counter per pass, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, as `MI355X
   * HBM: algorithmic 14 B/pixel ⇒ {c3['roofline']['hbm']['alg_bytes_per_launch']/1e6:.1f} MB per launch; measured traffic {c3['roofline']['traffic']/1e6:.0f} MB per launch —
     the staged cost rows and support windows — i.e. {c3['roofline']['hbm']['traffic_over_algorithmic']:.0f}× the algorithmic bytes, at ≈300 GB/s (3.8 % of HBM peak): it
     does not limit the kernel (DESIGN.md §9 item 1 has the fusion analysis).
+* CPU, all cores: the same band on {c3['cpu_baseline']['all_cores']['cores']} host threads runs at {c3['cpu_baseline']['all_cores']['value']:.2f} Mhyp/s.
 * `twoview_scan_kernel` {per(c3,'twoview_scan_kernel')/2:.2f} ms / launch ({s3['twoview_scan_kernel']['hbm_bytes_per_launch_corrected']/1e9:.1f} GB per launch since the cost rows are stored
   tile-transposed — the 32 pixels' k-th costs contiguous; 11.3 GB before, when every lane pulled its own 64-byte sectors),
   `geodesic_reg_kernel` {per(c3,'geodesic_reg_kernel')/2:.2f} ms / launch.
@@ -58,8 +59,8 @@ passes (one counter per pass, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, as `MI355X
 
 * **{c5['value']/1e3:.2f} G hyp/s, {c5['ms_per_step']:.0f} ms per pair** (row-run candidate lists: cost {per(c5,'twoview_rows_cost_kernel'):.0f} ms, refractive curve walk
   {per(c5,'twoview_rows_list_kernel'):.0f} ms, scan {per(c5,'twoview_rows_scan_kernel'):.1f} ms per step).  History: 1 497 ms (one thread per pixel) → 273 ms (lists evaluated in
-  list order, 242 gathers per candidate) → 189 ms (row runs) → 144 ms (one band) → {c5['ms_per_step']:.0f} ms (wave-tiled lists and
-  tile-transposed cost slots: scan 18 → {per(c5,'twoview_rows_scan_kernel'):.1f} ms).  Full-width band vs oracle: 0 mismatches.
+  list order, 242 gathers per candidate) → 189 ms (row runs) → 144 ms (one band) → 126 ms (wave-tiled lists and
+  tile-transposed cost slots: scan 18 → {per(c5,'twoview_rows_scan_kernel'):.1f} ms) → {c5['ms_per_step']:.0f} ms (select-form blocks compacted over the tile).  Full-width band vs oracle: 0 mismatches.
 
 ### C1: the example project's bunny pair (`--workload c1`)
 
