@@ -721,7 +721,6 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	const int y = y0 + trow;
 	const int tid = threadIdx.x;
 	const int x = x0 + tid;
-	const size_t q = (size_t)trow*W + x;
 
 	__shared__ unsigned short queue[SC_QN][SC_TW];
 	__shared__ unsigned char mrow[SC_MW];
