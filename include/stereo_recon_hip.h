@@ -131,8 +131,11 @@ void srh_destroy(srh_context *ctx);
 int  srh_set_stream(srh_context *ctx, void *hip_stream);
 int  srh_set_hooks(srh_context *ctx, const volatile int *cancel, srh_progress_fn progress, void *user);
 int  srh_synchronize(srh_context *ctx);
-/* Tuning / test switches: "force_generic" (0/1: never take the dense row-aligned
- * kernels), "band_budget_mb" (device scratch per row band). */
+/* Tuning / test switches (results never depend on them):
+ *   "force_generic"   0 default paths; 1 never the dense row-aligned TwoView kernels nor the MVS list kernels;
+ *                     2 additionally no candidate lists at all (one thread per pixel walks and costs its curve)
+ *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
+ *   "band_budget_mb"  device scratch per row band (default 8192) */
 int  srh_set_option(srh_context *ctx, const char *name, long value);
 
 /* ---- views: what VectorImage::fromQImage + the mask test hold (util/vectorimage.cpp:48-64) ----
