@@ -17,6 +17,7 @@ passes (one counter per pass, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, as `MI355X
 | `r01_c{{1,2,3,4,5}}_bench.json` | bench lines of this round (`python3 bench.py [--workload …] --steps 5 --warmup 1`, CPU baseline + full-size parity band included) |
 | `r01_c3_kernel_stats.csv`, `r01_c4_kernel_stats.csv`, `r01_c5_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv` per-kernel summaries |
 | `r01_c3_summary.json`, `r01_c4_summary.json` | kernel stats joined with the `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes (`summarize_rocprof.py`) |
+| `r01_c3_instruction_mix.txt` | `rocprofv3 --pmc` passes over one C3 step (`SQ_INSTS_VALU/LDS/SALU/MFMA`, `SQ_INSTS_VALU_ADD_F64` / `MUL_F64` / `FMA_F64` / `MFMA_F64`, `SQ_WAVE_CYCLES`, `SQ_BUSY_CU_CYCLES`), summed per kernel (`pmc_table.py`) |
 | `pmc_traffic.json` | HBM bytes per launch per kernel = (2·FETCH_SIZE + WRITE_SIZE)·1024 (gfx950 FETCH_SIZE counts half of wide reads); read by `bench.py` for `roofline.traffic` |
 | `microbench/fp64_rate.hip`, `fp64_rate_mi355x.txt` | what the chip sustains for separate `v_mul_f64`+`v_add_f64` (the no-contraction mix): 37.6–38.4 T lane-instr/s at ≥2 waves/SIMD, FMA 62.7–70.7 TFLOP/s |
 | `summarize_rocprof.py`, `pmc_table.py`, `mvs_bench.py`, `make_readme.py` | the scripts that made the summaries and this file |
@@ -38,6 +39,10 @@ passes (one counter per pass, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, as `MI355X
   * HBM: algorithmic 14 B/pixel ⇒ {c3['roofline']['hbm']['alg_bytes_per_launch']/1e6:.1f} MB per launch; measured traffic {c3['roofline']['traffic']/1e6:.0f} MB per launch —
     the staged cost rows and support windows — i.e. {c3['roofline']['hbm']['traffic_over_algorithmic']:.0f}× the algorithmic bytes, at ≈300 GB/s (3.8 % of HBM peak): it
     does not limit the kernel (DESIGN.md §9 item 1 has the fusion analysis).
+* Instruction mix of the two launches of one step (`r01_c3_instruction_mix.txt`): 19.58 G VALU wave-instructions, of
+  which 8.33 G `v_mul_f64` + 8.33 G `v_add_f64` (85 %; 1004 per nominal hypothesis against the 968 of the fast form),
+  0.36 G `v_fma_f64` (inside the compiler's division / square-root sequences only), 1.27 G LDS instructions,
+  **0 MFMA**; 19.58 G × 4 cycles on 1024 SIMDs for 40.5 ms at 2.4 GHz = 79 % of the VALU issue slots.
 * CPU, all cores: the same band on {c3['cpu_baseline']['all_cores']['cores']} host threads runs at {c3['cpu_baseline']['all_cores']['value']:.2f} Mhyp/s.
 * `twoview_scan_kernel` {per(c3,'twoview_scan_kernel')/2:.2f} ms / launch ({s3['twoview_scan_kernel']['hbm_bytes_per_launch_corrected']/1e9:.1f} GB per launch since the cost rows are stored
   tile-transposed — the 32 pixels' k-th costs contiguous; 11.3 GB before, when every lane pulled its own 64-byte sectors),
