@@ -366,6 +366,12 @@ int sro_line_points(double fx0, double fy0, double fx1, double fy1, int clip, in
 {
 	int x0 = trunc_sat(fx0), y0 = trunc_sat(fy0), x1 = trunc_sat(fx1), y1 = trunc_sat(fy1);
 	collect_ctx c = { out_xy, max_pts, 0 };
+	if (clip == 2) {
+		/* the bounded (jump-ahead) form the TwoView curve uses (sro_epipolar_curve, 4-arg
+		 * LineIterator of twoviewstereo.cpp:1028 restricted to the image): no clipping */
+		line_walk(x0, y0, x1, y1, w, h, collect_cb, &c);
+		return c.n;
+	}
 	if (clip) {
 		if (!clip_line(&x0, &y0, &x1, &y1, w, h)) return 0; /* lineiter.hpp:49-60 */
 	}

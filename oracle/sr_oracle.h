@@ -110,6 +110,9 @@ double sro_to_gray(double r, double g, double b);
 /* --- util/lineiter --- */
 /* LineIterator 4-arg (clip=0) or 6-arg (clip=1) ctor taking doubles truncated to
  * int, iterated to exhaustion (lineiter.hpp:32-118, lineiter.cpp:35-88).
+ * clip=2: the 4-arg walk in the bounded form sro_epipolar_curve uses for TwoView curves:
+ * by the closed form of the Bresenham state only the part whose major coordinate lies
+ * in [0,w) x [0,h) is visited (the callers drop every other point anyway).
  * Writes up to max_pts (x,y) pairs; returns the number of points of the line. */
 int sro_line_points(double x0, double y0, double x1, double y1, int clip, int w, int h,
                     int32_t *out_xy, int max_pts);

@@ -214,10 +214,12 @@ def weights(img, cx, cy, p):
     return out
 
 
-def line_points(x0, y0, x1, y1, clip=False, w=0, h=0, cap=1 << 16):
+def line_points(x0, y0, x1, y1, clip=False, w=0, h=0, cap=1 << 16, bounded=False):
+    """clip: 6-arg LineIterator; bounded: the 4-arg walk in the jump-ahead form restricted to [0,w)x[0,h)
+    that sro_epipolar_curve uses for TwoView curves (sr_oracle.c line_walk with bounds)."""
     out = np.empty((cap, 2), dtype=np.int32)
-    n = lib().sro_line_points(x0, y0, x1, y1, int(clip), w, h, iptr(out), cap)
-    return out[:n].copy()
+    n = lib().sro_line_points(x0, y0, x1, y1, 2 if bounded else int(clip), w, h, iptr(out), cap)
+    return out[:min(n, cap)].copy()
 
 
 def epipolar_curve(refcam, othcam, oth, p, mvs, x, y, cap=1 << 16):

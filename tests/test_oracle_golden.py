@@ -122,6 +122,59 @@ def test_live_reference_pieces_random():
         R.refp_image_free(rh)
 
 
+def _in_image(pts, w, h):
+    pts = np.asarray(pts, dtype=np.int32).reshape(-1, 2)
+    keep = (pts[:, 0] >= 0) & (pts[:, 1] >= 0) & (pts[:, 0] < w) & (pts[:, 1] < h)
+    return pts[keep]
+
+
+def test_bounded_walk_against_the_reference_fixture():
+    """The TwoView curve rasterises with the 4-arg LineIterator and then drops every point outside the
+    other image (mask.pixel() is INVALID there, twoviewstereo.cpp:1028-1040).  The oracle (and the
+    kernels) walk a *bounded* form that jumps over the off-image prefix through the closed form of the
+    Bresenham state (sr_oracle.c line_walk, bound_w > 0).  Pinned here: its in-image points equal the
+    in-image points of the reference's own unbounded walk (fixture = output of util/lineiter.cpp)."""
+    g = np.load(os.path.join(GOLD, "ref_pieces.npz"))
+    h, w = g["images"].shape[1:3]
+    pts, offs = g["line_points_clip0"], g["line_offsets_clip0"]
+    nonempty = 0
+    for k, s in enumerate(g["line_segments"]):
+        want = _in_image(pts[offs[k]:offs[k + 1]], w, h)
+        got = _in_image(O.line_points(s[0], s[1], s[2], s[3], w=w, h=h, bounded=True), w, h)
+        assert np.array_equal(got, want), (k, s)
+        nonempty += len(want) > 0
+    assert nonempty > 50
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_bounded_walk_against_the_live_reference():
+    """Same property against the compiled reference on random segments that start (far) off-image, at
+    both slopes and in both directions -- the jump-ahead formula sr_oracle.c:337-346 is exercised with
+    k from 1 to thousands of steps."""
+    R = O.ref()
+    rng = np.random.default_rng(11)
+    buf = np.empty((1 << 16, 2), np.int32)
+    checked = jumped = 0
+    for i in range(6000):
+        w, h = int(rng.integers(3, 90)), int(rng.integers(3, 70))
+        far = (40, 400, 6000)[i % 3]
+        a = rng.uniform(-far, far, 2)
+        b = rng.uniform(-20, max(w, h) + 20, 2) if i % 2 else rng.uniform(-far, far, 2)
+        if i % 5 == 0:
+            a, b = np.round(a), np.round(b)
+        if i % 7 == 0:
+            a, b = b, a
+        n = R.refp_line_points(a[0], a[1], b[0], b[1], 0, w, h, O.iptr(buf), buf.shape[0])
+        assert n <= buf.shape[0]
+        want = _in_image(buf[:n], w, h)
+        got_all = O.line_points(a[0], a[1], b[0], b[1], w=w, h=h, bounded=True)
+        got = _in_image(got_all, w, h)
+        assert np.array_equal(got, want), (i, w, h, a, b)
+        checked += len(want) > 0
+        jumped += len(got_all) < n and len(want) > 0
+    assert checked > 1500 and jumped > 500
+
+
 def test_oracle_twoview_rectified_candidates():
     """Rectified geometry: every candidate of pixel (x,y) lies on row y and the distinct columns
     are x-d for the label disparities (SURVEY.md 8(a) pixel-centre note, 8(d))."""
