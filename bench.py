@@ -304,8 +304,8 @@ def main():
         ctx.twoview_wta(0, 1, p)
         ctx.twoview_wta(1, 0, p)
         ctx.twoview_cross_check(0, 1, p)
-        ctx.copy_depth_to_device(0, outs[b][0].data_ptr())
-        ctx.copy_depth_to_device(1, outs[b][1].data_ptr())
+        ctx.copy_depth_to_device(0, outs[b][0].data_ptr(), H * W * 8)
+        ctx.copy_depth_to_device(1, outs[b][1].data_ptr(), H * W * 8)
         if world > 1:
             ctx.synchronize()      # the library's stream and torch's / RCCL's streams are not ordered
             src = outs[b] if on_dev else outs[b].cpu()

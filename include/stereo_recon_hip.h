@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 1
+#define SRH_ABI_VERSION 2
 
 enum {
 	SRH_OK = 0,
@@ -148,12 +148,14 @@ int  srh_view_size(srh_context *ctx, int slot, int *w, int *h);
 int  srh_view_depth_download(srh_context *ctx, int slot, double *host_out);
 int  srh_view_depth_upload(srh_context *ctx, int slot, const double *host_in);
 int  srh_view_depth_device_ptr(srh_context *ctx, int slot, void **dev_ptr);
-/* Asynchronous device-to-device copy of the slot's depth map into caller-owned
- * DEVICE memory (e.g. a tensor that RCCL then gathers); ordered on the context stream. */
-int  srh_view_depth_copy_to_device(srh_context *ctx, int slot, void *dst_dev);
-/* The reverse: the slot's depth map is replaced by w*h doubles from DEVICE memory (a map another
- * rank computed, received through RCCL); asynchronous, ordered on the context stream. */
-int  srh_view_depth_copy_from_device(srh_context *ctx, int slot, const void *src_dev);
+/* Asynchronous device-to-device copy of the slot's depth map (w*h doubles) into caller-owned
+ * DEVICE memory of `dst_bytes` bytes (e.g. a tensor that RCCL then gathers); ordered on the context
+ * stream.  SRH_E_INVALID when the buffer is smaller than the map (views may differ in size). */
+int  srh_view_depth_copy_to_device(srh_context *ctx, int slot, void *dst_dev, size_t dst_bytes);
+/* The reverse: the slot's depth map is replaced by its first w*h doubles of `src_bytes` bytes of DEVICE
+ * memory (a map another rank computed, received through RCCL); asynchronous, ordered on the context
+ * stream.  SRH_E_INVALID when fewer than w*h doubles are offered. */
+int  srh_view_depth_copy_from_device(srh_context *ctx, int slot, const void *src_dev, size_t src_bytes);
 
 /* ---- TwoViewStereo ----
  * One pass of computeCostVolumes (twoviewstereo.cpp:260-333 with ref=left,
@@ -177,7 +179,7 @@ int  srh_twoview_compute(srh_context *ctx, int left_slot, int right_slot, const 
 
 /* ---- MultiViewStereo ----
  * computeInitialEstimate(view) non-MRF result (multiviewstereo.cpp:524-604,654-660)
- * for `view_slot` against up to num_neighbours neighbour slots, rows [y0,y1).
+ * for `view_slot` against `nneigh` neighbour slots (0..8; the reference keeps 3), rows [y0,y1).
  * peaks_dev (optional, DEVICE pointer, w*h*top_k*2 doubles) receives the sorted
  * top-K (cost,depth) pairs the MRF branch would consume. */
 int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *neigh_slots, int nneigh,

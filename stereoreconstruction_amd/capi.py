@@ -117,8 +117,8 @@ def lib():
     L.srh_view_depth_download.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
-    L.srh_view_depth_copy_to_device.argtypes = [vp, C.c_int, vp]
-    L.srh_view_depth_copy_from_device.argtypes = [vp, C.c_int, vp]
+    L.srh_view_depth_copy_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.srh_view_depth_copy_from_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.srh_twoview_wta.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.srh_twoview_cross_check.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params)]
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
@@ -301,11 +301,11 @@ class Context:
         _check(lib().srh_view_depth_device_ptr(self._h, slot, C.byref(p)))
         return p.value
 
-    def copy_depth_to_device(self, slot, dst_dev_ptr):
-        _check(lib().srh_view_depth_copy_to_device(self._h, slot, C.c_void_p(dst_dev_ptr)))
+    def copy_depth_to_device(self, slot, dst_dev_ptr, dst_bytes):
+        _check(lib().srh_view_depth_copy_to_device(self._h, slot, C.c_void_p(dst_dev_ptr), C.c_size_t(dst_bytes)))
 
-    def copy_depth_from_device(self, slot, src_dev_ptr):
-        _check(lib().srh_view_depth_copy_from_device(self._h, slot, C.c_void_p(src_dev_ptr)))
+    def copy_depth_from_device(self, slot, src_dev_ptr, src_bytes):
+        _check(lib().srh_view_depth_copy_from_device(self._h, slot, C.c_void_p(src_dev_ptr), C.c_size_t(src_bytes)))
 
     # -- TwoViewStereo
     def twoview_wta(self, ref_slot, oth_slot, p, y0=0, y1=0):

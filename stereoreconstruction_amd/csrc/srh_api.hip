@@ -373,8 +373,13 @@ extern "C" int srh_create(int device, srh_context **out) {
 		srh_destroy(c);
 		return fail(SRH_E_DEVICE, "hipMalloc of context tables failed");
 	}
-	hipMemset(c->d_views, 0, sizeof(ViewDev)*SRH_MAX_VIEWS);
-	hipMemset(c->d_cnt, 0, sizeof(Counters));
+	// ordered on the context's own (non-blocking) stream, which the null stream does not synchronise with
+	if (hipMemsetAsync(c->d_views, 0, sizeof(ViewDev)*SRH_MAX_VIEWS, c->stream) != hipSuccess ||
+	    hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream) != hipSuccess ||
+	    hipStreamSynchronize(c->stream) != hipSuccess) {
+		srh_destroy(c);
+		return fail(SRH_E_DEVICE, "initialising the context tables failed");
+	}
 	*out = c;
 	return SRH_OK;
 }
@@ -517,20 +522,24 @@ extern "C" int srh_view_depth_device_ptr(srh_context *c, int slot, void **dev_pt
 	return SRH_OK;
 }
 
-extern "C" int srh_view_depth_copy_to_device(srh_context *c, int slot, void *dst_dev) {
+extern "C" int srh_view_depth_copy_to_device(srh_context *c, int slot, void *dst_dev, size_t dst_bytes) {
 	int rc = check_slot(c, slot, true); if (rc) return rc;
 	if (!dst_dev) return fail(SRH_E_INVALID, "null destination");
 	HIP_TRY(hipSetDevice(c->device));
 	const ViewHost &v = c->views[slot];
+	if (dst_bytes < (size_t)v.w*v.h*sizeof(double))
+		return fail(SRH_E_INVALID, "destination of %zu bytes is smaller than the %dx%d depth map of slot %d", dst_bytes, v.w, v.h, slot);
 	HIP_TRY(hipMemcpyAsync(dst_dev, v.depth, (size_t)v.w*v.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
 	return SRH_OK;
 }
 
-extern "C" int srh_view_depth_copy_from_device(srh_context *c, int slot, const void *src_dev) {
+extern "C" int srh_view_depth_copy_from_device(srh_context *c, int slot, const void *src_dev, size_t src_bytes) {
 	int rc = check_slot(c, slot, true); if (rc) return rc;
 	if (!src_dev) return fail(SRH_E_INVALID, "null source");
 	HIP_TRY(hipSetDevice(c->device));
 	const ViewHost &v = c->views[slot];
+	if (src_bytes < (size_t)v.w*v.h*sizeof(double))
+		return fail(SRH_E_INVALID, "source of %zu bytes is smaller than the %dx%d depth map of slot %d", src_bytes, v.w, v.h, slot);
 	HIP_TRY(hipMemcpyAsync(v.depth, src_dev, (size_t)v.w*v.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
 	return SRH_OK;
 }
@@ -551,6 +560,7 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.n_eval = (int64_t)h.n_eval;
 	c->stats.n_eval_device = (int64_t)h.n_eval_device;
 	c->stats.used_dense_path = used_dense;
+#ifdef SRH_PROFILE_PHASES
 	if (h.dbg_waves)
 		fprintf(stderr, "[srh dbg] dense: waves %llu, cycles/wave %.0f, fast blocks/wave %.1f, cycles/fast block %.0f\n",
 		        h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_blocks/h.dbg_waves,
@@ -563,6 +573,7 @@ static int fetch_counters(srh_context *c, int used_dense) {
 		fprintf(stderr, "[srh dbg] rows: tasks %llu fast %llu, rows/pixel %.2f, slots/px %.1f, wave iterations %llu all-fast %llu\n",
 		        h.dbg_phase[6], h.dbg_phase[7], (double)h.dbg_cycles/(double)h.n_pixels, 8.0*h.dbg_phase[6]/(double)h.n_pixels,
 		        h.dbg_blocks, h.dbg_total_cycles);
+#endif
 	return SRH_OK;
 }
 
@@ -814,7 +825,8 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 {
 	int rc;
 	if ((rc = check_slot(c, view, true)) || (rc = check_params(p))) return rc;
-	if (nneigh < 0 || nneigh > 3) return fail(SRH_E_UNSUPPORTED, "nneigh %d outside [0,3] (NUM_NEIGHBOURING_VIEWS is 3)", nneigh);
+	if (nneigh < 0 || nneigh > SRH_MAX_NEIGH)
+		return fail(SRH_E_UNSUPPORTED, "nneigh %d outside [0,%d] (the reference's NUM_NEIGHBOURING_VIEWS is 3)", nneigh, SRH_MAX_NEIGH);
 	if (nneigh > 0 && !neigh) return fail(SRH_E_INVALID, "null neighbour list");
 	if (peaks_dev && p->top_k < 1) return fail(SRH_E_INVALID, "top_k < 1");
 	for (int i = 0; i < nneigh; ++i) {
@@ -882,7 +894,7 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 
 	const int rows = band_rows(c, W, H, T);
 	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, rows, T)))) return rc;
-	if ((rc = ensure(c->cost, c->cost_cap, (size_t)rows*W*2*3))) return rc;       // per-neighbour best (cost, depth)
+	if ((rc = ensure(c->cost, c->cost_cap, (size_t)rows*W*2*(size_t)std::max(nneigh, 1)))) return rc;   // per-neighbour best (cost, depth)
 	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 	for (int by = y0; by < y1; by += rows) {
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");

@@ -13,8 +13,6 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
-#include <cstdlib>
-
 namespace srh {
 
 // ------------------------------------------------------------------ edge planes
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                                const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
-                               Counters *__restrict__ cnt, int dbg)
+                               Counters *__restrict__ cnt)
 {
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
@@ -326,9 +324,17 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 
 	const double nan = __builtin_nan("");
 
+	// Per-phase cycle stamps exist only in a -DSRH_PROFILE_PHASES diagnostic build (make EXTRA=-DSRH_PROFILE_PHASES):
+	// the shipped kernel carries no debug switch and no stamp.
+#ifdef SRH_PROFILE_PHASES
 	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	unsigned long long tp = (dbg & 2) ? __builtin_readcyclecounter() : 0;
-#define SRH_STAMP(k) do { if (dbg & 2) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
+	unsigned long long tp = __builtin_readcyclecounter();
+	unsigned long long t_fast = 0, n_fast = 0;
+	const unsigned long long t_begin = tp;
+#define SRH_STAMP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define SRH_STAMP(k) do { } while (0)
+#endif
 
 	// Staging and bookkeeping run at raised wave priority: a freshly dispatched workgroup
 	// shares its SIMDs with an older one that is deep in the FP64 loops, and must get its
@@ -363,26 +369,26 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	{
 		// tile-major window buffer: the T*DC_TP doubles of this tile are contiguous
 		static_assert(DC_TP == SRH_WTILE, "dense tile = window-buffer tile");
-		const double *wtile = wbuf + ((dbg & 16) ? wbuf_offset(W, T, 10, 320) : wbuf_offset(W, T, trow, x0));
+		const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
 		double tw_[NBW], tl_[NBL], tr_[NBR];
 #pragma unroll
 		for (int k = 0; k < NBW; ++k) {
 			const int idx = tid + k*DC_THREADS;
-			tw_[k] = (!(dbg & 8) && idx < T*DC_TP && x0 + (idx % DC_TP) < W) ? wtile[idx] : 0.5;
+			tw_[k] = (idx < T*DC_TP && x0 + (idx % DC_TP) < W) ? wtile[idx] : 0.0;
 		}
 #pragma unroll
 		for (int k = 0; k < NBL; ++k) {
 			const int idx = tid + k*DC_THREADS;
 			const int ty = idx / Smem::LW, tx = idx % Smem::LW;
 			const int gx = x0 - R + tx, gy = y - R + ty;
-			tl_[k] = (dbg & 8) ? 1.0*idx : (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
+			tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
 		}
 #pragma unroll
 		for (int k = 0; k < NBR; ++k) {
 			const int idx = tid + k*DC_THREADS;
 			const int ty = idx / Smem::RW, tx = idx % Smem::RW;
 			const int gx = cmin - R + tx, gy = y - R + ty;
-			tr_[k] = (dbg & 8) ? 2.0*idx : (cmin <= cmax && idx < WS*Smem::RW && gx >= 0 && gy >= 0 && gx < Rv.w && gy < Rv.h)
+			tr_[k] = (cmin <= cmax && idx < WS*Smem::RW && gx >= 0 && gy >= 0 && gx < Rv.w && gy < Rv.h)
 			       ? Rv.gray_tv[(size_t)gy*Rv.w + gx] : nan;
 		}
 #pragma unroll
@@ -436,8 +442,6 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	SRH_STAMP(2);
 
 	unsigned n_dev = 0;
-	unsigned long long t_fast = 0, n_fast = 0;
-	const unsigned long long t_begin = (dbg & 2) ? __builtin_readcyclecounter() : 0;
 	const Smem &CS = S;
 	for (int cs = cmin; cs <= cmax; cs += DC_CHUNK) {
 		if (cs != cmin) {
@@ -503,9 +507,9 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 					const int c = c0 + j;
 					if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) { fast = true; ++n_dev; }
 				}
-				if (dbg & 1) { if (c0 == -12345) crow[0] = 1.0; continue; }
-				const unsigned long long t0 = (dbg & 2) ? __builtin_readcyclecounter() : 0;
-				if (dbg & 32) fast = true;
+#ifdef SRH_PROFILE_PHASES
+				const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
 				if (fast) {
 					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
 					// Both passes are modulo-scheduled by hand: r[] / wv[] / av[] hold the current
@@ -599,12 +603,13 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 						const int c = c0 + j;
 						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							if (!(dbg & 4) || v == -12345.0)
 							crow[(size_t)(c - e.xmin)*DC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
-					if (dbg & 2) { t_fast += __builtin_readcyclecounter() - t0; ++n_fast; }
+#ifdef SRH_PROFILE_PHASES
+					t_fast += __builtin_readcyclecounter() - t0; ++n_fast;
+#endif
 				}
 			}
 		}
@@ -637,13 +642,16 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	SRH_STAMP(4);
 	block_count_add(&cnt->n_eval_device, n_dev);
 	SRH_STAMP(5);
-	if ((dbg & 2) && (tid & 63) == 0) {
+#ifdef SRH_PROFILE_PHASES
+	if ((tid & 63) == 0) {
 		for (int k = 0; k < 8; ++k) atomicAdd(&cnt->dbg_phase[k], ph[k]);
 		atomicAdd(&cnt->dbg_cycles, t_fast);
 		atomicAdd(&cnt->dbg_blocks, n_fast);
 		atomicAdd(&cnt->dbg_total_cycles, (unsigned long long)(__builtin_readcyclecounter() - t_begin));
 		atomicAdd(&cnt->dbg_waves, 1ull);
 	}
+#endif
+#undef SRH_STAMP
 }
 
 template <int R, int NCB, int CHUNK, int MINW>
@@ -652,15 +660,12 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
                                  const double *tnum, double *cost, int cstride, Counters *cnt)
 {
 	typedef DenseSmem<R, NCB, CHUNK> Smem;
-	static bool attr = false;
-	if (!attr) {
-		(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>,
-		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-		attr = true;
-	}
+	// a function attribute belongs to the CURRENT device: set it on every launch (a host-side table update),
+	// so contexts on several GPUs of one process all get their dynamic LDS
+	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>,
+	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
 	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>), grid, dim3(DC_THREADS), sizeof(Smem), st,
-	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt,
-	                   getenv("SRH_DENSE_DBG") ? atoi(getenv("SRH_DENSE_DBG")) : 0);
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt);
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -669,17 +674,10 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 {
 	const int tiles = (width + DC_TP - 1)/DC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
-	static int variant = -1;
-	if (variant < 0) { const char *v = getenv("SRH_DENSE_VARIANT"); variant = v ? atoi(v) : 0; }
 #define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt
 	switch (P.window_radius) {
 	case 5:
-		switch (variant) {
-		case 1:  launch_dense_variant<5, 6, 128, 3>(SRH_ARGS); break;
-		case 2:  launch_dense_variant<5, 4, 320, 2>(SRH_ARGS); break;
-		case 3:  launch_dense_variant<5, 4, 128, 3>(SRH_ARGS); break;
-		default: launch_dense_variant<5, 8, 320, 2>(SRH_ARGS); break;
-		}
+		launch_dense_variant<5, 8, 320, 2>(SRH_ARGS);
 		return true;
 	case 2:
 		launch_dense_variant<2, 8, 320, 2>(SRH_ARGS);
@@ -850,12 +848,7 @@ void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth,
 {
 	const size_t n = (size_t)nrows*width;
 	// block geometry of the dense kernel (dense_cover_hi must agree on both sides)
-	int ncb = 8, lanes = DC_G;
-	if (P.window_radius == 5) {
-		const char *v = getenv("SRH_DENSE_VARIANT");
-		const int variant = v ? atoi(v) : 0;
-		ncb = variant == 1 ? 6 : (variant == 2 || variant == 3 ? 4 : 8);
-	}
+	const int ncb = 8, lanes = DC_G;
 	(void)n;
 	const int tiles = (width + SC_TW - 1)/SC_TW;
 	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,

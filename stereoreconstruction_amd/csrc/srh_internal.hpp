@@ -49,6 +49,17 @@ struct Counters {
 	unsigned long long dbg_phase[8];
 };
 
+// Neighbour views of one MultiViewStereo estimate, passed to the kernels by value
+// (NUM_NEIGHBOURING_VIEWS is 3 in the reference, multiviewstereo.cpp:97; srh_params.num_neighbours is a
+// run-time parameter here, up to SRH_MAX_NEIGH).
+#define SRH_MAX_NEIGH 8
+struct NeighList { int32_t n[SRH_MAX_NEIGH]; };
+inline NeighList make_neigh_list(const int32_t *neigh, int nneigh) {
+	NeighList l;
+	for (int i = 0; i < SRH_MAX_NEIGH; ++i) l.n[i] = (i < nneigh) ? neigh[i] : 0;
+	return l;
+}
+
 // Per-pixel result of the curve-extent pass (dense path planning)
 struct Extent { int32_t xmin, xmax; };
 

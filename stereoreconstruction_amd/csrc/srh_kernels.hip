@@ -289,7 +289,7 @@ struct MvsVisitor {
 };
 
 __global__ void mvs_generic_kernel(const ViewDev *__restrict__ views, int ref,
-                                   int n0, int n1, int n2, int nneigh, srh_params P,
+                                   NeighList nl, int nneigh, srh_params P,
                                    int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                                    double *__restrict__ peaks, Counters *__restrict__ cnt)
 {
@@ -309,7 +309,7 @@ __global__ void mvs_generic_kernel(const ViewDev *__restrict__ views, int ref,
 			const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
 			MvsVisitor vis = { A, A, wbuf + wbuf_offset(W, T, (int)(q / W), x), wstride, P, ray, x, y, 0.0, -1.0, pk, 0 };
 			for (int ni = 0; ni < nneigh; ++ni) {
-				const int v2 = ni == 0 ? n0 : (ni == 1 ? n1 : n2);
+				const int v2 = nl.n[ni];
 				const ViewDev &B = views[v2];
 				MvsVisitor vb = { A, B, vis.wq, wstride, P, ray, x, y, vis.bestCost, vis.bestDepth, pk, vis.n };
 				walk_curve<true>(ray, A.cam, B, P, vb);
@@ -453,7 +453,7 @@ struct MvsRegVisitor {
 // (the non-MRF result is a maximum over all candidates, so the neighbours can run side by side).
 template <int R>
 __global__ __launch_bounds__(128)
-void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, int nneigh, srh_params P,
+void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, int nneigh, srh_params P,
                     int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                     double *__restrict__ peaks, double *__restrict__ best, Counters *__restrict__ cnt)
 {
@@ -505,7 +505,7 @@ void mvs_reg_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, 
 			MvsRegVisitor<R> vis = { A, &A, P, ray, w, a, x, y, okL, all, tw, s2, 0.0, -1.0, pk, 0, 0, 0, &A, false };
 			const int nfirst = best ? (int)blockIdx.y : 0, nlast = best ? (int)blockIdx.y + 1 : nneigh;
 			for (int ni = nfirst; ni < nlast; ++ni) {
-				const int v2 = ni == 0 ? n0 : (ni == 1 ? n1 : n2);
+				const int v2 = nl.n[ni];
 				vis.B = &views[v2];
 				walk_curve<true>(ray, A.cam, views[v2], P, vis);
 			}
@@ -547,7 +547,7 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 #define SRH_MVS_WAVES 2
 
 __global__ __launch_bounds__(MQ_T)
-void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
+void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                      int y0, int nrows, const double *__restrict__ tnum, uint32_t *__restrict__ cand, int cmax,
                      int32_t *__restrict__ count,
                      Counters *__restrict__ cnt, int *__restrict__ max_count)
@@ -555,7 +555,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1,
 	__shared__ uint32_t s_q[MQ_QN][MQ_T];
 	__shared__ int s_max;
 	const ViewDev &A = views[ref];
-	const ViewDev &B = views[blockIdx.y == 0 ? n0 : (blockIdx.y == 1 ? n1 : n2)];
+	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w, OH = B.h;
 	const int tid = threadIdx.x;
 	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
@@ -732,7 +732,7 @@ __device__ __noinline__ void mvs_unit_general(const ViewDev &A, const ViewDev &B
 // then needed at once); mvs_combine_kernel merges the neighbours' lists into the caller's buffer.
 template <int R, bool PEAKS>
 __global__ __launch_bounds__(MQ_T, SRH_MVS_WAVES)
-void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, int n1, int n2, srh_params P,
+void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                           int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                           const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
                           double *__restrict__ best, double *__restrict__ upk)
@@ -741,7 +741,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, int n0, in
 	__shared__ double s_w[T][MQ_T];                                 // per-thread columns: conflict-free
 	double a[T];
 	const ViewDev &A = views[ref];
-	const ViewDev &B = views[blockIdx.y == 0 ? n0 : (blockIdx.y == 1 ? n1 : n2)];
+	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w, OH = B.h;
 	const int tid = threadIdx.x;
 	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
@@ -858,8 +858,8 @@ void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
-	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, neigh[0], nneigh > 1 ? neigh[1] : 0,
-	                   nneigh > 2 ? neigh[2] : 0, P, y0, nrows, tnum, cand, cmax, count, cnt, max_count);
+	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
+	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count);
 }
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
@@ -869,12 +869,12 @@ void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const i
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
-	const int n1 = nneigh > 1 ? neigh[1] : 0, n2 = nneigh > 2 ? neigh[2] : 0;
+	const NeighList nl = make_neigh_list(neigh, nneigh);
 	if (peaks)
-		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, neigh[0], n1, n2, P, y0, nrows,
+		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
 		                   wbuf, wstride, cand, cmax, count, best, unit_peaks);
 	else
-		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, neigh[0], n1, n2, P, y0, nrows,
+		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
 		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr);
 	hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, ref, nneigh, y0, nrows, best,
 	                   unit_peaks, peaks, P.top_k);
@@ -914,21 +914,21 @@ void launch_mvs_generic(hipStream_t st, const ViewDev *views, int ref, const int
                         double *peaks, double *best, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
-	const int n0 = nneigh > 0 ? neigh[0] : 0, n1 = nneigh > 1 ? neigh[1] : 0, n2 = nneigh > 2 ? neigh[2] : 0;
-	if (P.window_radius == 2 && !getenv("SRH_MVS_GENERIC")) {
+	const NeighList nl = make_neigh_list(neigh, nneigh);
+	if (P.window_radius == 2) {
 		if (best && !peaks && nneigh > 1) {                         // neighbours side by side + maximum
 			hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128), (unsigned)nneigh), dim3(128), 0, st,
-			                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, best, cnt);
+			                   views, ref, nl, nneigh, P, y0, nrows, wbuf, wstride, peaks, best, cnt);
 			hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
 			                   views, ref, nneigh, y0, nrows, best, (const double *)nullptr, (double *)nullptr, 0);
 			return;
 		}
 		hipLaunchKernelGGL(mvs_reg_kernel<2>, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-		                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, (double *)nullptr, cnt);
+		                   views, ref, nl, nneigh, P, y0, nrows, wbuf, wstride, peaks, (double *)nullptr, cnt);
 		return;
 	}
 	hipLaunchKernelGGL(mvs_generic_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-	                   views, ref, n0, n1, n2, nneigh, P, y0, nrows, wbuf, wstride, peaks, cnt);
+	                   views, ref, nl, nneigh, P, y0, nrows, wbuf, wstride, peaks, cnt);
 }
 
 // MultiViewStereo::crossCheck(view) (multiviewstereo.cpp:666-729)

@@ -371,9 +371,9 @@ bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int
 	const dim3 grid((unsigned)(tiles*nrows));
 #define SRH_LC_LAUNCH(RR)                                                                                   \
 	{                                                                                                       \
-		static bool attr = false;                                                                           \
-		if (!attr) { (void)hipFuncSetAttribute((const void *)twoview_list_cost_kernel<RR>,                  \
-		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ListSmem<RR>)); attr = true; } \
+		/* per device, hence on every launch */                                                             \
+		(void)hipFuncSetAttribute((const void *)twoview_list_cost_kernel<RR>,                                                \
+		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ListSmem<RR>));                  \
 		hipLaunchKernelGGL(twoview_list_cost_kernel<RR>, grid, dim3(LC_THREADS), sizeof(ListSmem<RR>), st,  \
 		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, count, cand, cost, cmax, cnt);    \
 		return true;                                                                                        \

@@ -488,9 +488,9 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 	const dim3 grid((unsigned)(tiles*nrows));
 #define SRH_RC_LAUNCH(RR)                                                                                   \
 	{                                                                                                       \
-		static bool attr = false;                                                                           \
-		if (!attr) { (void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR>,                  \
-		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>)); attr = true; } \
+		/* per device, hence on every launch */                                                             \
+		(void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR>,                                                \
+		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>));                  \
 		hipLaunchKernelGGL(twoview_rows_cost_kernel<RR>, grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
 		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt);  \
 		return true;                                                                                        \

@@ -39,29 +39,36 @@ def all_gather_depth_maps(local):
 class HipMultiViewEngine:
     """The per-rank side of multiview_sharded() on a GPU: one srh_context holding all views
     (images and cameras are replicated -- a few MB -- so that every rank can match its own views
-    against any neighbour), depth maps exchanged as device tensors."""
+    against any neighbour), depth maps exchanged as device tensors.  Views may differ in raster size
+    (MultiViewStereo keeps one VectorImage per view, multiviewstereo.cpp:216-244): maps travel
+    flattened and padded with NaN to the largest view, `shape` is that common (1-D) exchange shape."""
 
     def __init__(self, ctx, slots, neighbours, params, device):
         self.ctx, self.slots, self.neigh, self.p, self.device = ctx, list(slots), neighbours, params, device
-        w, h = ctx.view_size(self.slots[0])
-        self.shape = (h, w)
+        self.sizes = [ctx.view_size(s) for s in self.slots]     # (w, h) per view
+        self.shape = (max(w * h for (w, h) in self.sizes),)
 
     def initial_estimate(self, v):
         self.ctx.mvs_initial_estimate(self.slots[v], [self.slots[n] for n in self.neigh[v]], self.p)
 
     def depth_tensor(self, v):
+        w, h = self.sizes[v]
         if torch.device(self.device).type == "cpu":             # host exchange (gloo rehearsal of the N>1 path)
-            return torch.from_numpy(self.ctx.download_depth(self.slots[v]))
-        t = torch.empty(self.shape, dtype=torch.float64, device=self.device)
-        self.ctx.copy_depth_to_device(self.slots[v], t.data_ptr())
+            t = torch.full(self.shape, float("nan"), dtype=torch.float64)
+            t[:w * h] = torch.from_numpy(self.ctx.download_depth(self.slots[v])).reshape(-1)
+            return t
+        t = torch.full(self.shape, float("nan"), dtype=torch.float64, device=self.device)
+        self.fence()                                             # the fill runs on torch's stream, the copy on the library's
+        self.ctx.copy_depth_to_device(self.slots[v], t.data_ptr(), t.numel() * 8)
         return t
 
     def set_depth(self, v, t):
         assert t.is_contiguous() and t.dtype == torch.float64 and tuple(t.shape) == self.shape
+        w, h = self.sizes[v]
         if t.device.type == "cpu":
-            self.ctx.upload_depth(self.slots[v], t.numpy())
+            self.ctx.upload_depth(self.slots[v], t[:w * h].reshape(h, w).numpy())
         else:
-            self.ctx.copy_depth_from_device(self.slots[v], t.data_ptr())
+            self.ctx.copy_depth_from_device(self.slots[v], t.data_ptr(), t.numel() * 8)
 
     def cross_check(self, v):
         self.ctx.mvs_cross_check(self.slots, v, self.p)
