@@ -134,6 +134,9 @@ int  srh_synchronize(srh_context *ctx);
 /* Tuning / test switches (results never depend on them):
  *   "force_generic"   0 default paths; 1 never the dense row-aligned TwoView kernels nor the MVS list kernels;
  *                     2 additionally no candidate lists at all (one thread per pixel walks and costs its curve)
+ *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
+ *                     not only for rigs the host check accepts (the device verifies every candidate and the
+ *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
  *   "band_budget_mb"  device scratch per row band (default 8192) */
 int  srh_set_option(srh_context *ctx, const char *name, long value);

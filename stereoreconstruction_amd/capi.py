@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstereo_recon_hip.so")
+# SRH_LIBRARY names another build of the same library (the -DSRH_PROFILE_PHASES diagnostic build)
+LIB_PATH = os.environ.get("SRH_LIBRARY") or os.path.join(_HERE, "libstereo_recon_hip.so")
 
 SRH_OK = 0
 SRH_E_INVALID, SRH_E_DEVICE, SRH_E_NO_DEVICE, SRH_E_CANCELLED, SRH_E_UNSUPPORTED = -1, -2, -3, -4, -5

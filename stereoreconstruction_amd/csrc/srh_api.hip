@@ -82,6 +82,7 @@ struct srh_context {
 	void *user = nullptr;
 	bool profiling = false;
 	bool force_generic = false;
+	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
 	srh_stats stats;
@@ -433,6 +434,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
 	if (!strcmp(name, "list_rows")) { c->list_rows = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
+	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
@@ -624,7 +626,12 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 	bool dense = !c->force_generic && (R == 5 || R == 2);
 	int cstride = 0;
 	double fx_bx = 0;
-	if (dense && !rig_is_row_aligned(L.cam, Rv.cam, &fx_bx)) dense = false;
+	if (dense && !rig_is_row_aligned(L.cam, Rv.cam, &fx_bx)) {
+		// test hook: any pinhole pair may be *proposed* (the scan kernel refutes the proposal, see the redo below)
+		const bool pinhole = !L.cam.is_distorted && !Rv.cam.is_distorted && !L.cam.is_refractive && !Rv.cam.is_refractive;
+		if (c->force_dense && pinhole) fx_bx = (double)(W + 8)/(p->image_scale*fabs(1.0/p->min_depth - 1.0/p->max_depth));
+		else dense = false;
+	}
 	if (dense) {
 		// widest candidate range a pixel can have: disparity(min_depth) - disparity(max_depth) + margins
 		const double span = fx_bx*p->image_scale*fabs(1.0/p->min_depth - 1.0/p->max_depth);

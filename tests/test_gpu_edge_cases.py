@@ -150,3 +150,64 @@ def test_rccl_exchange_single_rank(hip_ctx):
         hip_ctx.comm_destroy()
     with pytest.raises(capi.StereoHipError):
         hip_ctx.comm_allgather_depth(0, 1)                          # no communicator any more
+
+
+def _twoview_vs_oracle(ctx, case, expect_dense):
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(ctx, case, cams)
+    for ref, oth in ((0, 1), (1, 0)):
+        want = O.twoview_wta(imgs[ref], imgs[oth], ocams[ref], ocams[oth], op)
+        ctx.twoview_wta(ref, oth, p)
+        assert bool(ctx.stats()["used_dense_path"]) == expect_dense
+        ok, msg, _ = cases.compare_depth(ctx.download_depth(ref), want, 1e-9)
+        assert ok, (ref, msg)
+
+
+def test_dense_plan_refuted_on_device_is_redone_on_the_general_kernels(hip_ctx):
+    """srh_twoview_wta proposes the dense row-aligned plan from a host-side rig check and lets the scan kernel
+    verify every candidate; a candidate off its row makes the host redo the pass on the general kernels
+    (srh_api.hip, `not_row_aligned`).  The host check is strict enough that no real rig reaches the redo, so the
+    plan is forced ("force_dense") on a verged pinhole pair: the result must still equal the oracle."""
+    case = cases.get_twoview("adaptive_verged", w=72, h=44, D=20, radius=5)
+    hip_ctx.set_option("force_dense", 1)
+    try:
+        _twoview_vs_oracle(hip_ctx, case, expect_dense=False)
+    finally:
+        hip_ctx.set_option("force_dense", 0)
+    # and the same rig with the option off never tries the dense plan
+    _twoview_vs_oracle(hip_ctx, case, expect_dense=False)
+
+
+@pytest.mark.parametrize("zmin,dense", [(64.0 / 300.0, True), (64.0 / 5000.0, False)],
+                         ids=["span_wider_than_the_image", "span_4096_or_more"])
+def test_dense_plan_span_limits(hip_ctx, zmin, dense):
+    """Candidate ranges wider than the image clamp the cost-row stride to W+8 (still the dense kernels);
+    a nominal span of 4096 columns or more is left to the general kernels (srh_api.hip plan)."""
+    case = cases.get_twoview("geodesic_rect", w=64, h=36, D=24)
+    case["params"]["min_depth"] = zmin
+    _twoview_vs_oracle(hip_ctx, case, expect_dense=dense)
+
+
+def test_mvs_more_than_three_neighbours(hip_ctx):
+    """num_neighbours is a run-time parameter (the reference's NUM_NEIGHBOURING_VIEWS = 3 is a constant,
+    multiviewstereo.cpp:97): four neighbours per view on both MVS paths, against the oracle."""
+    case = cases.get_mvs("mvs_five_views")
+    case["params"]["num_neighbours"] = 4
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    neigh = O.mvs_neighbours(ocams, op)
+    assert [list(map(int, n)) for n in capi.mvs_neighbours(cams, p)] == [list(map(int, n)) for n in neigh]
+    assert max(len(n) for n in neigh) == 4
+    for v in (0, 2):
+        want, n_eval = O.mvs_initial_estimate(imgs, ocams, v, neigh[v], op)
+        for generic in (0, 1):
+            hip_ctx.set_option("force_generic", generic)
+            try:
+                hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+            finally:
+                hip_ctx.set_option("force_generic", 0)
+            ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(v), want, 1e-9)
+            assert ok, (v, generic, msg)
+            assert hip_ctx.stats()["n_eval"] == n_eval

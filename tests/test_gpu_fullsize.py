@@ -154,3 +154,96 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
     for v in range(NV):
         hip_ctx.mvs_cross_check(list(range(NV)), v, p)
     assert np.isnan(hip_ctx.download_depth(0)[masks[0] == 1]).any()   # the cross-check rejects something
+
+
+def test_c4_full_size(hip_ctx):
+    """C4 at BASELINE size: 8 views 1280x960, 128 uniform levels, r=2, 3 neighbours.  Two-stage kernels ==
+    inline kernel bit for bit (also across a band split); one full-width row PER VIEW against the oracle; the
+    ordered cross-check chain of all 8 views against the oracle's chain run on the same initial maps."""
+    W, H, D, NV = 1280, 960, 128, 8
+    cams3 = synthetic.semicircle_rig(NV, W, H, radius=10.0, step_deg=22.5, focal=float(W))
+    rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, 0x5EED0004, sphere_radius=2.0, tex_size=1024)
+    cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
+    kw = dict(min_depth=8.0, max_depth=12.0, num_depth_levels=D, cross_check_threshold=2 * 4.0 / (D - 1))
+    p = capi.params_mvs(**kw)
+    neigh = capi.mvs_neighbours(cams, p)
+    assert all(len(n) == 3 for n in neigh)
+    for v in range(NV):
+        hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
+    res = {}
+    for tag, generic, budget in (("two_stage", 0, 8192), ("two_stage_bands", 0, 256), ("inline", 1, 8192)):
+        hip_ctx.set_option("force_generic", generic)
+        hip_ctx.set_option("band_budget_mb", budget)
+        maps, evals = [], []
+        for v in range(NV):
+            hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+            maps.append(hip_ctx.download_depth(v))
+            evals.append(hip_ctx.stats()["n_eval"])
+        res[tag] = (maps, evals)
+    hip_ctx.set_option("force_generic", 0)
+    hip_ctx.set_option("band_budget_mb", 8192)
+    for v in range(NV):
+        for tag in ("two_stage_bands", "inline"):
+            assert _same_bits(res["two_stage"][0][v], res[tag][0][v]), (tag, v)
+            assert res["two_stage"][1][v] == res[tag][1][v], (tag, v)
+    ocams = [O.camera_set(K, R, t) for (K, R, t) in cams3]
+    op = O.params_mvs(**kw)
+    imgs = [O.OImage(rgba[v], masks[v]) for v in range(NV)]
+    for v in range(NV):
+        y = H // 2 + 7 * (v - NV // 2)
+        want, _ = O.mvs_initial_estimate(imgs, ocams, v, neigh[v], op, y, y + 1)
+        ok, msg, _ = _cmp(res["two_stage"][0][v][y], want[y])
+        assert ok, (v, y, msg)
+    # cross-check chain (multiviewstereo.cpp:427-431): the oracle starts from the device's initial maps
+    work = [m.copy() for m in res["two_stage"][0]]
+    for v in range(NV):
+        O.mvs_cross_check(imgs, ocams, v, op, work)
+    for v in range(NV):                                              # the maps of the last mode ("inline") are resident
+        hip_ctx.mvs_cross_check(list(range(NV)), v, p)
+    for v in range(NV):
+        ok, msg, _ = _cmp(hip_ctx.download_depth(v), work[v])
+        assert ok, (v, msg)
+    assert np.isnan(work[0][masks[0] == 1]).any()
+
+
+def _cmp(got, want):
+    import cases
+    return cases.compare_depth(got, want, 1e-9)
+
+
+@pytest.mark.parametrize("seed", [0x5EED0050, 0x5EED0057])
+def test_c5_full_size(hip_ctx, seed):
+    """C5 at BASELINE size (1920x1080, 256 levels, refractive interface), first and last pair seed of SURVEY 8(d):
+    row-run evaluation == list-order evaluation bit for bit (both directions), n_eval equal; one full-width row
+    per direction against the oracle."""
+    W, H, D = 1920, 1080, 256
+    L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, seed)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    plane = (np.array([0.0, 0.0, 1.0]), 0.1, 1.333)
+    hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl, None, *plane))
+    hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr, None, *plane))
+    kw = dict(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
+    p = capi.params_twoview(**kw)
+    res = {}
+    for tag, rows in (("rows", 1), ("ordered", 0)):
+        hip_ctx.set_option("list_rows", rows)
+        out = []
+        for ref, oth in ((0, 1), (1, 0)):
+            hip_ctx.twoview_wta(ref, oth, p)
+            st = hip_ctx.stats()
+            assert not st["used_dense_path"]
+            out.append((hip_ctx.download_depth(ref), st["n_eval"]))
+        res[tag] = out
+    hip_ctx.set_option("list_rows", 1)
+    for k in range(2):
+        assert _same_bits(res["rows"][k][0], res["ordered"][k][0]), k
+        assert res["rows"][k][1] == res["ordered"][k][1]
+        assert np.isfinite(res["rows"][k][0]).mean() > 0.2
+    op = O.params_twoview(**kw)
+    oc = [O.camera_set(Kl, Rl, tl, None, *plane), O.camera_set(Kr, Rr, tr, None, *plane)]
+    oi = [O.OImage(L, ml), O.OImage(R, mr)]
+    for ref, oth, y in ((0, 1, H // 2), (1, 0, H // 3)):
+        want = O.twoview_wta(oi[ref], oi[oth], oc[ref], oc[oth], op, y, y + 1)
+        ok, msg, _ = _cmp(res["rows"][ref][0][y], want[y])
+        assert ok, (ref, y, msg)
