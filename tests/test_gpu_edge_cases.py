@@ -37,7 +37,7 @@ def test_argument_validation(hip_ctx):
     with pytest.raises(capi.StereoHipError):
         hip_ctx.mvs_initial_estimate(0, [0], capi.params_mvs())      # own neighbour
     with pytest.raises(capi.StereoHipError) as e:
-        hip_ctx.mvs_initial_estimate(0, [1, 2, 1, 2], capi.params_mvs())
+        hip_ctx.mvs_initial_estimate(0, [1, 2] * 5, capi.params_mvs())   # more than SRH_MAX_NEIGH = 8
     assert e.value.code == capi.SRH_E_UNSUPPORTED
 
 
