@@ -88,8 +88,8 @@ typedef struct srh_stats {
 	int64_t n_pixels;        /* reference pixels with mask == WHITE */
 	int64_t n_eval;          /* cost evaluations the reference would have performed */
 	int64_t n_eval_device;   /* cost evaluations actually performed on the device */
-	int32_t used_dense_path; /* 1 if the row-aligned dense kernel ran */
-	int32_t reserved;
+	int32_t used_dense_path; /* 1 if the row-aligned dense kernels ran */
+	int32_t used_fused_kernel; /* 1 if that was the single fused kernel (cost rows never leave the CU) */
 } srh_stats;
 
 typedef struct srh_context srh_context;
@@ -134,6 +134,8 @@ int  srh_synchronize(srh_context *ctx);
 /* Tuning / test switches (results never depend on them):
  *   "force_generic"   0 default paths; 1 never the dense row-aligned TwoView kernels nor the MVS list kernels;
  *                     2 additionally no candidate lists at all (one thread per pixel walks and costs its curve)
+ *   "fused"           1 (default) row-aligned pairs run the single fused kernel (geometry + cost + WTA per tile in
+ *                     LDS); 0: the three-kernel form (cost rows staged in device memory, separate scan)
  *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
  *                     not only for rigs the host check accepts (the device verifies every candidate and the
  *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)

@@ -56,7 +56,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     """srh_stats"""
     _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
-                ("used_dense_path", C.c_int32), ("reserved", C.c_int32)]
+                ("used_dense_path", C.c_int32), ("used_fused_kernel", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
@@ -371,7 +371,7 @@ class Context:
         s = Stats()
         _check(lib().srh_get_stats(self._h, C.byref(s)))
         return dict(n_pixels=s.n_pixels, n_eval=s.n_eval, n_eval_device=s.n_eval_device,
-                    used_dense_path=bool(s.used_dense_path))
+                    used_dense_path=bool(s.used_dense_path), used_fused_kernel=bool(s.used_fused_kernel))
 
     def profile_enable(self, on=True):
         _check(lib().srh_profile_enable(self._h, int(on)))

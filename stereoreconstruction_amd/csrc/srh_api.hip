@@ -82,10 +82,12 @@ struct srh_context {
 	void *user = nullptr;
 	bool profiling = false;
 	bool force_generic = false;
+ 	bool use_fused = true;                              // option "fused": single fused kernel for row-aligned pairs
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
 	srh_stats stats;
+	bool last_fused = false;                            // the last TwoView pass ran the fused kernel
 };
 
 static bool cancelled(srh_context *c) { return c->cancel && *c->cancel; }
@@ -434,6 +436,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
 	if (!strcmp(name, "list_rows")) { c->list_rows = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
+	if (!strcmp(name, "fused")) { c->use_fused = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
@@ -562,6 +565,7 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.n_eval = (int64_t)h.n_eval;
 	c->stats.n_eval_device = (int64_t)h.n_eval_device;
 	c->stats.used_dense_path = used_dense;
+	c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 #ifdef SRH_PROFILE_PHASES
 	if (h.dbg_waves)
 		fprintf(stderr, "[srh dbg] dense: waves %llu, cycles/wave %.0f, fast blocks/wave %.1f, cycles/fast block %.0f\n",
@@ -638,6 +642,40 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		if (!(p->min_depth > 0) || !(p->max_depth > 0) || !(span < 4096.0)) dense = false;
 		else cstride = (((int)ceil(span) + 3) + 7) & ~7;
 		if (cstride > W + 8) cstride = (W + 8 + 7) & ~7;
+	}
+
+	c->last_fused = false;
+	// ---- row-aligned rig whose candidate range fits an LDS cost row: one fused kernel per band (srh_fused.hip)
+	if (dense && c->use_fused && p->num_depth_levels <= SRH_FUSED_MAXC &&
+	    fx_bx*p->image_scale*fabs(1.0/p->min_depth - 1.0/p->max_depth) + 1.0 <= (double)SRH_FUSED_MAXC) {
+		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+		if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
+		{ Scope s(c, "pinhole_label_table_kernel");
+		  launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum); }
+		size_t rows = c->wbuf_budget / ((size_t)T*sizeof(double)*(size_t)W);
+		if (rows < 1) rows = 1;
+		if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
+		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
+		bool launched = true;
+		for (int by = y0; by < y1 && launched; by += (int)rows) {
+			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+			const int nr = std::min((int)rows, y1 - by);
+			run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+			Scope s(c, "twoview_fused_kernel");
+			launched = launch_twoview_fused(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, c->tnum, c->d_cnt);
+		}
+		HIP_TRY(hipGetLastError());
+		if (launched) {
+			// the result stands only if every curve was monotone, on its row and inside the LDS tile
+			Counters hc;
+			HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (hc.not_row_aligned == 0) {
+				c->stats.used_dense_path = 1;
+				c->last_fused = true;
+				return SRH_OK;
+			}
+		}
 	}
 
 	for (int attempt = 0; attempt < 2; ++attempt) {

@@ -91,6 +91,12 @@ void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          const double *wbuf, size_t wstride, Counters *cnt);
 
+// Fused row-aligned TwoView kernel (geometry + cost + WTA per 16-pixel tile), srh_fused.hip.
+// SRH_FUSED_MAXC: cost-row columns (and labels) a pixel may have in LDS.
+#define SRH_FUSED_MAXC 256
+bool launch_twoview_fused(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                          int y0, int nrows, const double *wbuf, const double *tnum, Counters *cnt);
+
 // Candidate-list TwoView path for arbitrary geometry, srh_list.hip
 void launch_twoview_count(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                           int y0, int nrows, int32_t *count, Counters *cnt, int *max_count);
