@@ -277,6 +277,9 @@ def main():
 
     ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for opt in ("fused",):                     # tuning knobs (timing only / path choice; results are identical)
+        if os.environ.get("SRH_BENCH_" + opt.upper()):
+            ctx.set_option(opt, int(os.environ["SRH_BENCH_" + opt.upper()]))
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
     # Depth hand-over: both maps are copied device-to-device into a staging tensor; with N > 1 ranks they are

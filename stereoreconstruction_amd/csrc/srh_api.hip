@@ -567,15 +567,24 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.used_dense_path = used_dense;
 	c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 #ifdef SRH_PROFILE_PHASES
-	if (h.dbg_waves)
+	if (h.dbg_waves && !c->last_fused)
 		fprintf(stderr, "[srh dbg] dense: waves %llu, cycles/wave %.0f, fast blocks/wave %.1f, cycles/fast block %.0f\n",
 		        h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_blocks/h.dbg_waves,
 		        h.dbg_blocks ? (double)h.dbg_cycles/h.dbg_blocks : 0.0);
-	if (h.dbg_waves)
+	if (h.dbg_waves && !c->last_fused)
 		fprintf(stderr, "[srh dbg] phases/wave: stage_w %.0f prologue %.0f sync %.0f stage_rt %.0f compute %.0f tail %.0f\n",
 		        (double)h.dbg_phase[0]/h.dbg_waves, (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
 		        (double)h.dbg_phase[3]/h.dbg_waves, (double)h.dbg_phase[4]/h.dbg_waves, (double)h.dbg_phase[5]/h.dbg_waves);
-	if (h.dbg_phase[6])
+	if (h.dbg_waves && c->last_fused)
+		fprintf(stderr, "[srh dbg] fused: %llu tiles, %llu with select-form work, %llu pixels with an unusable tap of their own\n",
+		        h.dbg_waves, h.n_listed, h.n_slots);
+	if (h.dbg_waves && c->last_fused)
+		fprintf(stderr, "[srh dbg] fused, role wave cycles/tile: A geometry %.0f  B accept %.0f  C stage %.0f  D prologue %.0f  E1 blocks %.0f  E2 general %.0f  F wta %.0f  barriers %.0f | other waves: blocks %.0f barriers %.0f total %.0f\n",
+		        (double)h.dbg_phase[0]/h.dbg_waves, (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
+		        (double)h.dbg_phase[3]/h.dbg_waves, (double)h.dbg_phase[4]/h.dbg_waves, (double)h.dbg_phase[5]/h.dbg_waves,
+		        (double)h.dbg_phase[6]/h.dbg_waves, (double)h.dbg_phase[7]/h.dbg_waves,
+		        (double)h.dbg_cycles/(3.0*h.dbg_waves), (double)h.dbg_blocks/(3.0*h.dbg_waves), (double)h.dbg_total_cycles/(3.0*h.dbg_waves));
+	if (h.dbg_phase[6] && !c->last_fused)
 		fprintf(stderr, "[srh dbg] rows: tasks %llu fast %llu, rows/pixel %.2f, slots/px %.1f, wave iterations %llu all-fast %llu\n",
 		        h.dbg_phase[6], h.dbg_phase[7], (double)h.dbg_cycles/(double)h.n_pixels, 8.0*h.dbg_phase[6]/(double)h.n_pixels,
 		        h.dbg_blocks, h.dbg_total_cycles);

@@ -25,6 +25,8 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
+#include <cstdio>
+
 namespace srh {
 
 #define FZ_TP 16
@@ -50,7 +52,8 @@ struct FusedSmem {
 	int lall[FZ_TP];
 	int k0[FZ_TP], dir[FZ_TP], ilast[FZ_TP], nmerge[FZ_TP]; // first kept column, +1/-1, highest joint index, merged joints
 	int corg[FZ_TP], ca[FZ_TP], cb[FZ_TP];                  // cost-row origin (even), visited in-image column range (empty: cb < ca)
-	int pflag[FZ_TP];
+	int pflag[FZ_TP], firstd[FZ_TP];                        // row/monotony flags, first label with a projection
+	unsigned short kept[FZ_TP][MAXC/16];                    // phase B: bit k of kept[p][b]: label 16b+k is a kept point
 	unsigned joints[FZ_TP][JW];                             // bit i: a kept point (not the first) at column k0 + dir*i
 	unsigned char rfull[RW], colok[RW], mrow[RW];
 	static constexpr int GL_CAP = 1024;
@@ -131,30 +134,90 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 	constexpr int WS = Smem::WS, T = Smem::T, WP = Smem::WP;
 	constexpr int NCB = FZ_NCB;
 	constexpr int NR = NCB + 2*R;                             // other-view values a block needs per row (even)
+	constexpr int JW = Smem::JW;
 	static_assert(NR % 2 == 0 && WP % 2 == 0 && Smem::RW % 2 == 0 && WS % 2 == 1, "16-byte LDS rows");
+	static_assert(MAXC == FZ_G*16, "phase F: every lane of a pixel owns 16 positions of the visiting order");
 	extern __shared__ __align__(16) unsigned char smem_raw[];
 	Smem &S = *reinterpret_cast<Smem *>(smem_raw);
 
-	const ViewDev &L = views[ref];
-	const ViewDev &Rv = views[oth];
-	const int W = L.w, H = L.h, OW = Rv.w, OH = Rv.h;
+	const int W = views[ref].w, H = views[ref].h, OW = views[oth].w, OH = views[oth].h;
 	const int D = P.num_depth_levels;
 	const int tiles_per_row = (W + FZ_TP - 1)/FZ_TP;
-	const int trow = blockIdx.x / tiles_per_row;
-	const int x0 = (blockIdx.x % tiles_per_row)*FZ_TP;
-	const int y = y0 + trow;
-	const int tid = threadIdx.x;
+	const int ntiles = tiles_per_row*nrows;
+	const double nan = __builtin_nan("");
+	const double inf = __builtin_inf();
+
+#ifdef SRH_PROFILE_PHASES
+	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long tp = __builtin_readcyclecounter();
+#define FZ_STAMP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define FZ_STAMP(k) do { } while (0)
+#endif
+	// Everything but the block loops of phase E is latency-bound bookkeeping with few busy lanes.  A workgroup
+	// shares its SIMDs with another one that is usually deep in its FP64 loops; the hardware favours the older
+	// wave, which would starve these dependent chains (measured: 560 cycles per label in phase B).  They run at
+	// raised priority -- they leave almost every issue slot free anyway.
+	// A workgroup takes every gridDim.x-th tile (the launch uses one workgroup per tile: a persistent grid of two
+	// workgroups per CU, with or without a start offset between them, measured 8 % slower on MI355X).
+	unsigned long long n_eval = 0, n_pix = 0, n_dev = 0;
+	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	// the view table is re-read in every tile: camera matrices hoisted out of this loop would be held in
+	// registers across all phases (the compiler did so, and spilled)
+	// ... and so would every per-lane LDS address: the thread index is laundered once per tile
+	const ViewDev *vt = views;
+	asm volatile("" : "+s"(vt));
+	int tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
 	const int lane = tid & 63, wave = tid >> 6;
 	const int p = wave*4 + (lane & 3);                        // pixel within the tile (pixel-fastest inside a wave)
 	const int g = lane >> 2;                                  // lane within the pixel
-	const int x = x0 + p;
-	const int role = 0;                                       // the wave that runs the per-pixel sequential phases
-	const bool seq = wave == role && lane < FZ_TP;            // ... with lane = pixel q
+	// the two per-pixel sequential phases run side by side on two waves, one lane per pixel
+	const bool seqB = wave == 0 && lane < FZ_TP;              // B: which labels are kept
+	const bool seqD = wave == 1 && lane < FZ_TP;              // D: constants of the fast cost form
 	const int q = lane;
-	const double nan = __builtin_nan("");
-
+	const ViewDev &L = vt[ref];
+	const ViewDev &Rv = vt[oth];
+	const int trow = tile / tiles_per_row;
+	const int x0 = (tile % tiles_per_row)*FZ_TP;
+	const int y = y0 + trow;
+	const int x = x0 + p;
+	__builtin_amdgcn_s_setprio(3);
 	if (tid == 0) { S.glist_n = 0; S.cmin = 2147483647; S.cmax = -2147483647; S.need_general = 0; S.bad = 0; }
-	if (tid < FZ_TP) S.pflag[tid] = 0;
+	if (tid < FZ_TP) { S.pflag[tid] = 0; S.firstd[tid] = 2147483647; S.ilast[tid] = -1; S.nmerge[tid] = 0; }
+	for (int j = tid; j < FZ_TP*JW; j += FZ_THREADS) S.joints[j / JW][j % JW] = 0;
+
+	// ---- support windows and reference rows of the tile (wbuf is tile-major per 32 pixels, [tap][32]).
+	// Every global load of the thread is issued before the first LDS store: one memory latency for the lot.
+	{
+		const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
+		constexpr int NBW = (T*FZ_TP + FZ_THREADS - 1)/FZ_THREADS, NBL = (WS*Smem::LW + FZ_THREADS - 1)/FZ_THREADS;
+		double tw_[NBW], tl_[NBL];
+#pragma unroll
+		for (int k = 0; k < NBW; ++k) {
+			const int idx = tid + k*FZ_THREADS;
+			const int t = idx / FZ_TP, pi = idx % FZ_TP;
+			tw_[k] = (idx < T*FZ_TP && x0 + pi < W) ? wtile[(size_t)t*SRH_WTILE + pi] : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < NBL; ++k) {
+			const int idx = tid + k*FZ_THREADS;
+			const int ty = idx / Smem::LW, tx = idx % Smem::LW;
+			const int gx = x0 - R + tx, gy = y - R + ty;
+			tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
+		}
+#pragma unroll
+		for (int k = 0; k < NBW; ++k) {
+			const int idx = tid + k*FZ_THREADS;
+			const int t = idx / FZ_TP, pi = idx % FZ_TP;
+			if (idx < T*FZ_TP) S.w[pi][(t / WS)*WP + (t % WS)] = tw_[k];
+		}
+#pragma unroll
+		for (int k = 0; k < NBL; ++k) {
+			const int idx = tid + k*FZ_THREADS;
+			if (idx < WS*Smem::LW) S.lt[idx / Smem::LW][idx % Smem::LW] = tl_[k];
+		}
+	}
 	__syncthreads();
 
 	// ---- A: projections of all labels (every lane of a pixel holds the same ray)
@@ -166,12 +229,14 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 			nd = dot(normalized(load3(L.cam.pdir)), ray.dir);
 			hasray = !(fabs(nd) < 1e-10);                         // intersect() fails for every label otherwise
 		}
-		int yflag = 0;
+		int yflag = 0, fd = 2147483647;
+		double tcur = g < D ? tnum[g] : 0.0;
 		for (int d = g; d < D; d += FZ_G) {
+			const double tnext = d + FZ_G < D ? tnum[d + FZ_G] : 0.0;   // one label ahead: the load is never waited for
 			double xv = nan;
 			if (hasray) {
 				double x2, y2;
-				if (pinhole_project_label(ray, nd, tnum[d], Rv.cam, P.image_scale, x2, y2)) {
+				if (pinhole_project_label(ray, nd, tcur, Rv.cam, P.image_scale, x2, y2)) {
 					xv = x2;
 					// Row alignment, and exactness of phase B's test: with |y2 - (y+0.5)| < 2^-28 for every label,
 					// trunc(y2) == y and (dy*dy < 2^-54), so fl(dx*dx + dy*dy) >= 1  <=>  fl(dx*dx) >= 1.
@@ -179,37 +244,146 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 				}
 			}
 			S.cost[Smem::slot(p, d)] = xv;
+			if (xv == xv && fd == 2147483647) fd = d;
+			tcur = tnext;
 		}
 		if (yflag) atomicOr(&S.pflag[p], 1);
+		if (fd != 2147483647) atomicMin(&S.firstd[p], fd);
+	}
+	FZ_STAMP(0);
+	__syncthreads();
+	FZ_STAMP(7);
+
+	// ---- B1 (wave 0): which labels are kept (twoviewstereo.cpp:1018-1052), one lane per pixel.  Only the decision
+	// chain is sequential: x1 = first projected label; a label is kept when |x2 - x1| >= 1 (== fl(dx*dx) >= 1, and
+	// dy does not matter, see phase A), then x1 = x2.  A NaN x2 (label without a projection) is never kept.  The x2
+	// values come from LDS 16 at a time, one batch ahead; the chain itself runs on registers.
+	if (seqB) {
+		const int fd = S.firstd[q];
+		double x1 = fd != 2147483647 ? S.cost[Smem::slot(q, fd)] : nan;
+		double xa[16], xb[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) xa[k] = k < D ? S.cost[Smem::slot(q, k)] : nan;
+		for (int d0 = 0; d0 < D; d0 += 32) {
+#pragma unroll
+			for (int k = 0; k < 16; ++k) xb[k] = d0 + 16 + k < D ? S.cost[Smem::slot(q, d0 + 16 + k)] : nan;
+			unsigned bits = 0;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				const bool acc = fabs(xa[k] - x1) >= 1.0;
+				x1 = acc ? xa[k] : x1;
+				bits |= acc ? (1u << k) : 0u;
+			}
+			S.kept[q][d0 >> 4] = (unsigned short)bits;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) xa[k] = d0 + 32 + k < D ? S.cost[Smem::slot(q, d0 + 32 + k)] : nan;
+			bits = 0;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				const bool acc = fabs(xb[k] - x1) >= 1.0;
+				x1 = acc ? xb[k] : x1;
+				bits |= acc ? (1u << k) : 0u;
+			}
+			if (d0 + 16 < MAXC) S.kept[q][(d0 >> 4) + 1] = (unsigned short)bits;
+		}
+		for (int b2 = (D + 31)/32*2; b2 < MAXC/16; ++b2) S.kept[q][b2] = 0;
+	}
+	// ---- D (wave 1, meanwhile): per-pixel constants of the fast form -- meanL, totalWeight, sum2 do not depend on
+	// the candidate when every tap of the window is usable on both sides (same tap order as twoviewstereo.cpp:917-976)
+	if (seqD) {
+		bool all = (x0 + q < W);
+		double mL = 0, tw = 0;
+#pragma unroll 1
+		for (int row = 0; row < WS; ++row) {
+			double gl[WS], wt[WS];
+#pragma unroll
+			for (int col = 0; col < WS; ++col) { gl[col] = S.lt[row][q + col]; wt[col] = S.w[q][row*WP + col]; }
+#pragma unroll
+			for (int col = 0; col < WS; ++col) {
+				if (!(gl[col] == gl[col] && wt[col] > P.weight_cutoff)) all = false;
+				mL += wt[col]*gl[col];
+				tw += wt[col];
+			}
+		}
+		double s2 = 0;
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+#pragma unroll 1
+			for (int row = 0; row < WS; ++row) {
+				double gl[WS], wt[WS];
+#pragma unroll
+				for (int col = 0; col < WS; ++col) { gl[col] = S.lt[row][q + col]; wt[col] = S.w[q][row*WP + col]; }
+#pragma unroll
+				for (int col = 0; col < WS; ++col) { const double a = wt[col]*gl[col] - mL; s2 += a*a; }
+			}
+		} else all = false;
+		S.meanL[q] = mL; S.totalW[q] = tw; S.sum2[q] = s2; S.lall[q] = all ? 1 : 0;
+	}
+	FZ_STAMP(1);
+	__syncthreads();
+	FZ_STAMP(7);
+
+	// ---- B2 (all lanes, lane g of a pixel takes labels 16g..16g+15): from the kept flags, the geometry of the
+	// curve -- first kept column K0, direction, index i = (K - K0)*dir of every later kept point (a joint bit),
+	// monotony, kept points that truncate to the same column.
+	{
+		const int fd = S.firstd[p];
+		unsigned km[MAXC/16];
+#pragma unroll
+		for (int b2 = 0; b2 < MAXC/16; ++b2) km[b2] = S.kept[p][b2];
+		int firstk = -1, prevk = -1;                              // first kept label after fd; last kept label before my chunk
+#pragma unroll
+		for (int b2 = MAXC/16 - 1; b2 >= 0; --b2) if (km[b2]) firstk = 16*b2 + __ffs((int)km[b2]) - 1;
+#pragma unroll
+		for (int b2 = 0; b2 < MAXC/16; ++b2) if (b2 < g && km[b2]) prevk = 16*b2 + 31 - __clz((int)km[b2]);
+		unsigned mine = 0;
+#pragma unroll
+		for (int b2 = 0; b2 < MAXC/16; ++b2) if (b2 == g) mine = km[b2];
+		if (firstk >= 0) {
+			const double xf = S.cost[Smem::slot(p, fd)];
+			const int K0 = trunc_sat(xf);
+			const int sgn = S.cost[Smem::slot(p, firstk)] > xf ? 1 : -1;
+			if (g == 0) { S.k0[p] = K0; S.dir[p] = sgn; }
+			int il = -1, nm = 0, flag = 0;
+			// my 16 projections and the predecessor of my first kept label, fetched at once; the loop runs on registers
+			double xs[16];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) xs[k] = S.cost[Smem::slot(p, 16*g + k)];
+			double xp = S.cost[Smem::slot(p, prevk >= 0 ? prevk : fd)];
+			bool pfirst = prevk < 0;                              // the predecessor is the curve's first point
+			int curw = -1; unsigned curbits = 0;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				if ((mine >> k) & 1u) {
+					const double x2 = xs[k];
+					if ((x2 > xp ? 1 : -1) != sgn) flag |= 2;     // not monotone: not this kernel's case
+					const int K = trunc_sat(x2);
+					const long long i = (long long)(K - K0)*sgn;  // index along the curve
+					if (i < 0 || i >= MAXC) flag |= 4;
+					else {
+						if (!pfirst && K == trunc_sat(xp)) ++nm;  // two kept points on one column (x2 in (-1,1) truncates to 0 twice)
+						const int wi = (int)i >> 5;
+						if (wi != curw) {                         // indices never decrease along a monotone curve
+							if (curw >= 0) atomicOr(&S.joints[p][curw], curbits);
+							curw = wi; curbits = 0;
+						}
+						curbits |= 1u << ((int)i & 31);
+						if ((int)i > il) il = (int)i;
+					}
+					xp = x2; pfirst = false;
+				}
+			}
+			if (curw >= 0) atomicOr(&S.joints[p][curw], curbits);
+			if (il >= 0) atomicMax(&S.ilast[p], il);
+			if (nm) atomicAdd(&S.nmerge[p], nm);
+			if (flag) atomicOr(&S.pflag[p], flag);
+		} else if (g == 0) { S.k0[p] = 0; S.dir[p] = 0; }
 	}
 	__syncthreads();
-
-	// ---- B: which labels are kept (one lane per pixel); meanwhile the other waves stage windows and reference rows
-	if (seq) {
-#pragma unroll
-		for (int j = 0; j < Smem::JW; ++j) S.joints[q][j] = 0;
-		double x1 = nan;
-		int K0 = 0, Kprev = 0, sgn = 0, ilast = -1, nmerge = 0, nk = 0, flag = S.pflag[q];
-		for (int d = 0; d < D; ++d) {
-			const double x2 = S.cost[Smem::slot(q, d)];
-			if (!(x2 == x2)) continue;
-			if (!(x1 == x1)) { x1 = x2; K0 = Kprev = trunc_sat(x2); nk = 1; continue; }
-			const double dx = x2 - x1;
-			if (!(dx*dx >= 1)) continue;                          // twoviewstereo.cpp:1027 (dy: see phase A)
-			const int s = dx > 0 ? 1 : -1;
-			if (sgn && s != sgn) flag |= 2;                       // not monotone: not this kernel's case
-			sgn = s;
-			const int K = trunc_sat(x2);
-			long long i = (long long)(K - K0)*s;                  // index along the curve, >= 0 when monotone
-			if (i < 0 || i > MAXC + 30) { flag |= 4; i = 0; }
-			else {
-				if (nk >= 2 && K == Kprev) ++nmerge;              // two kept points on one column (x2 in (-1,1) truncates to 0 twice)
-				S.joints[q][(int)i >> 5] |= 1u << ((int)i & 31);
-				if ((int)i > ilast) ilast = (int)i;
-			}
-			Kprev = K; ++nk; x1 = x2;
-		}
-		// visited columns: k0 .. k0 + dir*ilast, inside the other image
+	// ---- B3: visited columns k0 .. k0 + dir*ilast inside the other image, cost-row origin, the tile's union
+	if (tid < FZ_TP) {
+		const int K0 = S.k0[tid], sgn = S.dir[tid], ilast = S.ilast[tid];
+		int flag = S.pflag[tid];
 		int ca = 0, cb = -1, corg = 0;
 		if (ilast >= 0) {
 			const int e0 = K0, e1 = K0 + sgn*ilast;
@@ -221,28 +395,13 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 			if (cb >= ca && cb - corg + 1 > MAXC) flag |= 4;      // does not fit the cost row
 			if (cb >= ca && (flag & 1)) flag |= 8;                // candidates, but not all on row y
 		}
-		if (flag & ~1) { cb = ca - 1; atomicOr(&S.bad, 1); }
-		S.k0[q] = K0; S.dir[q] = sgn; S.ilast[q] = ilast; S.nmerge[q] = nmerge;
-		S.ca[q] = ca; S.cb[q] = cb; S.corg[q] = corg;
+		if (flag & ~1) { cb = ca - 1; S.ilast[tid] = -1; atomicOr(&S.bad, 1); }
+		S.ca[tid] = ca; S.cb[tid] = cb; S.corg[tid] = corg;
 		if (cb >= ca) {
 			const int nb = (cb - corg + NCB)/NCB;
 			atomicMin(&S.cmin, corg);
 			atomicMax(&S.cmax, corg + nb*NCB - 1);
 		}
-	} else if (wave != role) {
-		// support windows of the tile: wbuf is tile-major per 32 pixels, [tap][32]
-		const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
-		const int nth = FZ_THREADS - 64, t3 = tid - 64*(wave > role ? 1 : 0) - (wave < role ? 0 : 0);
-		for (int idx = (wave > role ? tid - 64 : tid); idx < T*FZ_TP; idx += nth) {
-			const int t = idx / FZ_TP, pi = idx % FZ_TP;
-			S.w[pi][(t / WS)*WP + (t % WS)] = (x0 + pi < W) ? wtile[(size_t)t*SRH_WTILE + pi] : 0.0;
-		}
-		for (int idx = (wave > role ? tid - 64 : tid); idx < WS*Smem::LW; idx += nth) {
-			const int ty = idx / Smem::LW, tx = idx % Smem::LW;
-			const int gx = x0 - R + tx, gy = y - R + ty;
-			S.lt[ty][tx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
-		}
-		(void)t3;
 	}
 	__syncthreads();
 
@@ -252,59 +411,48 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 	const bool fits = have && (cmax - cmin + 1 + 2*R <= Smem::RW);
 	if (have && !fits && tid == 0) S.bad = 1;
 	if (fits) {
-		for (int idx = tid; idx < WS*Smem::RW; idx += FZ_THREADS) {
+		constexpr int NBR = (WS*Smem::RW + FZ_THREADS - 1)/FZ_THREADS, NBM = (Smem::RW + FZ_THREADS - 1)/FZ_THREADS;
+		double tr_[NBR]; unsigned char tm_[NBM];
+#pragma unroll
+		for (int k = 0; k < NBR; ++k) {
+			const int idx = tid + k*FZ_THREADS;
 			const int ty = idx / Smem::RW, tx = idx % Smem::RW;
 			const int gx = cmin - R + tx, gy = y - R + ty;
-			S.rt[ty][tx] = (gx >= 0 && gy >= 0 && gx < OW && gy < OH) ? Rv.gray_tv[(size_t)gy*OW + gx] : nan;
+			tr_[k] = (idx < WS*Smem::RW && gx >= 0 && gy >= 0 && gx < OW && gy < OH) ? Rv.gray_tv[(size_t)gy*OW + gx] : nan;
 		}
-		for (int tx = tid; tx < Smem::RW; tx += FZ_THREADS) {
+#pragma unroll
+		for (int k = 0; k < NBM; ++k) {
+			const int tx = tid + k*FZ_THREADS;
 			const int gx = cmin + tx;
-			S.mrow[tx] = (gx >= 0 && gx < OW && y >= 0 && y < OH) ? Rv.mask[(size_t)y*OW + gx] : 0;
+			tm_[k] = (tx < Smem::RW && gx >= 0 && gx < OW && y >= 0 && y < OH) ? Rv.mask[(size_t)y*OW + gx] : 0;
 		}
+#pragma unroll
+		for (int k = 0; k < NBR; ++k) {
+			const int idx = tid + k*FZ_THREADS;
+			if (idx < WS*Smem::RW) S.rt[idx / Smem::RW][idx % Smem::RW] = tr_[k];
+		}
+#pragma unroll
+		for (int k = 0; k < NBM; ++k) {
+			const int tx = tid + k*FZ_THREADS;
+			if (tx < Smem::RW) S.mrow[tx] = tm_[k];
+		}
+		if (tid < FZ_TP && !S.lall[tid] && S.cb[tid] >= S.ca[tid]) S.need_general = 1;   // a pixel with an unusable tap of its own
 	}
+	FZ_STAMP(2);
 	__syncthreads();
+	FZ_STAMP(7);
 
-	unsigned n_dev = 0;
 	if (fits) {
-		// ---- D: per-pixel constants of the fast form (one lane per pixel) ...
-		if (seq) {
-			const int xq = x0 + q;
-			bool all = (xq < W) && (S.cb[q] >= S.ca[q]);
-			double mL = 0, tw = 0;
-#pragma unroll 1
-			for (int row = 0; row < WS; ++row)
+		// which candidate columns have a fully usable window
+		for (int tx = tid; tx < Smem::RW; tx += FZ_THREADS) {
+			bool ok = true;
 #pragma unroll
-				for (int col = 0; col < WS; ++col) {
-					const double gl = S.lt[row][q + col];
-					const double wt = S.w[q][row*WP + col];
-					if (!(gl == gl && wt > P.weight_cutoff)) all = false;
-					mL += wt*gl;
-					tw += wt;
-				}
-			double s2 = 0;
-			if (all && !(tw < 1e-10)) {
-				mL /= tw;
-#pragma unroll 1
-				for (int row = 0; row < WS; ++row)
-#pragma unroll
-					for (int col = 0; col < WS; ++col) {
-						const double a = S.w[q][row*WP + col]*S.lt[row][q + col] - mL;
-						s2 += a*a;
-					}
-			} else all = false;
-			S.meanL[q] = mL; S.totalW[q] = tw; S.sum2[q] = s2; S.lall[q] = all ? 1 : 0;
-			if (!all && S.cb[q] >= S.ca[q]) S.need_general = 1;
-		} else if (wave != role) {
-			// ... and, on the other waves, which candidate columns have a fully usable window
-			const int nth = FZ_THREADS - 64, t0 = (wave > role ? tid - 64 : tid);
-			for (int tx = t0; tx < Smem::RW; tx += nth) {
-				bool ok = true;
-#pragma unroll
-				for (int ty = 0; ty < WS; ++ty) { const double v = S.rt[ty][tx]; ok = ok && (v == v); }
-				S.colok[tx] = ok ? 1 : 0;
-			}
+			for (int ty = 0; ty < WS; ++ty) { const double v = S.rt[ty][tx]; ok = ok && (v == v); }
+			S.colok[tx] = ok ? 1 : 0;
 		}
+		FZ_STAMP(3);
 		__syncthreads();
+		FZ_STAMP(7);
 		for (int tx = tid; tx < Smem::RW; tx += FZ_THREADS) {
 			bool ok = tx + 2*R < Smem::RW;
 			if (ok) {
@@ -316,6 +464,7 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 			if (!ok && c <= cmax) S.need_general = 1;
 		}
 		__syncthreads();
+		__builtin_amdgcn_s_setprio(0);
 
 		// ---- E: costs.  Phase 1: blocks of NCB adjacent columns in the fast form.
 		const Smem &CS = S;
@@ -424,94 +573,202 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 				}
 			}
 		}
+		FZ_STAMP(4);
 		// Phase 2: the remaining candidates (a tap unusable on either side) in the select form, compacted into an
 		// LDS work list and spread over all lanes.  Columns whose mask byte is not WHITE are never candidates.
 		const bool need_general = S.need_general != 0;            // uniform: written before the last barrier
-		for (int base = 0; need_general && base < FZ_TP*Smem::RW; base += Smem::GL_CAP) {
+#ifdef SRH_PROFILE_PHASES
+		if (tid == 0 && need_general) atomicAdd(&cnt->n_listed, 1ull);
+#endif
+		// One pass over all (pixel, column) pairs when the list holds them (the usual case: a few border columns or a
+		// pixel or two with an unusable tap); rounds of GL_CAP pairs otherwise (rows at the top / bottom of the image).
+		bool one_pass = true;
+		for (int base = 0; need_general && base < FZ_TP*Smem::RW; ) {
 			__syncthreads();
 			if (tid == 0) S.glist_n = 0;
 			__syncthreads();
-			for (int pr = base + tid; pr < base + Smem::GL_CAP && pr < FZ_TP*Smem::RW; pr += FZ_THREADS) {
+			const int end = one_pass ? FZ_TP*Smem::RW : (base + Smem::GL_CAP < FZ_TP*Smem::RW ? base + Smem::GL_CAP : FZ_TP*Smem::RW);
+			for (int pr = base + tid; pr < end; pr += FZ_THREADS) {
 				const int pi = pr / Smem::RW, k = pr % Smem::RW;
 				const int c = cmin + k;
 				if (c < S.ca[pi] || c > S.cb[pi]) continue;
 				if (CS.lall[pi] && CS.rfull[k]) continue;             // done in phase 1
 				if (CS.mrow[k] != 1) continue;
-				S.glist[atomicAdd(&S.glist_n, 1)] = (unsigned short)(pi*512 + k);
+				const int slot_ = atomicAdd(&S.glist_n, 1);
+				if (slot_ < Smem::GL_CAP) S.glist[slot_] = (unsigned short)(pi*512 + k);
 			}
 			__syncthreads();
 			const int nl = S.glist_n;
+			if (nl > Smem::GL_CAP) { one_pass = false; continue; }    // uniform: does not fit, take it in rounds
 			for (int e = tid; e < nl; e += FZ_THREADS) {
 				const int pi = S.glist[e] >> 9, k = S.glist[e] & 511;
 				++n_dev;
 				S.cost[Smem::slot(pi, cmin + k - S.corg[pi])] =
 					fused_cost_general<R, MAXC>(CS, pi, k, P.weight_cutoff, P.bad_ret, P.max_color_diff);
 			}
+			base = end;
 		}
 	}
+#ifdef SRH_PROFILE_PHASES
+	if (fits) { unsigned long long v_ = 0; for (int pi = tid; pi < FZ_TP; pi += FZ_THREADS) v_ += (S.lall[pi] == 0 && S.cb[pi] >= S.ca[pi]) ? 1 : 0;
+	            if (v_) atomicAdd(&cnt->dbg_phase[7], 0ull); if (v_) atomicAdd(&cnt->n_slots, v_); }
+#endif
+	__builtin_amdgcn_s_setprio(3);
+	FZ_STAMP(5);
 	__syncthreads();
+	FZ_STAMP(7);
 
-	// ---- F: winner-take-all in the reference's visiting order (one lane per pixel), depth of the winner
-	unsigned n_eval = 0, n_pix = 0;
-	if (seq) {
-		const int xq = x0 + q;
-		const bool act = xq < W && L.mask[(size_t)y*W + xq] == 1;
+	// ---- F: winner-take-all in the reference's visiting order, all 16 lanes of a pixel.
+	// Visiting order (twoviewstereo.cpp:1018-1040, lineiter.hpp:96-111): segments in label order, every segment in
+	// ascending column order; a column seen before cannot change the running minimum again (its cost is not
+	// < minCost - margin), so only first visits count.  With i = index along the curve (column k0 + dir*i) and the
+	// joint bits at the kept points, position v of the first-visit sequence is index v itself when the curve runs
+	// towards larger columns; when it runs towards smaller columns the indices between two joints (s..n, n a joint)
+	// are visited in reverse: index s + n - v.  Lane t takes positions 16t..16t+15, so lane order = visiting order.
+	// The running minimum with its margin (cost + 1e-10 < minCost) equals the plain running minimum unless a new
+	// minimum improves by less than the margin; lanes detect that case and the pixel is then replayed sequentially.
+	const int t = g;
+	const bool pix = fits && active && S.cb[p] >= S.ca[p];
+	double c16[16];
+	int col16[16];
+	{
+		const int ilast = S.ilast[p], K0 = S.k0[p], dirp = S.dir[p], ca = S.ca[p], cb = S.cb[p], corg = S.corg[p];
+		unsigned jw[JW];
+#pragma unroll
+		for (int j = 0; j < JW; ++j) jw[j] = S.joints[p][j];
+		const int a = 16*t;
+		unsigned mine = 0; int below = -1, above = -1;
+#pragma unroll
+		for (int j = 0; j < JW; ++j) {
+			if (j == (a >> 5)) mine = (jw[j] >> (a & 31)) & 0xffffu;
+			const unsigned mb = (32*j + 32 <= a) ? 0xffffffffu : (32*j >= a ? 0u : ((1u << (a - 32*j)) - 1u));
+			const unsigned m1 = jw[j] & mb;
+			if (m1) below = 32*j + 31 - __clz((int)m1);           // ascending j: the last hit is the highest joint < a
+		}
+#pragma unroll
+		for (int j = JW - 1; j >= 0; --j) {
+			const int a2 = a + 16;
+			const unsigned ma = (32*j >= a2) ? 0xffffffffu : (32*j + 32 <= a2 ? 0u : ~((1u << (a2 - 32*j)) - 1u));
+			const unsigned m2 = jw[j] & ma;
+			if (m2) above = 32*j + __ffs((int)m2) - 1;            // descending j: the last hit is the lowest joint >= a+16
+		}
+		unsigned char mk[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			const int v = a + k;
+			int i = v;
+			bool ok = pix && v <= ilast;
+			if (dirp < 0) {
+				const unsigned lo = mine & ((1u << k) - 1u), hi = mine >> k;
+				const int prevj = lo ? a + 31 - __clz((int)lo) : below;
+				const int n = hi ? v + __ffs((int)hi) - 1 : above;
+				ok = ok && n >= 0;
+				i = prevj + 1 + n - v;
+			}
+			const int c = K0 + dirp*i;
+			ok = ok && c >= ca && c <= cb;
+			col16[k] = ok ? c : -2147483647;
+			const int cc = ok ? c : ca;                           // a safe address for the unconditional loads
+			mk[k] = (pix ? S.mrow[cc - cmin] : 0);
+			c16[k] = pix ? S.cost[Smem::slot(p, cc - corg)] : inf;
+		}
+		unsigned dup = 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			const bool ok = col16[k] != -2147483647 && mk[k] == 1;    // mask.pixel(tx,ty) == WHITE, twoviewstereo.cpp:1034
+			if (!ok) { c16[k] = inf; col16[k] = -2147483647; }
+			n_eval += ok ? 1u : 0u;
+			// joints are evaluated twice by the reference (once per segment): count them as it does
+			if (pix && ((mine >> k) & 1u) && a + k != ilast) {
+				const int cj = K0 + dirp*(a + k);
+				if (cj >= ca && cj <= cb && S.mrow[cj - cmin] == 1) ++dup;
+			}
+		}
+		if (pix && t == 0 && S.nmerge[p] > 0 && 0 >= ca && 0 <= cb && S.mrow[0 - cmin] == 1) dup += S.nmerge[p];
+		n_eval += dup;
+	}
+	// running minimum before my first position: exclusive prefix-min over the lanes of the pixel (lane = 4g + pixel,
+	// so "one lane of the pixel earlier" is 4 wave lanes down); the pixel's 16 lanes are in one wave: no barrier
+	double lm = inf;
+#pragma unroll
+	for (int k = 0; k < 16; ++k) lm = c16[k] < lm ? c16[k] : lm;
+	double scan = lm;
+#pragma unroll
+	for (int off = 4; off < 64; off <<= 1) {
+		const double o = __shfl_up(scan, off, 64);
+		if (lane >= off && o < scan) scan = o;
+	}
+	double Pin = __shfl_up(scan, 4, 64);
+	if (t == 0) Pin = inf;
+	double Pm = Pin, sec = inf; int wc = -2147483647, amb = 0;
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		if (c16[k] < Pm) {
+			if (!(c16[k] + P.wta_margin < Pm)) amb = 1;           // the reference would not take this one
+			sec = Pm; Pm = c16[k]; wc = col16[k];
+		}
+	}
+	if (!(P.wta_margin >= 0)) amb = 1;
+	const double gmin = __shfl(scan, 60 + (lane & 3), 64);        // the pixel's last lane holds the overall minimum
+	const unsigned long long ambs = __ballot(amb) & (0x1111111111111111ull << (lane & 3));
+	// the lane that holds the last record (records decrease strictly, so it is the one whose record is the minimum)
+	// finishes the pixel; without any candidate lane 0 does
+	const bool owner = wc != -2147483647 && Pm == gmin;
+	if (owner || (t == 0 && !(gmin < inf))) {
 		double depth = nan;                                       // twoviewstereo.cpp:269
-		if (act) {
-			n_pix = 1;
-			const int ca = S.ca[q], cb = S.cb[q], corg = S.corg[q];
-			double minCost = __builtin_inf(), secondBest = __builtin_inf();
-			int wcol = -2147483647;
-			if (fits && cb >= ca) {
-				const int K0 = S.k0[q], dir = S.dir[q], ilast = S.ilast[q];
+		if (active) {
+			double minCost = owner ? Pm : inf, secondBest = owner ? sec : inf;
+			int wcol = wc;
+			if (pix && ambs) {
+				// replay with the reference's margin rule, sequentially (rare: two costs within 1e-10 of each other)
+				const int ilast = S.ilast[p], K0 = S.k0[p], dirp = S.dir[p], ca = S.ca[p], cb = S.cb[p], corg = S.corg[p];
+				minCost = inf; secondBest = inf; wcol = -2147483647;
 				auto visit = [&](int c) {
-					if (c < ca || c > cb) return;                     // outside the other image
-					if (S.mrow[c - cmin] != 1) return;                // mask.pixel(tx,ty) == WHITE, twoviewstereo.cpp:1034
-					++n_eval;
-					const double cv = S.cost[Smem::slot(q, c - corg)];
-					if (cv + P.wta_margin < minCost) {                // twoviewstereo.cpp:293-301
-						secondBest = minCost; minCost = cv; wcol = c;
-					}
+					if (c < ca || c > cb) return;
+					if (S.mrow[c - cmin] != 1) return;
+					const double cv = S.cost[Smem::slot(p, c - corg)];
+					if (cv + P.wta_margin < minCost) { secondBest = minCost; minCost = cv; wcol = c; }   // twoviewstereo.cpp:293-301
 				};
-				if (dir > 0) {
+				if (dirp > 0) {
 					for (int i = 0; i <= ilast; ++i) visit(K0 + i);
 				} else {
-					// segments in label order run towards smaller columns, each visited in ascending column order
-					// (lineiter.hpp:96-111); its upper end was visited by the segment before
 					int lo = 0;
 					while (true) {
-						const int nj = next_joint<Smem::JW>(S.joints[q], lo);
+						const int nj = next_joint<JW>(S.joints[p], lo);
 						if (nj < 0) break;
 						for (int i = nj; i >= lo; --i) visit(K0 - i);
 						lo = nj + 1;
 					}
 				}
-				// joints are evaluated twice by the reference (once per segment): count them as it does
-				{
-					int dup = 0, lo = 0;
-					while (true) {
-						const int nj = next_joint<Smem::JW>(S.joints[q], lo);
-						if (nj < 0) break;
-						const int c = K0 + dir*nj;
-						if (nj != ilast && c >= ca && c <= cb && S.mrow[c - cmin] == 1) ++dup;
-						lo = nj + 1;
-					}
-					if (S.nmerge[q] > 0 && 0 >= ca && 0 <= cb && S.mrow[0 - cmin] == 1) dup += S.nmerge[q];
-					n_eval += dup;
-				}
 			}
 			if (wcol != -2147483647) {
-				const Ray ray = cam_unproject(L.cam, (xq + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+				const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 				depth = candidate_depth(L.cam, Rv.cam, P, ray, wcol, y);
 			}
-			if (minCost > P.second_best_factor*secondBest) depth = __builtin_inf();   // twoviewstereo.cpp:304-305
+			if (minCost > P.second_best_factor*secondBest) depth = inf;   // twoviewstereo.cpp:304-305
 		}
-		if (xq < W) L.depth[(size_t)y*W + xq] = depth;
+		if (x < W) L.depth[(size_t)y*W + x] = depth;
 	}
+	if (t == 0 && active) ++n_pix;
+	if (tid == 0 && S.bad) atomicAdd(&cnt->not_row_aligned, 1ull);
+	FZ_STAMP(6);
+	__syncthreads();                                          // the tile's LDS is re-initialised next
+	FZ_STAMP(7);
+	}
+#ifdef SRH_PROFILE_PHASES
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) {
+		// per-wave phase cycles: wave 0 in dbg_phase[], the other waves summed in the dbg_* scalars
+		if (wave == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&cnt->dbg_phase[k], ph[k]);
+		                 atomicAdd(&cnt->dbg_waves, (unsigned long long)((ntiles - (int)blockIdx.x + (int)gridDim.x - 1)/(int)gridDim.x)); }
+		else { atomicAdd(&cnt->dbg_cycles, ph[4]); atomicAdd(&cnt->dbg_blocks, ph[7]);
+		       atomicAdd(&cnt->dbg_total_cycles, ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6] + ph[7]); }
+	}
+#endif
 	block_count_add(&cnt->n_eval, n_eval);
 	block_count_add(&cnt->n_eval_device, n_dev);
 	block_count_add(&cnt->n_pixels, n_pix);
-	if (tid == 0 && S.bad) atomicAdd(&cnt->not_row_aligned, 1ull);
+#undef FZ_STAMP
 }
 
 bool launch_twoview_fused(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -529,6 +786,11 @@ bool launch_twoview_fused(hipStream_t st, const ViewDev *views, int ref, int oth
 		                   views, ref, oth, P, y0, nrows, wbuf, tnum, cnt);                                  \
 		return true;                                                                                         \
 	}
+#ifdef SRH_PROFILE_PHASES
+	{ static bool once = false; if (!once) { once = true; int nb = 0;
+	  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)twoview_fused_kernel<5, SRH_FUSED_MAXC>, FZ_THREADS, sizeof(FusedSmem<5, SRH_FUSED_MAXC>));
+	  fprintf(stderr, "[srh dbg] fused<5>: %zu bytes of LDS, %d workgroups per CU\n", sizeof(FusedSmem<5, SRH_FUSED_MAXC>), nb); } }
+#endif
 	if (P.num_depth_levels > SRH_FUSED_MAXC) return false;        // the label projections share the cost rows' LDS
 	switch (P.window_radius) {
 	case 5: SRH_FZ_LAUNCH(5, SRH_FUSED_MAXC)
