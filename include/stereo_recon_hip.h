@@ -134,8 +134,9 @@ int  srh_synchronize(srh_context *ctx);
 /* Tuning / test switches (results never depend on them):
  *   "force_generic"   0 default paths; 1 never the dense row-aligned TwoView kernels nor the MVS list kernels;
  *                     2 additionally no candidate lists at all (one thread per pixel walks and costs its curve)
- *   "fused"           1 (default) row-aligned pairs run the single fused kernel (geometry + cost + WTA per tile in
- *                     LDS); 0: the three-kernel form (cost rows staged in device memory, separate scan)
+ *   "fused"           1: row-aligned pairs run the single fused kernel (geometry + cost + WTA per 16-pixel tile
+ *                     in LDS: no cost rows or candidate lists in device memory); 0 (default): the three-kernel form
+ *                     (cost rows staged in device memory, separate scan), which is the faster one on MI355X today
  *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
  *                     not only for rigs the host check accepts (the device verifies every candidate and the
  *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)

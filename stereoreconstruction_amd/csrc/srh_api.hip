@@ -82,7 +82,7 @@ struct srh_context {
 	void *user = nullptr;
 	bool profiling = false;
 	bool force_generic = false;
- 	bool use_fused = true;                              // option "fused": single fused kernel for row-aligned pairs
+ 	bool use_fused = false;                             // option "fused": single fused kernel for row-aligned pairs
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;

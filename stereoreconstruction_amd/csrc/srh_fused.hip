@@ -143,7 +143,6 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 	const int W = views[ref].w, H = views[ref].h, OW = views[oth].w, OH = views[oth].h;
 	const int D = P.num_depth_levels;
 	const int tiles_per_row = (W + FZ_TP - 1)/FZ_TP;
-	const int ntiles = tiles_per_row*nrows;
 	const double nan = __builtin_nan("");
 	const double inf = __builtin_inf();
 
@@ -158,17 +157,13 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 	// shares its SIMDs with another one that is usually deep in its FP64 loops; the hardware favours the older
 	// wave, which would starve these dependent chains (measured: 560 cycles per label in phase B).  They run at
 	// raised priority -- they leave almost every issue slot free anyway.
-	// A workgroup takes every gridDim.x-th tile (the launch uses one workgroup per tile: a persistent grid of two
-	// workgroups per CU, with or without a start offset between them, measured 8 % slower on MI355X).
+	// One workgroup per tile (a persistent grid of two workgroups per CU, with or without a start offset between
+	// the two, measured 8 % slower on MI355X).
 	unsigned long long n_eval = 0, n_pix = 0, n_dev = 0;
-	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-	// the view table is re-read in every tile: camera matrices hoisted out of this loop would be held in
-	// registers across all phases (the compiler did so, and spilled)
-	// ... and so would every per-lane LDS address: the thread index is laundered once per tile
+	{
+	const int tile = blockIdx.x;
 	const ViewDev *vt = views;
-	asm volatile("" : "+s"(vt));
-	int tid = threadIdx.x;
-	asm volatile("" : "+v"(tid));
+	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
 	const int p = wave*4 + (lane & 3);                        // pixel within the tile (pixel-fastest inside a wave)
 	const int g = lane >> 2;                                  // lane within the pixel
@@ -752,15 +747,13 @@ void twoview_fused_kernel(const ViewDev *__restrict__ views, int ref, int oth, s
 	if (t == 0 && active) ++n_pix;
 	if (tid == 0 && S.bad) atomicAdd(&cnt->not_row_aligned, 1ull);
 	FZ_STAMP(6);
-	__syncthreads();                                          // the tile's LDS is re-initialised next
-	FZ_STAMP(7);
 	}
 #ifdef SRH_PROFILE_PHASES
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if (lane == 0) {
 		// per-wave phase cycles: wave 0 in dbg_phase[], the other waves summed in the dbg_* scalars
 		if (wave == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&cnt->dbg_phase[k], ph[k]);
-		                 atomicAdd(&cnt->dbg_waves, (unsigned long long)((ntiles - (int)blockIdx.x + (int)gridDim.x - 1)/(int)gridDim.x)); }
+		                 atomicAdd(&cnt->dbg_waves, 1ull); }
 		else { atomicAdd(&cnt->dbg_cycles, ph[4]); atomicAdd(&cnt->dbg_blocks, ph[7]);
 		       atomicAdd(&cnt->dbg_total_cycles, ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6] + ph[7]); }
 	}

@@ -28,7 +28,7 @@ def _run(ctx, ref, oth, p, fused, generic=0):
         st = ctx.stats()
         return ctx.download_depth(ref), st
     finally:
-        ctx.set_option("fused", 1)
+        ctx.set_option("fused", 0)                   # the library's default
         ctx.set_option("force_generic", 0)
 
 
