@@ -220,6 +220,10 @@ int  srh_comm_init(srh_context *ctx, int nranks, int rank, const void *id);
 int  srh_comm_gather_depth(srh_context *ctx, int slot, int root, void *recv_dev);
 /* Every rank receives every rank's map of `slot` (MVS cross-check input). */
 int  srh_comm_allgather_depth(srh_context *ctx, int slot, void *recv_dev);
+/* The same collective on HOST buffers: every rank contributes `count` doubles and receives nranks*count (rank
+ * order); staged through device memory of the context, RCCL in between.  For callers above the C-ABI that hold
+ * several maps per rank in host memory (host/sharded.hpp). */
+int  srh_comm_allgather_host(srh_context *ctx, const double *send_host, size_t count, double *recv_host);
 int  srh_comm_destroy(srh_context *ctx);
 
 /* ---- measurement ---- */

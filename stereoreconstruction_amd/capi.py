@@ -71,7 +71,8 @@ EXPORTS = [
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_epipolar_curves",
-    "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_destroy",
+    "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
+    "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
 ]
 

@@ -1056,6 +1056,21 @@ extern "C" int srh_comm_allgather_depth(srh_context *c, int slot, void *recv_dev
 	return SRH_OK;
 }
 
+extern "C" int srh_comm_allgather_host(srh_context *c, const double *send_host, size_t count, double *recv_host) {
+	if (!c || !send_host || !recv_host || count == 0) return fail(SRH_E_INVALID, "null argument");
+	if (!c->comm) return fail(SRH_E_INVALID, "srh_comm_init has not been called");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc;
+	// staging in the band scratch (free between runs): [send | recv]
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, count*(size_t)(c->comm_ranks + 1)))) return rc;
+	HIP_TRY(hipMemcpyAsync(c->wbuf, send_host, count*sizeof(double), hipMemcpyHostToDevice, c->stream));
+	if (const char *e = rccl_allgather_f64(c->comm, c->wbuf, c->wbuf + count, count, c->stream))
+		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
+	HIP_TRY(hipMemcpyAsync(recv_host, c->wbuf + count, count*(size_t)c->comm_ranks*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return SRH_OK;
+}
+
 extern "C" int srh_comm_destroy(srh_context *c) {
 	if (!c) return fail(SRH_E_INVALID, "null context");
 	if (c->comm) { rccl_comm_destroy(c->comm); c->comm = nullptr; c->comm_ranks = 0; }
