@@ -196,6 +196,17 @@ int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *ne
 int  srh_mvs_cross_check(srh_context *ctx, const int32_t *slots, int nviews, int view_index,
                          const srh_params *p);
 
+/* ---- depth map -> point cloud ----
+ * The output side of the path (the reference keeps only the PLY writer, multiviewstereo.cpp:291-315,
+ * and the per-view coverage figure it logs, :402-421).  For every pixel of `slot` whose mask is WHITE and whose depth is
+ * finite: the 3-D point unproject((x+0.5)/scale, (y+0.5)/scale) cut at that depth by pointFromDepth with the camera's
+ * principal direction and centre -- the construction both cross-checks use (twoviewstereo.cpp:612-614,
+ * multiviewstereo.cpp:688-692) -- and the pixel's colour.  HOST outputs, pixel order: xyz (w*h*3 doubles, NaN where
+ * there is no point), rgb (w*h*3 bytes), valid (w*h bytes); each may be NULL.  *n_points = points produced,
+ * *n_masked = pixels with a WHITE mask (coverage = finite depths / masked pixels is what the reference prints). */
+int  srh_view_point_cloud(srh_context *ctx, int slot, const srh_params *p, double *xyz_out, uint8_t *rgb_out,
+                          uint8_t *valid_out, int64_t *n_points, int64_t *n_masked, int64_t *n_finite);
+
 /* ---- epipolar curves ----
  * TwoViewStereo::epipolarCurve (public member, twoviewstereo.hpp:66-70, twoviewstereo.cpp:999-1054;
  * the GUI's curve preview calls it, stereowidget.cpp:621-672) when mvs == 0, and

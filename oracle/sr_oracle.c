@@ -267,6 +267,19 @@ int sro_image_sample(const sro_image *img, double x, double y, double out[3]) {
 	return 0;
 }
 
+/* forward: defined with the camera model below */
+void sro_unproject(const sro_camera *cam, double px, double py, double src[3], double dir[3]);
+static int point_from_depth(const double src[3], const double dir[3], const double normal[3], double depth, double p[3]);
+
+int sro_back_project(const sro_camera *cam, const sro_params *p, int x, int y, double depth, double out[3]) {
+	double src[3], dir[3];
+	sro_unproject(cam, (x + 0.5) / p->image_scale, (y + 0.5) / p->image_scale, src, dir);
+	double pt[3] = { cam->C[0], cam->C[1], cam->C[2] };
+	if (!point_from_depth(src, dir, cam->pdir, depth, pt)) return 0;
+	out[0] = pt[0]; out[1] = pt[1]; out[2] = pt[2];
+	return 1;
+}
+
 /* ------------------------------------------------------------------ */
 /* util/lineiter */
 

@@ -131,6 +131,11 @@ int  sro_project(const sro_camera *cam, double p[3]);
 void sro_closest_points(const double s1[3], const double d1[3], const double s2[3], const double d2[3],
                         double p1[3], double p2[3]);
 
+/* The 3-D point of pixel (x,y) at depth `depth`: unproject((x+0.5)/scale, (y+0.5)/scale), then pointFromDepth with
+ * the camera's principal direction and centre -- the construction both cross-checks use (twoviewstereo.cpp:612-614,
+ * multiviewstereo.cpp:688-692).  Returns 0 when pointFromDepth fails (e.g. depth -1, the "no peak" value). */
+int  sro_back_project(const sro_camera *cam, const sro_params *p, int x, int y, double depth, double out[3]);
+
 /* --- epipolar curves --- */
 /* TwoViewStereo::epipolarCurve (twoviewstereo.cpp:999-1054) when mvs==0 (non-uniform
  * labels, no clipping, no de-duplication); MultiViewStereo::epipolarCurve

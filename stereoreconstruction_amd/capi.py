@@ -70,7 +70,7 @@ EXPORTS = [
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
-    "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_epipolar_curves",
+    "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
     "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
@@ -119,6 +119,7 @@ def lib():
     L.srh_view_depth_download.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.srh_view_point_cloud.argtypes = [vp, C.c_int, C.POINTER(Params), c_double_p, c_uint8_p, c_uint8_p, vp, vp, vp]
     L.srh_view_depth_copy_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.srh_view_depth_copy_from_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.srh_twoview_wta.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
@@ -332,6 +333,19 @@ class Context:
     def mvs_cross_check(self, slots, view_index, p):
         s = np.ascontiguousarray(slots, dtype=np.int32)
         _check(lib().srh_mvs_cross_check(self._h, s.ctypes.data_as(c_int32_p), len(s), view_index, C.byref(p)))
+
+    def point_cloud(self, slot, p):
+        """-> dict(xyz (h,w,3) float64 with NaN where there is no point, rgb (h,w,3) uint8, valid (h,w) uint8,
+        n_points, n_masked, n_finite): srh_view_point_cloud."""
+        w, h = self.view_size(slot)
+        xyz = np.empty((h, w, 3), dtype=np.float64)
+        rgb = np.empty((h, w, 3), dtype=np.uint8)
+        valid = np.empty((h, w), dtype=np.uint8)
+        n = (C.c_int64 * 3)()
+        _check(lib().srh_view_point_cloud(self._h, slot, C.byref(p), _dptr(xyz), rgb.ctypes.data_as(c_uint8_p),
+                                          valid.ctypes.data_as(c_uint8_p), C.cast(C.byref(n, 0), C.c_void_p),
+                                          C.cast(C.byref(n, 8), C.c_void_p), C.cast(C.byref(n, 16), C.c_void_p)))
+        return dict(xyz=xyz, rgb=rgb, valid=valid, n_points=int(n[0]), n_masked=int(n[1]), n_finite=int(n[2]))
 
     def epipolar_curves(self, ref_slot, oth_slot, p, xy, mvs=False, max_pts=4096):
         """Candidate pixels of each reference pixel in `xy` (n,2), in the reference's visiting order

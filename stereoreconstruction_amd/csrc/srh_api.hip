@@ -982,6 +982,38 @@ extern "C" int srh_mvs_cross_check(srh_context *c, const int32_t *slots, int nvi
 	return SRH_OK;
 }
 
+// ------------------------------------------------------------------ depth map -> point cloud
+extern "C" int srh_view_point_cloud(srh_context *c, int slot, const srh_params *p, double *xyz_out, uint8_t *rgb_out,
+                                    uint8_t *valid_out, int64_t *n_points, int64_t *n_masked, int64_t *n_finite)
+{
+	int rc;
+	if ((rc = check_slot(c, slot, true)) || (rc = check_params(p))) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	const size_t n = (size_t)v.w*v.h;
+	// scratch: xyz (3n doubles) | rgb (3n) | valid (n) | 3 counters, in the band buffer (free between runs)
+	const size_t need = 3*n + (3*n + n + 7)/8 + 4;
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, need))) return rc;
+	double *d_xyz = c->wbuf;
+	uint8_t *d_rgb = reinterpret_cast<uint8_t *>(c->wbuf + 3*n);
+	uint8_t *d_valid = d_rgb + 3*n;
+	unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(c->wbuf + need - 4);
+	HIP_TRY(hipMemsetAsync(d_counts, 0, 3*sizeof(unsigned long long), c->stream));
+	{ Scope s(c, "point_cloud_kernel");
+	  launch_point_cloud(c->stream, c->d_views, slot, v.w, v.h, *p, d_xyz, d_rgb, d_valid, d_counts); }
+	HIP_TRY(hipGetLastError());
+	unsigned long long hc[3] = { 0, 0, 0 };
+	HIP_TRY(hipMemcpyAsync(hc, d_counts, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+	if (xyz_out) HIP_TRY(hipMemcpyAsync(xyz_out, d_xyz, 3*n*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb, 3*n, hipMemcpyDeviceToHost, c->stream));
+	if (valid_out) HIP_TRY(hipMemcpyAsync(valid_out, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (n_points) *n_points = (int64_t)hc[0];
+	if (n_masked) *n_masked = (int64_t)hc[1];
+	if (n_finite) *n_finite = (int64_t)hc[2];
+	return SRH_OK;
+}
+
 // ------------------------------------------------------------------ epipolar curves on request
 extern "C" int srh_epipolar_curves(srh_context *c, int ref, int oth, const srh_params *p, int mvs,
                                    int nq, const int32_t *xy, int32_t *out_xy, int max_pts, int32_t *counts)

@@ -115,6 +115,8 @@ void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const i
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,
                           double *unit_peaks, double *peaks);
+void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, int h, const srh_params &P,
+                        double *xyz, uint8_t *rgb, uint8_t *valid, unsigned long long *counts);
 void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int mvs,
                             int nq, const int32_t *xy, int32_t *out, int cap, int32_t *counts);
 

@@ -254,6 +254,47 @@ void launch_twoview_cross_check(hipStream_t st, const ViewDev *views, int self, 
 	                   views, self, other, P);
 }
 
+// ------------------------------------------------------------------ depth map -> point cloud
+// one thread per pixel: unproject + pointFromDepth (the cross-checks' construction, twoviewstereo.cpp:612-614)
+__global__ void point_cloud_kernel(const ViewDev *__restrict__ views, int slot, srh_params P,
+                                   double *__restrict__ xyz, uint8_t *__restrict__ rgb, uint8_t *__restrict__ valid,
+                                   unsigned long long *__restrict__ counts)
+{
+	const ViewDev &A = views[slot];
+	const int W = A.w, H = A.h;
+	const size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	unsigned n_pt = 0, n_mask = 0, n_fin = 0;
+	if (i < (size_t)W*H) {
+		const int x = (int)(i % W), y = (int)(i / W);
+		const double nanv = __builtin_nan("");
+		Vec3 pt = v3(nanv, nanv, nanv);
+		bool ok = false;
+		if (A.mask[i] == 1) {
+			n_mask = 1;
+			const double depth = A.depth[i];
+			if (isfinite_d(depth)) {
+				n_fin = 1;
+				const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+				Vec3 q = load3(A.cam.C);
+				if (point_from_depth(ray, load3(A.cam.pdir), depth, q)) { pt = q; ok = true; n_pt = 1; }
+			}
+		}
+		if (xyz) { xyz[3*i] = pt.x; xyz[3*i + 1] = pt.y; xyz[3*i + 2] = pt.z; }
+		if (rgb) { const uint32_t c = A.rgba[i]; rgb[3*i] = (uint8_t)(c & 255u); rgb[3*i + 1] = (uint8_t)((c >> 8) & 255u); rgb[3*i + 2] = (uint8_t)((c >> 16) & 255u); }
+		if (valid) valid[i] = ok ? 1 : 0;
+	}
+	block_count_add(&counts[0], n_pt);
+	block_count_add(&counts[1], n_mask);
+	block_count_add(&counts[2], n_fin);
+}
+
+void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, int h, const srh_params &P,
+                        double *xyz, uint8_t *rgb, uint8_t *valid, unsigned long long *counts)
+{
+	const size_t n = (size_t)w*h;
+	hipLaunchKernelGGL(point_cloud_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, slot, P, xyz, rgb, valid, counts);
+}
+
 // ------------------------------------------------------------------ MVS, general geometry
 struct MvsVisitor {
 	const ViewDev &A, &B;

@@ -157,3 +157,33 @@ const MultiViewStereo::DepthMap *MultiViewStereo::depths(CameraPtr view) const {
 		if (views[v] == view) return &computedDepths[v];
 	return nullptr;
 }
+
+std::vector<PLYPoint> MultiViewStereo::pointCloud(CameraPtr view) {
+	std::vector<PLYPoint> pts;
+	for (size_t v = 0; v < views.size(); ++v) if (views[v] == view && ctx_) {
+		const size_t n = static_cast<size_t>(images[v].w)*images[v].h;
+		std::vector<double> xyz(3*n);
+		std::vector<uint8_t> rgb(3*n), valid(n);
+		params_.image_scale = imageScale;
+		if (srh_view_depth_upload(ctx_, static_cast<int>(v), computedDepths[v].data()) != SRH_OK ||
+		    srh_view_point_cloud(ctx_, static_cast<int>(v), &params_, xyz.data(), rgb.data(), valid.data(), nullptr, nullptr, nullptr) != SRH_OK) {
+			error_ = srh_last_error();
+			return pts;
+		}
+		for (size_t i = 0; i < n; ++i) if (valid[i]) {
+			PLYPoint q;
+			for (int k = 0; k < 3; ++k) { q.p[k] = xyz[3*i + k]; q.rgb[k] = rgb[3*i + k]; }
+			pts.push_back(q);
+		}
+	}
+	return pts;
+}
+
+double MultiViewStereo::coverage(CameraPtr view) const {
+	for (size_t v = 0; v < views.size(); ++v) if (views[v] == view) {
+		long total = 0, have = 0;
+		for (size_t i = 0; i < masks[v].size(); ++i) if (masks[v][i] == 1) { ++total; if (std::isfinite(computedDepths[v][i])) ++have; }
+		return total ? (100.0*have)/total : 0.0;
+	}
+	return 0.0;
+}

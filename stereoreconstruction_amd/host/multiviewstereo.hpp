@@ -52,6 +52,11 @@ public:
 
 	Image depthMap(CameraPtr view) const;              // grayscale, NaN/INF/unknown white (:252-276)
 	const DepthMap *depths(CameraPtr view) const;      // computedDepths[view]
+	// The view's current depth map as coloured 3-D points (pixels with a WHITE mask and a finite depth; the point
+	// is the cross-checks' construction, multiviewstereo.cpp:688-692) -- what outputPLYFile takes.
+	std::vector<PLYPoint> pointCloud(CameraPtr view);
+	// "percent of pixels have depth hypotheses": finite depths among the masked-in pixels (:402-421)
+	double coverage(CameraPtr view) const;
 	const std::vector<std::vector<int> > &neighbourViews() const { return neighbours; }
 
 	srh_params &params() { return params_; }

@@ -68,8 +68,22 @@ static int runProject(int argc, char **argv) {
 	return 0;
 }
 
+// host_api_test ply in.bin out.ply : in.bin = int32 n; n x (double x,y,z; uint8 r,g,b) -> outputPLYFile (host only)
+static int runPly(const char *in, const char *out) {
+	FILE *f = fopen(in, "rb");
+	if (!f) { perror(in); return 2; }
+	int32_t n;
+	rd(f, &n, 1);
+	std::vector<PLYPoint> pts(n);
+	for (int i = 0; i < n; ++i) { rd(f, pts[i].p, 3); rd(f, pts[i].rgb, 3); }
+	fclose(f);
+	outputPLYFile(out, pts);
+	return 0;
+}
+
 int main(int argc, char **argv) {
 	if (argc >= 2 && !strcmp(argv[1], "mvsproject")) return runProject(argc, argv);
+	if (argc == 4 && !strcmp(argv[1], "ply")) return runPly(argv[2], argv[3]);
 	if (argc != 4) { fprintf(stderr, "usage: %s twoview|mvs in out\n", argv[0]); return 2; }
 	const bool mvs = !strcmp(argv[1], "mvs");
 	FILE *f = fopen(argv[2], "rb");
@@ -132,6 +146,11 @@ int main(int argc, char **argv) {
 		for (int v = 0; v < nviews; ++v) out.push_back(*m->depths(cams[v]));
 		if (!m->depthMap(CameraPtr(new Camera("x"))).isNull()) return 5;     // unknown view => null image
 		if (m->depthMap(cams[0]).width() != w) return 5;
+		// output side: the first view's depth map as a PLY point cloud next to out.bin, its coverage on stdout
+		const std::vector<PLYPoint> cloud = m->pointCloud(cams[0]);
+		if (!m->lastError().empty()) { fprintf(stderr, "cloud: %s\n", m->lastError().c_str()); return 3; }
+		outputPLYFile(std::string(argv[3]) + ".ply", cloud);
+		printf("coverage %.17g points %zu\n", m->coverage(cams[0]), cloud.size());
 	}
 	if (!started || !finished) return 6;
 	FILE *o = fopen(argv[3], "wb");

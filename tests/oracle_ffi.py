@@ -92,6 +92,8 @@ def lib():
     L.sro_project.argtypes = [C.POINTER(Camera), c_double_p]
     L.sro_project.restype = C.c_int
     L.sro_closest_points.argtypes = [c_double_p] * 6
+    L.sro_back_project.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_int, C.c_int, C.c_double, c_double_p]
+    L.sro_back_project.restype = C.c_int
     L.sro_epipolar_curve.argtypes = [C.POINTER(Camera), C.POINTER(Camera), C.POINTER(Image),
                                      C.POINTER(Params), C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int]
     L.sro_epipolar_curve.restype = C.c_int

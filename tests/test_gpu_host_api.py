@@ -167,3 +167,80 @@ def test_multiviewstereo_from_a_project_file(tmp_path):
     for v, c in enumerate(ids):
         ok, msg, _ = cases.compare_depth(got[c], ref[v], 1e-9)
         assert ok, "%s: %s" % (c, msg)
+
+
+def _read_ply(path):
+    lines = open(path).read().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format ascii 1.0"
+    n = int(lines[2].split()[-1])
+    assert lines[3:10] == ["property float x", "property float y", "property float z", "property uchar diffuse_red",
+                           "property uchar diffuse_green", "property uchar diffuse_blue", "end_header"]
+    body = [ln.split() for ln in lines[10:10 + n]]
+    assert len(body) == n and all(len(b) == 6 for b in body) and lines[10 + n:] == [""]
+    return np.array([[float(v) for v in b[:3]] for b in body]).reshape(n, 3), np.array([[int(v) for v in b[3:]] for b in body]).reshape(n, 3)
+
+
+def test_output_ply_file_round_trip(tmp_path):
+    """outputPLYFile (multiviewstereo.cpp:291-315): ASCII header + "x y z r g b" lines through operator<< of an
+    ofstream (6 significant digits): re-read and compared."""
+    exe = _build(str(tmp_path))
+    rng = np.random.default_rng(2)
+    pts = np.concatenate([rng.normal(0, 40, (50, 3)), [[0.0, -0.0, 1e-7], [123456.789, -9.87654321e-5, 3.0]]])
+    rgb = rng.integers(0, 256, (len(pts), 3)).astype(np.uint8)
+    inp, outp = str(tmp_path / "pts.bin"), str(tmp_path / "pts.ply")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<i", len(pts)))
+        for q, c in zip(pts, rgb):
+            f.write(struct.pack("<3d3B", *q, *[int(v) for v in c]))
+    subprocess.check_call([exe, "ply", inp, outp])
+    xyz, col = _read_ply(outp)
+    assert np.array_equal(col, rgb)
+    assert np.array_equal(xyz, np.array([[float("%g" % v) for v in q] for q in pts]))   # %g == ostream default formatting
+
+
+@pytest.mark.gpu
+def test_point_cloud_of_a_depth_map(tmp_path, hip_ctx):
+    """srh_view_point_cloud: unproject + pointFromDepth per finite masked-in pixel == the oracle's construction, bit
+    for bit; colours = the pixels'; counters; and the host class writes the same points as a PLY file."""
+    exe = _build(str(tmp_path))
+    case = cases.get_mvs("mvs_distorted")
+    views = []
+    for (rgba, mask, cam, dist, plane) in case["views"]:
+        im = rgba.copy()
+        im[..., 3] = np.where(mask == 1, 255, 51)
+        views.append((im, mask, cam, dist, plane))
+    case = dict(case, views=views)
+    h, w = views[0][0].shape[:2]
+    nv = len(views)
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_input(inp, case, False)
+    r = subprocess.run([exe, "mvs", inp, outp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got, steps = _read_output(outp, nv, w, h)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.upload_depth(0, got[0])
+    pc = hip_ctx.point_cloud(0, p)
+    mask = views[0][1] == 1
+    fin = np.isfinite(got[0]) & mask
+    assert pc["n_masked"] == int(mask.sum()) and pc["n_finite"] == int(fin.sum())
+    want = np.full((h, w, 3), np.nan)
+    n_ok = 0
+    out3 = np.zeros(3)
+    for y, x in np.argwhere(fin):
+        if O.lib().sro_back_project(ocams[0], op, int(x), int(y), float(got[0][y, x]), O.dptr(out3)):
+            want[y, x] = out3
+            n_ok += 1
+    assert pc["n_points"] == n_ok and 0 < n_ok <= int(fin.sum())
+    assert np.array_equal(np.isnan(pc["xyz"]), np.isnan(want))
+    assert np.array_equal(pc["xyz"][pc["valid"] == 1].view(np.uint64), want[pc["valid"] == 1].view(np.uint64))
+    assert np.array_equal(pc["rgb"], views[0][0][..., :3])
+    # -1 ("no peak") is finite but pointFromDepth fails on it: counted as finite, no point
+    assert (got[0][fin] == -1).sum() == int(fin.sum()) - n_ok
+    xyz, col = _read_ply(outp + ".ply")
+    assert len(xyz) == n_ok
+    assert np.array_equal(xyz, np.array([[float("%g" % v) for v in q] for q in pc["xyz"][pc["valid"] == 1]]))
+    assert np.array_equal(col, pc["rgb"][pc["valid"] == 1])
+    cov = float(r.stdout.split()[1])
+    assert abs(cov - 100.0 * fin.sum() / mask.sum()) < 1e-9
