@@ -254,6 +254,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the CPU-baseline band (0 = skip)")
+    ap.add_argument("--arith", default="exact", choices=["exact", "fma"],
+                    help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
+                         "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -318,6 +321,16 @@ def main():
             ctx.set_option(opt, int(os.environ["SRH_BENCH_" + opt.upper()]))
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
+    mismatch = None
+    if args.arith == "fma":
+        if args.workload in ("c1", "c4", "c5"):
+            sys.exit("--arith fma applies to the dense row-aligned TwoView path (c2, c3, small)")
+        ctx.twoview_wta(0, 1, p)
+        exact_l = ctx.download_depth(0)
+        ctx.set_option("arith", 1)
+        ctx.twoview_wta(0, 1, p)
+        fma_l = ctx.download_depth(0)
+        mismatch = float((exact_l.view(np.uint64) != fma_l.view(np.uint64)).mean())
     # Depth hand-over: both maps are copied device-to-device into a staging tensor; with N > 1 ranks they are
     # gathered on rank 0 (RCCL over xGMI).  The gather of step k runs while step k+1 computes (two staging
     # buffers, async collective); everything is drained inside the timed region by fence().
@@ -407,6 +420,9 @@ def main():
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
                        "pairs_per_gpu": 1, "parallelism": ("pairs sharded, %s gather" % ("RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                        "dense_path": bool(stats["used_dense_path"]),
+                       "arithmetic": ("exact: the reference's operation order, no contraction (bit parity)" if args.arith == "exact"
+                                      else "fma: multiply-adds of the cost loops fused (opt-in, NOT the parity mode)"),
+                       "winner_mismatch_vs_exact": mismatch,
                        "n_eval_reference_last_pass": stats["n_eval"],
                        "n_eval_device_last_pass": stats["n_eval_device"]},
             # The binding roof is the vector FP64 ALU (intensity ~3e4 flop/B; SQ_INSTS_MFMA = 0).

@@ -131,12 +131,16 @@ void srh_destroy(srh_context *ctx);
 int  srh_set_stream(srh_context *ctx, void *hip_stream);
 int  srh_set_hooks(srh_context *ctx, const volatile int *cancel, srh_progress_fn progress, void *user);
 int  srh_synchronize(srh_context *ctx);
-/* Tuning / test switches (results never depend on them):
+/* Tuning / test switches (results never depend on them, "arith" excepted):
  *   "force_generic"   0 default paths; 1 never the dense row-aligned TwoView kernels nor the MVS list kernels;
  *                     2 additionally no candidate lists at all (one thread per pixel walks and costs its curve)
  *   "fused"           1: row-aligned pairs run the single fused kernel (geometry + cost + WTA per 16-pixel tile
  *                     in LDS: no cost rows or candidate lists in device memory); 0 (default): the three-kernel form
  *                     (cost rows staged in device memory, separate scan), which is the faster one on MI355X today
+ *   "arith"           0 (default): the reference's arithmetic, operation by operation (bit parity).  1: opt-in "fma"
+ *                     mode -- the multiply-adds of the dense cost loops are fused (half the FP64 instructions);
+ *                     costs move in their last bits, a winner can change only between near-tied candidates
+ *                     (mismatch rate measured by bench.py --arith fma).  THE ONE OPTION THAT CHANGES RESULTS.
  *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
  *                     not only for rigs the host check accepts (the device verifies every candidate and the
  *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)

@@ -83,6 +83,7 @@ struct srh_context {
 	bool profiling = false;
 	bool force_generic = false;
  	bool use_fused = false;                             // option "fused": single fused kernel for row-aligned pairs
+	int arith = 0;                                      // option "arith": 0 = the reference's arithmetic, 1 = fused multiply-add in the dense cost loops
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
@@ -437,6 +438,10 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "list_rows")) { c->list_rows = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "fused")) { c->use_fused = value != 0; return SRH_OK; }
+	if (!strcmp(name, "arith")) {
+		if (value != 0 && value != 1) return fail(SRH_E_INVALID, "arith must be 0 (exact) or 1 (fma)");
+		c->arith = (int)value; return SRH_OK;
+	}
 	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
@@ -655,7 +660,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 
 	c->last_fused = false;
 	// ---- row-aligned rig whose candidate range fits an LDS cost row: one fused kernel per band (srh_fused.hip)
-	if (dense && c->use_fused && p->num_depth_levels <= SRH_FUSED_MAXC &&
+	if (dense && c->use_fused && c->arith == 0 && p->num_depth_levels <= SRH_FUSED_MAXC &&
 	    fx_bx*p->image_scale*fabs(1.0/p->min_depth - 1.0/p->max_depth) + 1.0 <= (double)SRH_FUSED_MAXC) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
@@ -812,7 +817,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 			if (dense) {
 				{ Scope s(c, "twoview_dense_cost_kernel");
 				  launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-				                            c->tnum, c->cost, cstride, c->d_cnt); }
+				                            c->tnum, c->cost, cstride, c->d_cnt, c->arith); }
 				{ Scope s(c, "twoview_scan_kernel");
 				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
 				                      c->wbuf, wstride, c->d_cnt); }

@@ -293,7 +293,12 @@ __device__ __noinline__ double dense_cost_general(const DenseSmem<R, DC_NCB, DC_
 	return (v < max_color_diff) ? v : max_color_diff;
 }
 
-template <int R, int DC_NCB, int DC_CHUNK, int MINW>
+// FMA = false: the reference's arithmetic, operation by operation (the default and the parity mode).
+// FMA = true : the opt-in "fma" mode (option "arith" = 1): the same sums with every multiply-add of the block loops
+// fused (one rounding instead of two): half the FP64 instructions, costs differ from the reference's in the last
+// bits (|delta cost| ~ 1e-13), which can flip a winner only between near-tied candidates -- the mismatch rate is
+// measured, not assumed (bench.py --arith fma, tests/test_gpu_arith_modes.py).
+template <int R, int DC_NCB, int DC_CHUNK, int MINW, bool FMA>
 __global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
@@ -540,12 +545,17 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 						for (int col = 0; col < WS; ++col) {
 							// products first, sums second: no instruction waits on its predecessor, so a
 							// wave keeps the FP64 pipe full even when it is alone on its SIMD
-							double pr[DC_NCB];
+							if (FMA) {
 #pragma unroll
-							for (int j = 0; j < DC_NCB; ++j) pr[j] = wv[col]*r[col + j];
-							__builtin_amdgcn_sched_barrier(0);
+								for (int j = 0; j < DC_NCB; ++j) acc[j] = __builtin_fma(wv[col], r[col + j], acc[j]);
+							} else {
+								double pr[DC_NCB];
 #pragma unroll
-							for (int j = 0; j < DC_NCB; ++j) acc[j] += pr[j];            // meanR += weight*gray
+								for (int j = 0; j < DC_NCB; ++j) pr[j] = wv[col]*r[col + j];
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int j = 0; j < DC_NCB; ++j) acc[j] += pr[j];        // meanR += weight*gray
+							}
 							__builtin_amdgcn_sched_barrier(0);              // keep each refill where it is written
 							if (col & 1) {                                  // r[col-1], r[col], wv[col-1], wv[col] are dead
 								const double2 v = rp[col >> 1]; r[col - 1] = v.x; r[col] = v.y;
@@ -572,6 +582,15 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
 							const double wt = wv[col];
+							if (FMA) {
+								const double a = __builtin_fma(wt, av[col], -mL);
+								double bb[DC_NCB];
+#pragma unroll
+								for (int j = 0; j < DC_NCB; ++j) bb[j] = __builtin_fma(wt, r[col + j], -mR[j]);
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int j = 0; j < DC_NCB; ++j) { s1[j] = __builtin_fma(a, bb[j], s1[j]); s3[j] = __builtin_fma(bb[j], bb[j], s3[j]); }
+							} else {
 							double bb[DC_NCB], u1[DC_NCB], u3[DC_NCB];
 							const double pa = wt*av[col];
 #pragma unroll
@@ -586,6 +605,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 							__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 							for (int j = 0; j < DC_NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+							}
 							__builtin_amdgcn_sched_barrier(0);
 							av[col] = lp[col];
 							if (col & 1) {
@@ -654,7 +674,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #undef SRH_STAMP
 }
 
-template <int R, int NCB, int CHUNK, int MINW>
+template <int R, int NCB, int CHUNK, int MINW, bool FMA>
 static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
                                  int y0, int nrows, const double *wbuf, size_t wstride,
                                  const double *tnum, double *cost, int cstride, Counters *cnt)
@@ -662,25 +682,25 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
 	typedef DenseSmem<R, NCB, CHUNK> Smem;
 	// a function attribute belongs to the CURRENT device: set it on every launch (a host-side table update),
 	// so contexts on several GPUs of one process all get their dynamic LDS
-	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>,
+	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>,
 	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW>), grid, dim3(DC_THREADS), sizeof(Smem), st,
+	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>), grid, dim3(DC_THREADS), sizeof(Smem), st,
 	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt);
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const double *tnum, double *cost, int cstride, Counters *cnt)
+                               const double *tnum, double *cost, int cstride, Counters *cnt, int arith)
 {
 	const int tiles = (width + DC_TP - 1)/DC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
 #define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt
 	switch (P.window_radius) {
 	case 5:
-		launch_dense_variant<5, 8, 320, 2>(SRH_ARGS);
+		if (arith == 1) launch_dense_variant<5, 8, 320, 2, true>(SRH_ARGS); else launch_dense_variant<5, 8, 320, 2, false>(SRH_ARGS);
 		return true;
 	case 2:
-		launch_dense_variant<2, 8, 320, 2>(SRH_ARGS);
+		if (arith == 1) launch_dense_variant<2, 8, 320, 2, true>(SRH_ARGS); else launch_dense_variant<2, 8, 320, 2, false>(SRH_ARGS);
 		return true;
 	default: return false;
 	}

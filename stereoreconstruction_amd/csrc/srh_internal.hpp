@@ -86,7 +86,7 @@ bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int widt
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const double *tnum, double *cost, int cstride, Counters *cnt);
+                               const double *tnum, double *cost, int cstride, Counters *cnt, int arith = 0);
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          const double *wbuf, size_t wstride, Counters *cnt);
