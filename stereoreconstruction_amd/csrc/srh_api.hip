@@ -66,6 +66,7 @@ struct srh_context {
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
 	double *tnum = nullptr;   size_t tnum_cap = 0;      // per-label table of the pinhole walk
+	double *pconst = nullptr; size_t pconst_cap = 0;    // per-pixel constants of the dense kernel's fast form (4 doubles per pixel of a band)
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
@@ -412,6 +413,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->wbuf) hipFree(c->wbuf);
 	if (c->cost) hipFree(c->cost);
 	if (c->tnum) hipFree(c->tnum);
+	if (c->pconst) hipFree(c->pconst);
 	if (c->lcount) hipFree(c->lcount);
 	if (c->lcand) hipFree(c->lcand);
 	if (c->lrowinfo) hipFree(c->lrowinfo);
@@ -598,13 +600,14 @@ static int fetch_counters(srh_context *c, int used_dense) {
 }
 
 // support windows of rows [by, by+nr) of view `ref` into c->wbuf
-static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int by, int nr, size_t wstride) {
+static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int by, int nr, size_t wstride,
+                        double *pconst = nullptr) {
 	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic) {
 		Scope s(c, "geodesic_reg_kernel");
-		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride)) return;
+		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride, pconst)) return;
 	}
 	Scope s(c, "weights_kernel");
-	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride);
+	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride, pconst);
 }
 
 // Can every epipolar curve of `a` in `b` stay on its own image row?  Undistorted, non-refractive
@@ -809,15 +812,16 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		const size_t wstride = SRH_WTILE;
 		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
 		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*(size_t)((W + 31)/32)*32*(size_t)cstride))) return rc;   // 32-pixel tiles
+		if (dense && (rc = ensure(c->pconst, c->pconst_cap, rows*(size_t)W*4))) return rc;
 
 		for (int by = y0; by < y1; by += (int)rows) {
 			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 			const int nr = std::min((int)rows, y1 - by);
-			run_weights(c, ref, W, *p, by, nr, wstride);
+			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr);
 			if (dense) {
 				{ Scope s(c, "twoview_dense_cost_kernel");
 				  launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-				                            c->tnum, c->cost, cstride, c->d_cnt, c->arith); }
+				                            c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith); }
 				{ Scope s(c, "twoview_scan_kernel");
 				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
 				                      c->wbuf, wstride, c->d_cnt); }

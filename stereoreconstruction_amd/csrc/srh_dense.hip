@@ -58,7 +58,8 @@ void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, doub
 template <int R>
 __global__ __launch_bounds__(GW_TW)
 void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const double *__restrict__ edges,
-                         srh_params P, int y0, int nrows, double *__restrict__ wbuf, size_t wstride)
+                         srh_params P, int y0, int nrows, double *__restrict__ wbuf, size_t wstride,
+                         double *__restrict__ pconst)
 {
 	constexpr int WS = 2*R + 1;
 	constexpr int TWD = GW_TW + 2*R;            // tile width
@@ -72,7 +73,15 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 	if (trow >= nrows) return;
 
 	__shared__ double eE[WS][TWD], eS[WS][TWD], eSE[WS][TWD], eSW[WS][TWD];
+	__shared__ double gt[WS][TWD];                           // the view's TwoView tap values (NaN = unusable), for pconst
 	const double inf = __builtin_inf();
+	if (pconst) {
+		for (int idx = threadIdx.x; idx < WS*TWD; idx += GW_TW) {
+			const int ty = idx / TWD, tx = idx % TWD;
+			const int gx = x0 - R + tx, gy = cy - R + ty;
+			gt[ty][tx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? V.gray_tv[(size_t)gy*W + gx] : __builtin_nan("");
+		}
+	}
 	{
 		// all global loads of the thread first, LDS stores after: one memory latency per tile
 		constexpr int NB = (WS*TWD + GW_TW - 1)/GW_TW;
@@ -171,20 +180,48 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 #pragma unroll
 	for (int a = 0; a < WS; ++a) {
 #pragma unroll
-		for (int b = 0; b < WS; ++b)
-			wb[(size_t)(a*WS + b)*wstride] = exp(-w[a][b] / P.geodesic_sigma);
+		for (int b = 0; b < WS; ++b) {
+			w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
+			wb[(size_t)(a*WS + b)*wstride] = w[a][b];
+		}
 		asm volatile("" ::: "memory");
+	}
+	if (pconst) {
+		// Per-pixel constants of the dense kernel's fast cost form, while the window is in registers: when every tap
+		// is usable (gray value valid, weight above the cut-off), meanL, totalWeight and sum2 of
+		// twoviewstereo.cpp:917-976 do not depend on the candidate.  Same tap order, same operations.
+		bool all = true;
+		double mL = 0, tw = 0;
+#pragma unroll
+		for (int a = 0; a < WS; ++a)
+#pragma unroll
+			for (int b = 0; b < WS; ++b) {
+				const double gl = gt[a][i + b];
+				if (!(gl == gl && w[a][b] > P.weight_cutoff)) all = false;
+				mL += w[a][b]*gl;
+				tw += w[a][b];
+			}
+		double s2 = 0;
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+#pragma unroll
+			for (int a = 0; a < WS; ++a)
+#pragma unroll
+				for (int b = 0; b < WS; ++b) { const double t = w[a][b]*gt[a][i + b] - mL; s2 += t*t; }
+		} else all = false;
+		double *pc = pconst + ((size_t)trow*W + cx)*4;
+		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
 	}
 }
 
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
-                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride)
+                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst)
 {
 	const int tiles = (width + GW_TW - 1)/GW_TW;
 	const dim3 grid((unsigned)(tiles*nrows)), block(GW_TW);
 	switch (P.window_radius) {
-	case 5: hipLaunchKernelGGL(geodesic_reg_kernel<5>, grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride); return true;
-	case 2: hipLaunchKernelGGL(geodesic_reg_kernel<2>, grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride); return true;
+	case 5: hipLaunchKernelGGL(geodesic_reg_kernel<5>, grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst); return true;
+	case 2: hipLaunchKernelGGL(geodesic_reg_kernel<2>, grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst); return true;
 	default: return false;
 	}
 }
@@ -303,7 +340,7 @@ __global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                                const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
-                               Counters *__restrict__ cnt)
+                               Counters *__restrict__ cnt, const double *__restrict__ pconst)
 {
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
@@ -416,31 +453,16 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	__syncthreads();
 	SRH_STAMP(1);
 
-	// ---- per-pixel constants of the fast form (one lane per pixel) ...
+	// ---- per-pixel constants of the fast form: computed by the weights kernel while the window was in registers
+	// (geodesic_reg_kernel / weights_kernel, `pconst`), 4 doubles per pixel
 	if (g == 0) {
 		bool all = (x < W) && (e.xmax >= e.xmin);
-		double mL = 0, tw = 0;
-#pragma unroll 1
-		for (int row = 0; row < WS; ++row)
-#pragma unroll
-			for (int col = 0; col < WS; ++col) {
-				const double gl = S.lt[row][i + col];
-				const double wt = S.w[i][row*WP + col];
-				if (!(gl == gl && wt > P.weight_cutoff)) all = false;
-				mL += wt*gl;
-				tw += wt;
-			}
-		double s2 = 0;
-		if (all && !(tw < 1e-10)) {
-			mL /= tw;
-#pragma unroll 1
-			for (int row = 0; row < WS; ++row)
-#pragma unroll
-				for (int col = 0; col < WS; ++col) {
-					const double a = S.w[i][row*WP + col]*S.lt[row][i + col] - mL;
-					s2 += a*a;
-				}
-		} else all = false;
+		double mL = 0, tw = 0, s2 = 0;
+		if (all) {
+			const double *pc = pconst + ((size_t)trow*W + x)*4;
+			mL = pc[0]; tw = pc[1]; s2 = pc[2];
+			all = pc[3] != 0.0;
+		}
 		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
 		if (!all && x < W && e.xmax >= e.xmin) s_need_pix = 1;      // this pixel needs the general form
 	}
@@ -677,7 +699,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 template <int R, int NCB, int CHUNK, int MINW, bool FMA>
 static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
                                  int y0, int nrows, const double *wbuf, size_t wstride,
-                                 const double *tnum, double *cost, int cstride, Counters *cnt)
+                                 const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst)
 {
 	typedef DenseSmem<R, NCB, CHUNK> Smem;
 	// a function attribute belongs to the CURRENT device: set it on every launch (a host-side table update),
@@ -685,16 +707,16 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
 	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>,
 	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
 	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>), grid, dim3(DC_THREADS), sizeof(Smem), st,
-	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt);
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst);
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const double *tnum, double *cost, int cstride, Counters *cnt, int arith)
+                               const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith)
 {
 	const int tiles = (width + DC_TP - 1)/DC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
-#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt
+#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst
 	switch (P.window_radius) {
 	case 5:
 		if (arith == 1) launch_dense_variant<5, 8, 320, 2, true>(SRH_ARGS); else launch_dense_variant<5, 8, 320, 2, false>(SRH_ARGS);

@@ -67,8 +67,10 @@ struct Extent { int32_t xmin, xmax; };
 void launch_prep_view(hipStream_t st, const uint32_t *rgba, const uint8_t *mask, int w, int h,
                       double *gray, double *gray_tv);
 void launch_fill(hipStream_t st, double *p, size_t n, double v);
+// pconst (optional): 4 doubles per pixel of the band -- meanL, totalWeight, sum2, all-taps-usable -- the per-pixel
+// constants of the dense cost kernel's fast form, computed while the window is at hand
 void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
-                    int y0, int nrows, double *wbuf, size_t wstride);
+                    int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr);
 void launch_twoview_generic(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                             int y0, int nrows, const double *wbuf, size_t wstride, Counters *cnt);
 void launch_twoview_cross_check(hipStream_t st, const ViewDev *views, int self, int other, int w, int h,
@@ -82,11 +84,11 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 // Dense (row-aligned) TwoView path, srh_dense.hip
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
-                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride);
+                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr);
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const double *tnum, double *cost, int cstride, Counters *cnt, int arith = 0);
+                               const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          const double *wbuf, size_t wstride, Counters *cnt);

@@ -73,7 +73,7 @@ __device__ __forceinline__ double color_dist(uint32_t a, uint32_t b) {
 // Any-radius version: the window lives in the global weight buffer
 // (tile-major layout of srh_internal.hpp: wb[tap*wstride], wstride = SRH_WTILE).
 __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_params P,
-                               int y0, int nrows, double *__restrict__ wbuf, size_t wstride)
+                               int y0, int nrows, double *__restrict__ wbuf, size_t wstride, double *__restrict__ pconst)
 {
 	const ViewDev &V = views[ref];
 	const int W = V.w, H = V.h;
@@ -138,14 +138,39 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 			}
 		}
 	}
+	if (pconst) {
+		// per-pixel constants of the dense kernel's fast cost form (see geodesic_reg_kernel): same taps, same order
+		bool all = true;
+		double mL = 0, tw = 0;
+		for (int row = -R; row <= R; ++row)
+			for (int col = -R; col <= R; ++col) {
+				const int px = cx + col, py = cy + row;
+				const double gl = (px < 0 || py < 0 || px >= W || py >= H) ? __builtin_nan("") : V.gray_tv[(size_t)py*W + px];
+				const double wt = wb[(size_t)((row + R)*WS + (col + R))*wstride];
+				if (!(gl == gl && wt > P.weight_cutoff)) all = false;
+				mL += wt*gl;
+				tw += wt;
+			}
+		double s2 = 0;
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+			for (int row = -R; row <= R; ++row)
+				for (int col = -R; col <= R; ++col) {
+					const double t = wb[(size_t)((row + R)*WS + (col + R))*wstride]*V.gray_tv[(size_t)(cy + row)*W + (cx + col)] - mL;
+					s2 += t*t;
+				}
+		} else all = false;
+		double *pc = pconst + ((size_t)(q / W)*W + cx)*4;
+		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+	}
 }
 
 void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
-                    int y0, int nrows, double *wbuf, size_t wstride)
+                    int y0, int nrows, double *wbuf, size_t wstride, double *pconst)
 {
 	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(weights_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
-	                   views, ref, P, y0, nrows, wbuf, wstride);
+	                   views, ref, P, y0, nrows, wbuf, wstride, pconst);
 }
 
 // ------------------------------------------------------------------ TwoView, general geometry
