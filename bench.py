@@ -66,7 +66,8 @@ def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/), or None."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(tpath)).get(workload, {}).get(kernel)
+        t = json.load(open(tpath))
+        return t.get(workload, {}).get(kernel) or t.get(workload + "_fused", {}).get(kernel)
     except Exception:
         return None
 
@@ -76,7 +77,8 @@ def pmc_executed(workload, kernel, avg_launch_ms):
     SQ_INSTS_VALU_MUL_F64 + ADD_F64 wave-instructions per launch, x64 lanes) over the launch time measured live,
     against the no-contraction ceiling (separate multiply and add: half the FMA datasheet rate)."""
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_instr.json"))).get(workload, {}).get(kernel)
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_instr.json")))
+        e = t.get(workload, {}).get(kernel) or t.get(workload + "_fused", {}).get(kernel)
     except Exception:
         e = None
     if not e:
