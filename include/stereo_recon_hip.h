@@ -223,6 +223,23 @@ int  srh_view_point_cloud(srh_context *ctx, int slot, const srh_params *p, doubl
 int  srh_epipolar_curves(srh_context *ctx, int ref_slot, int oth_slot, const srh_params *p, int mvs,
                          int nqueries, const int32_t *xy, int32_t *out_xy, int max_pts, int32_t *counts);
 
+/* ---- GUI-side users of the camera model ----
+ * StereoWidget::epipolarLineItem (gui/widgets/stereowidget.cpp:621-672): the curve preview drawn while the user moves
+ * over the left image.  For each of the nqueries pixels xy[2q], xy[2q+1] (image coordinates as the GUI has them: no
+ * +0.5, no scale): num_depths UNIFORM depths in [min_depth, max_depth], plane Plane3d(principal direction, depth),
+ * projection into `oth_slot`; a point becomes a vertex of the path when it is more than one pixel from the last one.
+ * out_xy: nqueries*num_depths*2 doubles (the vertices of query q start at q*num_depths*2), counts[q] = vertices
+ * (0: nothing to draw).  HOST pointers. */
+int  srh_epipolar_preview(srh_context *ctx, int ref_slot, int oth_slot, double min_depth, double max_depth, int num_depths,
+                          int nqueries, const double *xy, double *out_xy, int32_t *counts);
+/* RefractionCalibration::error / totalError (stereo/refractioncalibration.cpp:175-199, 408-469): for npairs
+ * correspondences (p1 in slot1's image, p2 in slot2's): the ray-ray distance scaled to image space, per pair
+ * (err_out, may be NULL: diff()'s single component -- RefractionCalibration::error is its absolute value), the sum
+ * of its squares in pair order (*total) and total / npairs (*average, NaN for no pairs); the cameras are those
+ * uploaded with the slots (re-upload a view to try other interface parameters: the LM loop above stays host code). */
+int  srh_refraction_error(srh_context *ctx, int slot1, int slot2, int npairs, const double *p1_xy, const double *p2_xy,
+                          double *err_out, double *total, double *average);
+
 /* ---- multi-GPU exchange (RCCL over xGMI; one process and one context per GPU) ----
  * srh_comm_unique_id: rank 0 creates the 128-byte id and hands it to the other ranks by any
  * means (MPI, files, torch.distributed ...).  srh_comm_init is collective.  librccl is loaded on

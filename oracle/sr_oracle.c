@@ -1129,3 +1129,53 @@ void sro_mvs_cross_check(int nviews, const sro_image *imgs, const sro_camera *ca
 		}
 	}
 }
+
+/* ------------------------------------------------------------------ */
+/* GUI-side users of the camera model */
+
+int sro_epipolar_preview(const sro_camera *left, const sro_camera *right, double px, double py,
+                         double min_depth, double max_depth, int num_depths, double *out_xy, int max_pts)
+{
+	/* stereowidget.cpp:621-672 */
+	double src[3], dir[3];
+	sro_unproject(left, px, py, src, dir);
+	double n[3] = { left->pdir[0], left->pdir[1], left->pdir[2] };
+	normalize3(n);                                            /* Plane3d(normal, d): normal normalised */
+	int nv = 0, first = 1;
+	double p1x = NAN, p1y = 0;
+	for (int k = 0; k < num_depths; ++k) {
+		const double t = k / (num_depths - 1.0);
+		const double depth = min_depth*(1 - t) + max_depth*t;
+		double p2[3];
+		if (!intersect_plane(src, dir, n, depth, p2)) continue;
+		if (!sro_project(right, p2)) continue;
+		if (isnan(p1x)) { p1x = p2[0]; p1y = p2[1]; }
+		const double dx = p2[0] - p1x, dy = p2[1] - p1y;
+		if ((dx*dx + dy*dy) > 1) {                            /* (p2 - p1).squaredNorm() > 1; z components are both 1 */
+			if (first) {
+				if (nv < max_pts) { out_xy[2*nv] = p1x; out_xy[2*nv + 1] = p1y; }
+				++nv; first = 0;
+			}
+			if (nv < max_pts) { out_xy[2*nv] = p2[0]; out_xy[2*nv + 1] = p2[1]; }
+			++nv;
+			p1x = p2[0]; p1y = p2[1];
+		}
+	}
+	return nv;
+}
+
+double sro_refraction_pair_error(const sro_camera *v1, const sro_camera *v2, const double p1[2], const double p2[2]) {
+	/* refractioncalibration.cpp:175-199 */
+	double s1[3], d1[3], s2[3], d2[3], q1[3], q2[3];
+	sro_unproject(v1, p1[0], p1[1], s1, d1);
+	sro_unproject(v2, p2[0], p2[1], s2, d2);
+	sro_closest_points(s1, d1, s2, d2, q1, q2);
+	const double df[3] = { q1[0] - q2[0], q1[1] - q2[1], q1[2] - q2[2] };
+	const double out = sqrt(dot3(df, df));
+	const double mid[3] = { (q1[0] + q2[0])*0.5, (q1[1] + q2[1])*0.5, (q1[2] + q2[2])*0.5 };
+	const double z1 = ((v1->R[6]*mid[0] + v1->R[7]*mid[1]) + v1->R[8]*mid[2]) + v1->t[2];
+	const double z2 = ((v2->R[6]*mid[0] + v2->R[7]*mid[1]) + v2->R[8]*mid[2]) + v2->t[2];
+	const double e1 = (0.5 * v1->K[0] * out) / z1;
+	const double e2 = (0.5 * v2->K[0] * out) / z2;
+	return e1 + e2;
+}

@@ -136,6 +136,19 @@ void sro_closest_points(const double s1[3], const double d1[3], const double s2[
  * multiviewstereo.cpp:688-692).  Returns 0 when pointFromDepth fails (e.g. depth -1, the "no peak" value). */
 int  sro_back_project(const sro_camera *cam, const sro_params *p, int x, int y, double depth, double out[3]);
 
+/* StereoWidget::epipolarLineItem (gui/widgets/stereowidget.cpp:621-672), the GUI's curve preview: `num_depths` UNIFORM
+ * depths in [min_depth, max_depth]; the pixel (px,py) is unprojected as given (no +0.5, no scale); the plane of a
+ * depth is Plane3d(principal direction, depth) -- normal . x = depth in global coordinates, not the plane through the
+ * camera centre that pointFromDepth builds; a projected point becomes a vertex when it is MORE than one pixel (squared
+ * distance > 1) from the last vertex; the first projected point is the path's start.  out_xy: up to max_pts (x,y)
+ * doubles; returns the number of vertices (0: nothing drawn). */
+int  sro_epipolar_preview(const sro_camera *left, const sro_camera *right, double px, double py,
+                          double min_depth, double max_depth, int num_depths, double *out_xy, int max_pts);
+/* RefractiveCalibrationFunction::diff (stereo/refractioncalibration.cpp:175-199): the error of one correspondence
+ * (p1 in view 1, p2 in view 2): distance of the two unprojected rays, scaled to image space by 0.5*fx/z of the
+ * mid-point in both cameras.  totalError (:408-447) sums the squares. */
+double sro_refraction_pair_error(const sro_camera *v1, const sro_camera *v2, const double p1[2], const double p2[2]);
+
 /* --- epipolar curves --- */
 /* TwoViewStereo::epipolarCurve (twoviewstereo.cpp:999-1054) when mvs==0 (non-uniform
  * labels, no clipping, no de-duplication); MultiViewStereo::epipolarCurve

@@ -71,6 +71,7 @@ EXPORTS = [
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
+    "srh_epipolar_preview", "srh_refraction_error",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
     "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
@@ -119,6 +120,8 @@ def lib():
     L.srh_view_depth_download.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.srh_epipolar_preview.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p, c_int32_p]
+    L.srh_refraction_error.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.srh_view_point_cloud.argtypes = [vp, C.c_int, C.POINTER(Params), c_double_p, c_uint8_p, c_uint8_p, vp, vp, vp]
     L.srh_view_depth_copy_to_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.srh_view_depth_copy_from_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -346,6 +349,26 @@ class Context:
                                           valid.ctypes.data_as(c_uint8_p), C.cast(C.byref(n, 0), C.c_void_p),
                                           C.cast(C.byref(n, 8), C.c_void_p), C.cast(C.byref(n, 16), C.c_void_p)))
         return dict(xyz=xyz, rgb=rgb, valid=valid, n_points=int(n[0]), n_masked=int(n[1]), n_finite=int(n[2]))
+
+    def epipolar_preview(self, ref_slot, oth_slot, min_depth, max_depth, num_depths, xy):
+        """The GUI's curve preview (StereoWidget::epipolarLineItem) for the pixels `xy` (n,2) -> list of (k,2) float64."""
+        q = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        n = q.shape[0]
+        out = np.zeros((max(n, 1), num_depths, 2), dtype=np.float64)
+        counts = np.zeros(max(n, 1), dtype=np.int32)
+        _check(lib().srh_epipolar_preview(self._h, ref_slot, oth_slot, C.c_double(min_depth), C.c_double(max_depth),
+                                          num_depths, n, _dptr(q), _dptr(out), counts.ctypes.data_as(c_int32_p)))
+        return [out[i, :counts[i]].copy() for i in range(n)]
+
+    def refraction_error(self, slot1, slot2, p1, p2):
+        """RefractionCalibration::error per pair and totalError -> (errors (n,), total, average)."""
+        a = np.ascontiguousarray(p1, dtype=np.float64).reshape(-1, 2)
+        b = np.ascontiguousarray(p2, dtype=np.float64).reshape(-1, 2)
+        assert a.shape == b.shape
+        err = np.zeros(max(len(a), 1), dtype=np.float64)
+        tot, avg = C.c_double(0), C.c_double(0)
+        _check(lib().srh_refraction_error(self._h, slot1, slot2, len(a), _dptr(a), _dptr(b), _dptr(err), C.byref(tot), C.byref(avg)))
+        return err[:len(a)].copy(), tot.value, avg.value
 
     def epipolar_curves(self, ref_slot, oth_slot, p, xy, mvs=False, max_pts=4096):
         """Candidate pixels of each reference pixel in `xy` (n,2), in the reference's visiting order

@@ -1056,6 +1056,57 @@ extern "C" int srh_epipolar_curves(srh_context *c, int ref, int oth, const srh_p
 	return SRH_OK;
 }
 
+// ------------------------------------------------------------------ GUI-side users of the camera model
+extern "C" int srh_epipolar_preview(srh_context *c, int ref, int oth, double zmin, double zmax, int nd,
+                                    int nq, const double *xy, double *out_xy, int32_t *counts)
+{
+	int rc;
+	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true))) return rc;
+	if (nd < 2 || nq < 0 || (nq > 0 && (!xy || !out_xy || !counts))) return fail(SRH_E_INVALID, "bad preview arguments");
+	if (nq == 0) return SRH_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t nout = (size_t)nq*nd*2;
+	// scratch in the band buffer: [xy | out | counts]
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, (size_t)2*nq + nout + (size_t)(nq + 1)/2 + 2))) return rc;
+	double *d_xy = c->wbuf, *d_out = c->wbuf + 2*(size_t)nq;
+	int32_t *d_cnt = reinterpret_cast<int32_t *>(d_out + nout);
+	HIP_TRY(hipMemcpyAsync(d_xy, xy, (size_t)2*nq*sizeof(double), hipMemcpyHostToDevice, c->stream));
+	{ Scope s(c, "epipolar_preview_kernel");
+	  launch_epipolar_preview(c->stream, c->d_views, ref, oth, zmin, zmax, nd, nq, d_xy, d_out, d_cnt); }
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out_xy, d_out, nout*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(counts, d_cnt, (size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return SRH_OK;
+}
+
+extern "C" int srh_refraction_error(srh_context *c, int v1, int v2, int n, const double *p1, const double *p2,
+                                    double *err_out, double *total, double *average)
+{
+	int rc;
+	if ((rc = check_slot(c, v1, true)) || (rc = check_slot(c, v2, true))) return rc;
+	if (n < 0 || (n > 0 && (!p1 || !p2))) return fail(SRH_E_INVALID, "bad correspondence arguments");
+	HIP_TRY(hipSetDevice(c->device));
+	std::vector<double> err((size_t)n);
+	if (n > 0) {
+		if ((rc = ensure(c->wbuf, c->wbuf_cap, (size_t)5*n))) return rc;
+		double *d1 = c->wbuf, *d2 = c->wbuf + 2*(size_t)n, *de = c->wbuf + 4*(size_t)n;
+		HIP_TRY(hipMemcpyAsync(d1, p1, (size_t)2*n*sizeof(double), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(d2, p2, (size_t)2*n*sizeof(double), hipMemcpyHostToDevice, c->stream));
+		{ Scope s(c, "refraction_error_kernel");
+		  launch_refraction_error(c->stream, c->d_views, v1, v2, n, d1, d2, de); }
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(err.data(), de, (size_t)n*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	double tot = 0.0;                                             // totalError: summed in correspondence order (:440)
+	for (int i = 0; i < n; ++i) tot += err[i]*err[i];
+	if (err_out) for (int i = 0; i < n; ++i) err_out[i] = err[i];
+	if (total) *total = tot;
+	if (average) *average = tot / n;
+	return SRH_OK;
+}
+
 // ------------------------------------------------------------------ multi-GPU exchange
 extern "C" int srh_comm_unique_id(void *id_out) {
 	if (!id_out) return fail(SRH_E_INVALID, "null id buffer");

@@ -119,6 +119,9 @@ void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const i
                           double *unit_peaks, double *peaks);
 void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, int h, const srh_params &P,
                         double *xyz, uint8_t *rgb, uint8_t *valid, unsigned long long *counts);
+void launch_epipolar_preview(hipStream_t st, const ViewDev *views, int ref, int oth, double zmin, double zmax, int nd,
+                             int nq, const double *xy, double *out, int32_t *counts);
+void launch_refraction_error(hipStream_t st, const ViewDev *views, int v1, int v2, int n, const double *p1, const double *p2, double *err);
 void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int mvs,
                             int nq, const int32_t *xy, int32_t *out, int cap, int32_t *counts);
 

@@ -320,6 +320,67 @@ void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, i
 	hipLaunchKernelGGL(point_cloud_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, slot, P, xyz, rgb, valid, counts);
 }
 
+// ------------------------------------------------------------------ GUI-side users of the camera model
+// StereoWidget::epipolarLineItem (gui/widgets/stereowidget.cpp:621-672): one thread per queried pixel
+__global__ void epipolar_preview_kernel(const ViewDev *__restrict__ views, int ref, int oth, double min_depth, double max_depth,
+                                        int num_depths, int nq, const double *__restrict__ xy, double *__restrict__ out,
+                                        int32_t *__restrict__ counts)
+{
+	const int q = blockIdx.x*blockDim.x + threadIdx.x;
+	if (q >= nq) return;
+	const srh_camera &L = views[ref].cam, &Rc = views[oth].cam;
+	const Ray ray = cam_unproject(L, xy[2*q], xy[2*q + 1]);           // the pixel as given: no +0.5, no scale
+	const Vec3 n = normalized(load3(L.pdir));                           // Plane3d(direction, depth)
+	double *o = out + (size_t)q*2*num_depths;
+	int nv = 0;
+	bool first = true;
+	double p1x = __builtin_nan(""), p1y = 0;
+	for (int k = 0; k < num_depths; ++k) {
+		const double t = k / (num_depths - 1.0);
+		const double depth = min_depth*(1 - t) + max_depth*t;
+		Vec3 p2;
+		if (!intersect_plane(ray, n, depth, p2)) continue;
+		if (!cam_project(Rc, p2)) continue;
+		if (isnan_d(p1x)) { p1x = p2.x; p1y = p2.y; }
+		const double dx = p2.x - p1x, dy = p2.y - p1y;
+		if ((dx*dx + dy*dy) > 1) {
+			if (first) { o[2*nv] = p1x; o[2*nv + 1] = p1y; ++nv; first = false; }
+			o[2*nv] = p2.x; o[2*nv + 1] = p2.y; ++nv;
+			p1x = p2.x; p1y = p2.y;
+		}
+	}
+	counts[q] = nv;
+}
+
+// RefractiveCalibrationFunction::diff (stereo/refractioncalibration.cpp:175-199): one thread per correspondence
+__global__ void refraction_error_kernel(const ViewDev *__restrict__ views, int v1, int v2, int n,
+                                        const double *__restrict__ p1, const double *__restrict__ p2, double *__restrict__ err)
+{
+	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const srh_camera &A = views[v1].cam, &B = views[v2].cam;
+	const Ray R1 = cam_unproject(A, p1[2*i], p1[2*i + 1]);
+	const Ray R2 = cam_unproject(B, p2[2*i], p2[2*i + 1]);
+	Vec3 q1, q2;
+	closest_points(R1, R2, q1, q2);
+	const double out = norm(q1 - q2);
+	const Vec3 mid = (q1 + q2)*0.5;
+	const double e1 = (0.5 * A.K[0] * out) / cam_local_z(A, mid);
+	const double e2 = (0.5 * B.K[0] * out) / cam_local_z(B, mid);
+	err[i] = e1 + e2;
+}
+
+void launch_epipolar_preview(hipStream_t st, const ViewDev *views, int ref, int oth, double zmin, double zmax, int nd,
+                             int nq, const double *xy, double *out, int32_t *counts)
+{
+	hipLaunchKernelGGL(epipolar_preview_kernel, dim3((unsigned)((nq + 63)/64)), dim3(64), 0, st, views, ref, oth, zmin, zmax, nd, nq, xy, out, counts);
+}
+
+void launch_refraction_error(hipStream_t st, const ViewDev *views, int v1, int v2, int n, const double *p1, const double *p2, double *err)
+{
+	hipLaunchKernelGGL(refraction_error_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st, views, v1, v2, n, p1, p2, err);
+}
+
 // ------------------------------------------------------------------ MVS, general geometry
 struct MvsVisitor {
 	const ViewDev &A, &B;

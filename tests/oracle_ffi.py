@@ -92,6 +92,10 @@ def lib():
     L.sro_project.argtypes = [C.POINTER(Camera), c_double_p]
     L.sro_project.restype = C.c_int
     L.sro_closest_points.argtypes = [c_double_p] * 6
+    L.sro_epipolar_preview.argtypes = [C.POINTER(Camera), C.POINTER(Camera), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_double_p, C.c_int]
+    L.sro_epipolar_preview.restype = C.c_int
+    L.sro_refraction_pair_error.argtypes = [C.POINTER(Camera), C.POINTER(Camera), c_double_p, c_double_p]
+    L.sro_refraction_pair_error.restype = C.c_double
     L.sro_back_project.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_int, C.c_int, C.c_double, c_double_p]
     L.sro_back_project.restype = C.c_int
     L.sro_epipolar_curve.argtypes = [C.POINTER(Camera), C.POINTER(Camera), C.POINTER(Image),
@@ -222,6 +226,20 @@ def line_points(x0, y0, x1, y1, clip=False, w=0, h=0, cap=1 << 16, bounded=False
     out = np.empty((cap, 2), dtype=np.int32)
     n = lib().sro_line_points(x0, y0, x1, y1, 2 if bounded else int(clip), w, h, iptr(out), cap)
     return out[:min(n, cap)].copy()
+
+
+def epipolar_preview(refcam, othcam, px, py, min_depth, max_depth, num_depths):
+    """StereoWidget::epipolarLineItem: the vertices (k,2) of the previewed path (k == 0: nothing drawn)."""
+    out = np.empty((num_depths, 2), dtype=np.float64)
+    n = lib().sro_epipolar_preview(C.byref(refcam), C.byref(othcam), px, py, min_depth, max_depth, num_depths,
+                                   dptr(out), num_depths)
+    return out[:n].copy()
+
+
+def refraction_pair_error(cam1, cam2, p1, p2):
+    a = np.ascontiguousarray(p1, dtype=np.float64)
+    b = np.ascontiguousarray(p2, dtype=np.float64)
+    return lib().sro_refraction_pair_error(C.byref(cam1), C.byref(cam2), dptr(a), dptr(b))
 
 
 def epipolar_curve(refcam, othcam, oth, p, mvs, x, y, cap=1 << 16):

@@ -546,3 +546,42 @@ def mvs_cross_check_pixel(P, cams, depth_maps, view, x, y):
         if math.isfinite(nrm) and nrm < P.cross_check:
             return depth
     return NaN
+
+
+# ------------------------------------------------------------------ gui/widgets/stereowidget.cpp:621-672
+def epipolar_preview(left, right, px, py, min_depth, max_depth, num_depths):
+    """The path the GUI draws over the right image for the pixel under the cursor: list of (x, y)."""
+    ray = left.unproject(px, py)
+    path, p1 = [], None
+    for k in range(num_depths):
+        t = k / (num_depths - 1.0)
+        depth = min_depth * (1 - t) + max_depth * t
+        pt = intersect(ray, Plane(left.pdir, dist=depth))
+        if pt is None:
+            continue
+        p2 = right.project(pt)
+        if p2 is None:
+            continue
+        if p1 is None:
+            p1 = p2
+        d = (p2[0] - p1[0], p2[1] - p1[1])
+        if d[0] * d[0] + d[1] * d[1] > 1:
+            if not path:
+                path.append((p1[0], p1[1]))
+            path.append((p2[0], p2[1]))
+            p1 = p2
+    return path
+
+
+# ------------------------------------------------------------------ stereo/refractioncalibration.cpp:175-199
+def refraction_pair_error(view1, view2, p1, p2):
+    r1 = view1.unproject(p1[0], p1[1])
+    r2 = view2.unproject(p2[0], p2[1])
+    if r1 is None or r2 is None:
+        return float("nan")
+    c1, c2 = closest_points(r1, r2)
+    out = math.sqrt(float((c1 - c2) @ (c1 - c2)))
+    mid = (c1 + c2) * 0.5
+    e1 = (0.5 * view1.K[0, 0] * out) / view1.to_local(mid)[2]
+    e2 = (0.5 * view2.K[0, 0] * out) / view2.to_local(mid)[2]
+    return e1 + e2

@@ -197,3 +197,30 @@ def test_mvs_pixels_agree(name, over, npix):
             assert _close(float(work[v][y, x]), got), (name, v, x, y, work[v][y, x], got)
             n_checked += 1
     assert n_checked >= 10
+
+
+def test_gui_curve_preview_and_refraction_error_agree():
+    """StereoWidget::epipolarLineItem (stereowidget.cpp:621-672) and RefractiveCalibrationFunction::diff
+    (refractioncalibration.cpp:175-199): same vertices / same errors from both readings."""
+    for name in ("geodesic_verged_dist_masks", "adaptive_refractive", "geodesic_rect"):
+        case = cases.get_twoview(name)
+        _, ocams, _ = cases.oracle_inputs(case)
+        _, _, cams, P = _scene(case)
+        h, w = case["views"][0][0].shape[:2]
+        before = S2.AMBIGUOUS_PROJECTIONS
+        for (x, y) in _pixels(w, h, 12, 77):
+            for nd in (2, 37, 500):
+                S2.AMBIGUOUS_PROJECTIONS = 0
+                want = S2.epipolar_preview(cams[0], cams[1], x, y, P.min_depth, P.max_depth, nd)
+                if S2.AMBIGUOUS_PROJECTIONS:
+                    continue
+                got = O.epipolar_preview(ocams[0], ocams[1], x, y, P.min_depth, P.max_depth, nd)
+                assert len(got) == len(want), (name, x, y, nd)
+                for g, s in zip(got, want):
+                    assert _close(g[0], s[0], 1e-9) and _close(g[1], s[1], 1e-9)
+        rng = np.random.default_rng(5)
+        for _ in range(40):
+            p1 = rng.uniform(0, [w, h]); p2 = rng.uniform(0, [w, h])
+            assert _close(O.refraction_pair_error(ocams[0], ocams[1], p1, p2),
+                          S2.refraction_pair_error(cams[0], cams[1], p1, p2), 1e-9)
+        S2.AMBIGUOUS_PROJECTIONS = before
