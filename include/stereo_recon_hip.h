@@ -200,6 +200,38 @@ int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *ne
 int  srh_mvs_cross_check(srh_context *ctx, const int32_t *slots, int nviews, int view_index,
                          const srh_params *p);
 
+/* ---- MultiViewStereo, MRF branch ----
+ * What computeInitialEstimate does with the top-K peaks when the reference is built with CONFIG+=mrf
+ * (multiviewstereo.cpp:481-516 cost functions, :610-652 optimisation and label -> depth): a W x H grid, K + 1 labels
+ * (the K peaks of each pixel + "unknown"), sequential TRW-S sweeps until the energy drops by no more than
+ * min_energy_drop or max_iters + 1 sweeps were made, then depth = the chosen peak's depth (INF for "unknown" or a
+ * placeholder peak) where the mask is WHITE.  PARITY UNPINNED: the reference takes the optimiser from a third-party
+ * library (-lMRF) that is not in its tree; DESIGN.md 5 says what was restated instead. */
+typedef struct srh_mrf_params {
+	double  beta, lambda;         /* BETA 1, LAMBDA 1 (multiviewstereo.cpp:98-99) */
+	double  phi_u, psi_u;         /* PHIU 0.5, PSIU 0.002 (:100-101) */
+	int32_t max_iters;            /* 50 (:631) */
+	double  min_energy_drop;      /* 5 (:641) */
+} srh_mrf_params;
+typedef struct srh_mrf_info {
+	int32_t iterations;           /* sweeps made */
+	double  energy_initial;       /* totalEnergy() of the all-zero labelling */
+	double  energy_final;
+} srh_mrf_info;
+void srh_mrf_params_defaults(srh_mrf_params *m);
+/* peaks_dev: the DEVICE buffer srh_mvs_initial_estimate filled for this view (w*h*top_k (cost, depth) pairs),
+ * 1 <= top_k <= 15.  Writes the slot's depth map.  info may be NULL. */
+int  srh_mvs_mrf_estimate(srh_context *ctx, int view_slot, int top_k, const void *peaks_dev,
+                          const srh_mrf_params *m, srh_mrf_info *info);
+/* computeInitialEstimate as a CONFIG+=mrf build runs it: srh_mvs_initial_estimate with the peaks kept in the
+ * context's own scratch, then srh_mvs_mrf_estimate on them. */
+int  srh_mvs_initial_estimate_mrf(srh_context *ctx, int view_slot, const int32_t *neigh_slots, int nneigh,
+                                  const srh_params *p, const srh_mrf_params *m, srh_mrf_info *info);
+/* State of the last srh_mvs_mrf_estimate on this context, to HOST buffers (each may be NULL): labels (w*h, what
+ * getLabel(p) returns), data_costs (w*h*(top_k+1)), messages (w*h*2*(top_k+1): [pixel][towards x+1, towards y+1][label],
+ * the message currently stored on that edge). */
+int  srh_mvs_mrf_state(srh_context *ctx, int32_t *labels, double *data_costs, double *messages);
+
 /* ---- depth map -> point cloud ----
  * The output side of the path (the reference keeps only the PLY writer, multiviewstereo.cpp:291-315,
  * and the per-view coverage figure it logs, :402-421).  For every pixel of `slot` whose mask is WHITE and whose depth is

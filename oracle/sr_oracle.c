@@ -1179,3 +1179,148 @@ double sro_refraction_pair_error(const sro_camera *v1, const sro_camera *v2, con
 	const double e2 = (0.5 * v2->K[0] * out) / z2;
 	return e1 + e2;
 }
+
+/* ------------------------------------------------------------------ */
+/* MRF branch of MultiViewStereo::computeInitialEstimate -- PARITY UNPINNED, see sr_oracle.h */
+
+void sro_mrf_params_defaults(sro_mrf_params *m) {
+	m->beta = 1; m->lambda = 1; m->phi_u = 0.5; m->psi_u = 0.002;      /* multiviewstereo.cpp:98-101 */
+	m->max_iters = 50; m->min_energy_drop = 5;                        /* :631, :641 */
+}
+
+double sro_mrf_data_cost(const sro_mrf_params *m, int K, const double *pk, int label) {
+	/* multiviewstereo.cpp:485-497 */
+	if (label == K) return m->phi_u;
+	if (pk[2*label + 1] < 0) return m->lambda;
+	return m->lambda*exp(-m->beta * pk[2*label]);
+}
+
+double sro_mrf_smooth_cost(const sro_mrf_params *m, int K, const double *pk1, const double *pk2, int l1, int l2) {
+	/* multiviewstereo.cpp:499-514 */
+	if (l1 == K && l2 == K) return 0.0;
+	if (l1 == K || l2 == K) return m->psi_u;
+	const double z1 = pk1[2*l1 + 1], z2 = pk2[2*l2 + 1];
+	if (z1 < 0 || z2 < 0) return 2*m->psi_u;
+	return 2.0 * fabs(z1 - z2) / (z1 + z2);
+}
+
+typedef struct {
+	int w, h, K, L;
+	const double *peaks;
+	const sro_mrf_params *m;
+	double *D, *M;               /* D: n*L; M: n*2*L, [pixel][0: edge to x+1, 1: edge to y+1][label] */
+	int32_t *ans;
+} trws_t;
+
+static double trws_V(const trws_t *t, int p, int q, int lp, int lq) {
+	return sro_mrf_smooth_cost(t->m, t->K, t->peaks + (size_t)p*t->K*2, t->peaks + (size_t)q*t->K*2, lp, lq);
+}
+
+/* new message over the edge p -> q, written over the stored (reverse) message; returns the constant taken out */
+static double trws_update(const trws_t *t, double *M, const double *Di, int p, int q) {
+	const int L = t->L;
+	double buf[64], delta = 0;
+	for (int ks = 0; ks < L; ks++) buf[ks] = 0.5*Di[ks] - M[ks];
+	for (int kd = 0; kd < L; kd++) {
+		double vmin = buf[0] + trws_V(t, p, q, 0, kd);
+		for (int ks = 1; ks < L; ks++) {
+			const double v = buf[ks] + trws_V(t, p, q, ks, kd);
+			if (vmin > v) vmin = v;
+		}
+		M[kd] = vmin;
+		if (kd == 0 || delta > vmin) delta = vmin;
+	}
+	for (int kd = 0; kd < L; kd++) M[kd] -= delta;
+	return delta;
+}
+
+static void trws_gather(const trws_t *t, int x, int y, double *Di) {
+	const int L = t->L, w = t->w, h = t->h, n = y*w + x;
+	const double *M = t->M + (size_t)n*2*L;
+	for (int k = 0; k < L; k++) Di[k] = t->D[(size_t)n*L + k];
+	if (x > 0)     for (int k = 0; k < L; k++) Di[k] += (M - 2*L)[k];                 /* (x-1,y) -> (x,y) */
+	if (y > 0)     for (int k = 0; k < L; k++) Di[k] += (M - (size_t)2*w*L + L)[k];   /* (x,y-1) -> (x,y) */
+	if (x < w - 1) for (int k = 0; k < L; k++) Di[k] += M[k];                         /* (x+1,y) -> (x,y) */
+	if (y < h - 1) for (int k = 0; k < L; k++) Di[k] += (M + L)[k];                   /* (x,y+1) -> (x,y) */
+}
+
+static double trws_sweep(trws_t *t) {
+	const int L = t->L, w = t->w, h = t->h;
+	double Di[64], lower = 0;
+	for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {                         /* forward */
+		const int n = y*w + x;
+		double *M = t->M + (size_t)n*2*L;
+		trws_gather(t, x, y, Di);
+		if (x < w - 1) trws_update(t, M, Di, n, n + 1);
+		if (y < h - 1) trws_update(t, M + L, Di, n, n + w);
+	}
+	for (int y = h - 1; y >= 0; y--) for (int x = w - 1; x >= 0; x--) {               /* backward */
+		const int n = y*w + x;
+		double *M = t->M + (size_t)n*2*L;
+		trws_gather(t, x, y, Di);
+		double vmin = Di[0];
+		for (int k = 1; k < L; k++) if (vmin > Di[k]) vmin = Di[k];
+		for (int k = 0; k < L; k++) Di[k] -= vmin;
+		lower += vmin;
+		if (x > 0) lower += trws_update(t, M - 2*L, Di, n, n - 1);
+		if (y > 0) lower += trws_update(t, M - (size_t)2*w*L + L, Di, n, n - w);
+	}
+	for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {                         /* read the labels off */
+		const int n = y*w + x;
+		const double *M = t->M + (size_t)n*2*L;
+		for (int k = 0; k < L; k++) Di[k] = t->D[(size_t)n*L + k];
+		if (x > 0)     for (int k = 0; k < L; k++) Di[k] += trws_V(t, n - 1, n, t->ans[n - 1], k);
+		if (y > 0)     for (int k = 0; k < L; k++) Di[k] += trws_V(t, n - w, n, t->ans[n - w], k);
+		if (x < w - 1) for (int k = 0; k < L; k++) Di[k] += M[k];
+		if (y < h - 1) for (int k = 0; k < L; k++) Di[k] += (M + L)[k];
+		double best = Di[0];
+		int a = 0;
+		for (int k = 1; k < L; k++) if (best > Di[k]) { best = Di[k]; a = k; }
+		t->ans[n] = a;
+	}
+	return lower;
+}
+
+static double trws_energy(const trws_t *t) {
+	const int L = t->L, w = t->w, h = t->h;
+	double data = 0, smooth = 0;
+	for (int n = 0; n < w*h; n++) data += t->D[(size_t)n*L + t->ans[n]];
+	for (int y = 0; y < h; y++) for (int x = 1; x < w; x++) { const int n = y*w + x; smooth += trws_V(t, n, n - 1, t->ans[n], t->ans[n - 1]); }
+	for (int y = 1; y < h; y++) for (int x = 0; x < w; x++) { const int n = y*w + x; smooth += trws_V(t, n, n - w, t->ans[n], t->ans[n - w]); }
+	return data + smooth;
+}
+
+void sro_mvs_mrf(int w, int h, int K, const double *peaks, const uint8_t *mask, const sro_mrf_params *m,
+                 double *depth, int32_t *labels, const double *data_costs, double *messages, sro_mrf_info *info) {
+	trws_t t;
+	const int L = K + 1;
+	const size_t n = (size_t)w*h;
+	t.w = w; t.h = h; t.K = K; t.L = L; t.peaks = peaks; t.m = m;
+	t.D = (double *)malloc(n*L*sizeof(double));
+	t.M = (double *)calloc(n*2*L, sizeof(double));                     /* initialize(): messages zero */
+	t.ans = (int32_t *)calloc(n, sizeof(int32_t));                     /* clearAnswer(): label 0 */
+	if (data_costs) memcpy(t.D, data_costs, n*L*sizeof(double));
+	else for (size_t p = 0; p < n; p++) for (int l = 0; l < L; l++) t.D[p*L + l] = sro_mrf_data_cost(m, K, peaks + p*K*2, l);
+
+	/* multiviewstereo.cpp:627-641 */
+	double energy = trws_energy(&t), prev = 0.0, lower = 0.0;
+	const double e0 = energy;
+	int num_iters = m->max_iters, iters = 0;
+	do {
+		prev = energy;
+		lower = trws_sweep(&t);
+		energy = trws_energy(&t);
+		++iters;
+	} while (prev - energy > m->min_energy_drop && num_iters-- > 0);
+
+	/* :645-652 */
+	for (size_t p = 0; p < n; p++) if (!mask || mask[p]) {
+		const int label = t.ans[p];
+		const double d = (label == K ? INFINITY : peaks[(p*K + label)*2 + 1]);
+		depth[p] = d > 0 ? d : INFINITY;
+	}
+	if (labels) memcpy(labels, t.ans, n*sizeof(int32_t));
+	if (messages) memcpy(messages, t.M, n*2*L*sizeof(double));
+	if (info) { info->iterations = iters; info->energy_initial = e0; info->energy_final = energy; info->lower_bound = lower; }
+	free(t.D); free(t.M); free(t.ans);
+}

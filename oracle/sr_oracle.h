@@ -202,6 +202,37 @@ void sro_mvs_initial_estimate(int nviews, const sro_image *imgs, const sro_camer
 void sro_mvs_cross_check(int nviews, const sro_image *imgs, const sro_camera *cams, int view,
                          const sro_params *p, double *const *depths);
 
+/* ---- MRF branch of computeInitialEstimate (multiviewstereo.cpp:481-516, 610-652; CONFIG+=mrf) ----
+ * PARITY UNPINNED: the reference links a third-party library here (`LIBS *= -lMRF`, StereoReconstruction.pro:100-103,
+ * <MRF/mrf.h>: the Middlebury "MRF energy minimization software" with V. Kolmogorov's TRW-S, no version pinned, not in
+ * the reference tree, not in this image).  What follows restates the PUBLISHED algorithm (Kolmogorov, "Convergent
+ * tree-reweighted message passing for energy minimization", PAMI 2006, sequential TRW-S on a 4-connected grid,
+ * gamma = 1/2, forward then backward sweep, solution read off by a forward sweep) in the form that library's grid /
+ * general-smoothness code takes, in double; the energies, the stopping rule and the label -> depth rule are the
+ * reference's own lines.  No reference fixture or compiled reference can pin it. */
+typedef struct sro_mrf_params {
+	double  beta, lambda;         /* BETA 1, LAMBDA 1 (multiviewstereo.cpp:98-99) */
+	double  phi_u, psi_u;         /* PHIU 0.5, PSIU 0.002 (:100-101) */
+	int32_t max_iters;            /* numIters 50 (:631): at most max_iters + 1 sweeps */
+	double  min_energy_drop;      /* 5 (:641) */
+} sro_mrf_params;
+typedef struct sro_mrf_info {
+	int32_t iterations;           /* optimize(1) calls made */
+	double  energy_initial;       /* totalEnergy() after clearAnswer() */
+	double  energy_final;
+	double  lower_bound;          /* TRW-S bound of the last sweep */
+} sro_mrf_info;
+void sro_mrf_params_defaults(sro_mrf_params *m);
+/* dataCost / smoothnessCost of CostFunction (multiviewstereo.cpp:485-515); labels 0..K-1 = peaks, K = unknown */
+double sro_mrf_data_cost(const sro_mrf_params *m, int K, const double *pixel_peaks, int label);
+double sro_mrf_smooth_cost(const sro_mrf_params *m, int K, const double *peaks1, const double *peaks2, int l1, int l2);
+/* peaks: w*h*K (cost, depth) pairs as sro_mvs_initial_estimate writes them; mask: w*h (NULL = all WHITE).
+ * depth (w*h, in/out): written where mask is WHITE (:645-652).  labels (optional, w*h), data_costs (optional
+ * OVERRIDE, w*h*(K+1): when given these are used instead of evaluating dataCost -- lets a test feed the engine
+ * another exp()), messages (optional out, w*h*2*(K+1): [pixel][right, down][label]). */
+void sro_mvs_mrf(int w, int h, int K, const double *peaks, const uint8_t *mask, const sro_mrf_params *m,
+                 double *depth, int32_t *labels, const double *data_costs, double *messages, sro_mrf_info *info);
+
 #ifdef __cplusplus
 }
 #endif

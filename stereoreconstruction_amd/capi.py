@@ -53,6 +53,15 @@ class Params(C.Structure):
     ]
 
 
+class SrhMrfParams(C.Structure):
+    _fields_ = [("beta", C.c_double), ("lambda_", C.c_double), ("phi_u", C.c_double), ("psi_u", C.c_double),
+                ("max_iters", C.c_int32), ("min_energy_drop", C.c_double)]
+
+
+class SrhMrfInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("energy_initial", C.c_double), ("energy_final", C.c_double)]
+
+
 class Stats(C.Structure):
     """srh_stats"""
     _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
@@ -72,6 +81,7 @@ EXPORTS = [
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
     "srh_epipolar_preview", "srh_refraction_error",
+    "srh_mrf_params_defaults", "srh_mvs_mrf_estimate", "srh_mvs_mrf_state", "srh_mvs_initial_estimate_mrf",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
     "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
@@ -120,6 +130,11 @@ def lib():
     L.srh_view_depth_download.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_upload.argtypes = [vp, C.c_int, c_double_p]
     L.srh_view_depth_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.srh_mrf_params_defaults.argtypes = [C.POINTER(SrhMrfParams)]
+    L.srh_mrf_params_defaults.restype = None
+    L.srh_mvs_mrf_estimate.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
+    L.srh_mvs_initial_estimate_mrf.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
+    L.srh_mvs_mrf_state.argtypes = [vp, c_int32_p, c_double_p, c_double_p]
     L.srh_epipolar_preview.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p, c_int32_p]
     L.srh_refraction_error.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.srh_view_point_cloud.argtypes = [vp, C.c_int, C.POINTER(Params), c_double_p, c_uint8_p, c_uint8_p, vp, vp, vp]
@@ -163,6 +178,15 @@ def params_twoview(**kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def mrf_params(**kw):
+    """srh_mrf_params with the reference's constants (multiviewstereo.cpp:98-101, 631, 641)."""
+    m = SrhMrfParams()
+    lib().srh_mrf_params_defaults(C.byref(m))
+    for k, v in kw.items():
+        setattr(m, "lambda_" if k == "lambda" else k, v)
+    return m
 
 
 def params_mvs(**kw):
@@ -349,6 +373,30 @@ class Context:
                                           valid.ctypes.data_as(c_uint8_p), C.cast(C.byref(n, 0), C.c_void_p),
                                           C.cast(C.byref(n, 8), C.c_void_p), C.cast(C.byref(n, 16), C.c_void_p)))
         return dict(xyz=xyz, rgb=rgb, valid=valid, n_points=int(n[0]), n_masked=int(n[1]), n_finite=int(n[2]))
+
+    def mvs_mrf_estimate(self, view_slot, top_k, peaks_dev, m=None):
+        """MRF branch of computeInitialEstimate on the device peaks buffer -> dict(iterations, energy_initial, energy_final)."""
+        m = m if m is not None else mrf_params()
+        info = SrhMrfInfo()
+        _check(lib().srh_mvs_mrf_estimate(self._h, view_slot, top_k, C.c_void_p(peaks_dev), C.byref(m), C.byref(info)))
+        return dict(iterations=info.iterations, energy_initial=info.energy_initial, energy_final=info.energy_final)
+
+    def mvs_initial_estimate_mrf(self, view_slot, neigh_slots, p, m=None):
+        """computeInitialEstimate of a CONFIG+=mrf build: peaks, then TRW-S on them."""
+        m = m if m is not None else mrf_params()
+        info = SrhMrfInfo()
+        nb = np.ascontiguousarray(neigh_slots, dtype=np.int32)
+        _check(lib().srh_mvs_initial_estimate_mrf(self._h, view_slot, nb.ctypes.data_as(c_int32_p), len(nb), C.byref(p),
+                                                  C.byref(m), C.byref(info)))
+        return dict(iterations=info.iterations, energy_initial=info.energy_initial, energy_final=info.energy_final)
+
+    def mvs_mrf_state(self, w, h, top_k):
+        """(labels (h,w) int32, data_costs (h,w,K+1), messages (h,w,2,K+1)) of the last MRF run."""
+        labels = np.zeros((h, w), dtype=np.int32)
+        D = np.zeros((h, w, top_k + 1), dtype=np.float64)
+        M = np.zeros((h, w, 2, top_k + 1), dtype=np.float64)
+        _check(lib().srh_mvs_mrf_state(self._h, labels.ctypes.data_as(c_int32_p), _dptr(D), _dptr(M)))
+        return labels, D, M
 
     def epipolar_preview(self, ref_slot, oth_slot, min_depth, max_depth, num_depths, xy):
         """The GUI's curve preview (StereoWidget::epipolarLineItem) for the pixels `xy` (n,2) -> list of (k,2) float64."""

@@ -66,6 +66,9 @@ struct srh_context {
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
 	double *tnum = nullptr;   size_t tnum_cap = 0;      // per-label table of the pinhole walk
+	double *mrf_peaks = nullptr; size_t mrf_peaks_cap = 0;   // top-K peaks of srh_mvs_initial_estimate_mrf
+	double *mrf = nullptr;    size_t mrf_cap = 0;       // MRF stage scratch (srh_mrf.hip); mrf_w/h/k: what the last run left in it
+	int mrf_w = 0, mrf_h = 0, mrf_k = 0;
 	double *pconst = nullptr; size_t pconst_cap = 0;    // per-pixel constants of the dense kernel's fast form (4 doubles per pixel of a band)
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
@@ -414,6 +417,8 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->cost) hipFree(c->cost);
 	if (c->tnum) hipFree(c->tnum);
 	if (c->pconst) hipFree(c->pconst);
+	if (c->mrf) hipFree(c->mrf);
+	if (c->mrf_peaks) hipFree(c->mrf_peaks);
 	if (c->lcount) hipFree(c->lcount);
 	if (c->lcand) hipFree(c->lcand);
 	if (c->lrowinfo) hipFree(c->lrowinfo);
@@ -1053,6 +1058,94 @@ extern "C" int srh_epipolar_curves(srh_context *c, int ref, int oth, const srh_p
 	if (d_n) (void)hipFree(d_n);
 	if (d_out) (void)hipFree(d_out);
 	if (e != hipSuccess) return fail(SRH_E_DEVICE, "epipolar curves: %s", hipGetErrorString(e));
+	return SRH_OK;
+}
+
+// ------------------------------------------------------------------ MultiViewStereo, MRF branch
+extern "C" void srh_mrf_params_defaults(srh_mrf_params *m)
+{
+	if (!m) return;
+	m->beta = 1; m->lambda = 1; m->phi_u = 0.5; m->psi_u = 0.002;     // multiviewstereo.cpp:98-101
+	m->max_iters = 50; m->min_energy_drop = 5;                       // :631, :641
+}
+
+extern "C" int srh_mvs_mrf_estimate(srh_context *c, int slot, int K, const void *peaks_dev, const srh_mrf_params *m, srh_mrf_info *info)
+{
+	int rc;
+	if ((rc = check_slot(c, slot, true))) return rc;
+	if (!peaks_dev || !m) return fail(SRH_E_INVALID, "null peaks / params");
+	if (K < 1 || K > 15) return fail(SRH_E_UNSUPPORTED, "top_k %d outside [1,15] (one lane per label, 16 lanes per pixel)", K);
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	const int w = v.w, h = v.h;
+	if ((rc = ensure(c->mrf, c->mrf_cap, mrf_scratch_doubles(w, h)))) return rc;
+	c->mrf_w = c->mrf_h = c->mrf_k = 0;
+	MrfLayout lay;
+	{ Scope s(c, "mrf_data_kernel");
+	  HIP_TRY(launch_mrf_setup(c->stream, c->mrf, w, h, K, m->beta, m->lambda, m->phi_u, static_cast<const double *>(peaks_dev), lay)); }
+	struct { double energy, pad; unsigned status[4]; } hs;
+	auto energy = [&](double &e) -> int {
+		{ Scope s(c, "mrf_energy_kernel");
+		  HIP_TRY(launch_mrf_energy(c->stream, c->mrf, w, h, K, m->psi_u)); }
+		HIP_TRY(hipMemcpyAsync(&hs, lay.energy, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (hs.status[0])
+			return fail(SRH_E_DEVICE, "MRF sweep %u: band %u waited too long for the band above (hand-off never arrived)", hs.status[2], hs.status[1] - 1);
+		e = hs.energy;
+		return SRH_OK;
+	};
+	// multiviewstereo.cpp:627-641
+	double e = 0.0, prev = 0.0;
+	if ((rc = energy(e))) return rc;
+	const double e0 = e;
+	int num_iters = m->max_iters, iters = 0;
+	do {
+		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+		prev = e;
+		{ Scope s(c, "mrf_pass_kernel");
+		  HIP_TRY(launch_mrf_sweep(c->stream, c->mrf, w, h, K, m->psi_u)); }
+		if ((rc = energy(e))) return rc;
+		++iters;
+	} while (prev - e > m->min_energy_drop && num_iters-- > 0);
+	{ Scope s(c, "mrf_depth_kernel");
+	  HIP_TRY(launch_mrf_depth(c->stream, c->d_views, slot, c->mrf, w, h, K)); }
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->mrf_w = w; c->mrf_h = h; c->mrf_k = K;
+	if (info) { info->iterations = iters; info->energy_initial = e0; info->energy_final = e; }
+	return SRH_OK;
+}
+
+extern "C" int srh_mvs_initial_estimate_mrf(srh_context *c, int slot, const int32_t *neigh, int nneigh, const srh_params *p,
+                                            const srh_mrf_params *m, srh_mrf_info *info)
+{
+	int rc;
+	if ((rc = check_slot(c, slot, true)) || (rc = check_params(p))) return rc;
+	if (!m) return fail(SRH_E_INVALID, "null MRF params");
+	if (p->top_k < 1 || p->top_k > 15) return fail(SRH_E_UNSUPPORTED, "top_k %d outside [1,15]", p->top_k);
+	HIP_TRY(hipSetDevice(c->device));
+	const ViewHost &v = c->views[slot];
+	if ((rc = ensure(c->mrf_peaks, c->mrf_peaks_cap, (size_t)v.w*v.h*p->top_k*2))) return rc;
+	if ((rc = srh_mvs_initial_estimate(c, slot, neigh, nneigh, p, 0, 0, c->mrf_peaks))) return rc;
+	return srh_mvs_mrf_estimate(c, slot, p->top_k, c->mrf_peaks, m, info);
+}
+
+extern "C" int srh_mvs_mrf_state(srh_context *c, int32_t *labels, double *data_costs, double *messages)
+{
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (!c->mrf_w) return fail(SRH_E_INVALID, "no finished MRF run on this context");
+	HIP_TRY(hipSetDevice(c->device));
+	const int w = c->mrf_w, h = c->mrf_h, K = c->mrf_k, L = K + 1;
+	const size_t n = (size_t)w*h;
+	MrfLayout lay;
+	launch_mrf_layout(c->mrf, w, h, lay);
+	if (labels) HIP_TRY(hipMemcpyAsync(labels, lay.ans, n*sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+	// device rows are 16 labels wide: copy the first L of each
+	if (data_costs) HIP_TRY(hipMemcpy2DAsync(data_costs, L*sizeof(double), lay.D, 16*sizeof(double), L*sizeof(double), n, hipMemcpyDeviceToHost, c->stream));
+	if (messages) {
+		HIP_TRY(hipMemcpy2DAsync(messages, 2*L*sizeof(double), lay.Mh, 16*sizeof(double), L*sizeof(double), n, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipMemcpy2DAsync(messages + L, 2*L*sizeof(double), lay.Mv, 16*sizeof(double), L*sizeof(double), n, hipMemcpyDeviceToHost, c->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));
 	return SRH_OK;
 }
 

@@ -119,6 +119,21 @@ void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const i
                           double *unit_peaks, double *peaks);
 void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, int h, const srh_params &P,
                         double *xyz, uint8_t *rgb, uint8_t *valid, unsigned long long *counts);
+// MRF stage (srh_mrf.hip): one scratch buffer, carved the same way by every launch
+struct MrfLayout {
+	double *pz, *D, *Mh, *Mv, *carry, *partial, *energy;
+	unsigned *status, *sync;
+	int32_t *ans;
+	int nparts, nbands;
+	size_t sync_words, total_doubles;
+};
+size_t mrf_scratch_doubles(int w, int h);
+void launch_mrf_layout(double *buf, int w, int h, MrfLayout &lay);
+hipError_t launch_mrf_setup(hipStream_t st, double *buf, int w, int h, int K, double beta, double lambda, double phiu,
+                            const double *peaks, MrfLayout &lay);
+hipError_t launch_mrf_sweep(hipStream_t st, double *buf, int w, int h, int K, double psiu);
+hipError_t launch_mrf_energy(hipStream_t st, double *buf, int w, int h, int K, double psiu);
+hipError_t launch_mrf_depth(hipStream_t st, const ViewDev *views, int slot, double *buf, int w, int h, int K);
 void launch_epipolar_preview(hipStream_t st, const ViewDev *views, int ref, int oth, double zmin, double zmax, int nd,
                              int nq, const double *xy, double *out, int32_t *counts);
 void launch_refraction_error(hipStream_t st, const ViewDev *views, int v1, int v2, int n, const double *p1, const double *p2, double *err);

@@ -23,6 +23,7 @@ MultiViewStereo::MultiViewStereo(int deviceOrdinal)
 	: minDepth(0), maxDepth(0), crossCheckThreshold(0), imageScale(1), numDepthLevels(0), ctx_(nullptr)
 {
 	srh_params_mvs_defaults(&params_);
+	srh_mrf_params_defaults(&mrfParams_);
 	if (srh_create(deviceOrdinal, &ctx_) != SRH_OK) { error_ = srh_last_error(); ctx_ = nullptr; }
 }
 
@@ -119,8 +120,9 @@ void MultiViewStereo::runTask() {
 	for (int v = 0; v < nv; ++v) {                     // initial stereo estimate, :365-376
 		emitProgress(current_step++);
 		emitStage("Computing cost volume for camera " + views[v]->name());
-		const int rc = srh_mvs_initial_estimate(ctx_, v, &neigh[static_cast<size_t>(v)*params_.num_neighbours], count[v],
-		                                        &params_, 0, 0, nullptr);
+		const int32_t *nb = &neigh[static_cast<size_t>(v)*params_.num_neighbours];
+		const int rc = useMrf_ ? srh_mvs_initial_estimate_mrf(ctx_, v, nb, count[v], &params_, &mrfParams_, nullptr)   // #ifdef USE_MRF, :610-652
+		                       : srh_mvs_initial_estimate(ctx_, v, nb, count[v], &params_, 0, 0, nullptr);
 		if (rc == SRH_E_CANCELLED || isCancelled()) { srh_set_hooks(ctx_, nullptr, nullptr, nullptr); return; }
 		if (rc != SRH_OK) { error_ = srh_last_error(); srh_set_hooks(ctx_, nullptr, nullptr, nullptr); return; }
 	}

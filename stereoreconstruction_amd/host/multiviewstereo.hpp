@@ -60,6 +60,11 @@ public:
 	const std::vector<std::vector<int> > &neighbourViews() const { return neighbours; }
 
 	srh_params &params() { return params_; }
+	// The reference picks the MRF branch of computeInitialEstimate at build time (CONFIG+=mrf -> USE_MRF,
+	// StereoReconstruction.pro:100-103); here it is a run-time switch, off by default like the reference's default build.
+	void setUseMRF(bool on) { useMrf_ = on; }
+	bool useMRF() const { return useMrf_; }
+	srh_mrf_params &mrfParams() { return mrfParams_; }
 	const std::string &lastError() const { return error_; }
 
 protected:
@@ -79,6 +84,8 @@ private:
 	double minDepth, maxDepth, crossCheckThreshold, imageScale;
 	int numDepthLevels;
 	srh_params params_;
+	srh_mrf_params mrfParams_;
+	bool useMrf_ = false;
 	srh_context *ctx_;
 	std::string error_;
 };

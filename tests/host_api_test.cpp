@@ -136,6 +136,7 @@ int main(int argc, char **argv) {
 		std::shared_ptr<MultiViewStereo> m(new MultiViewStereo());
 		if (!m->lastError().empty()) { fprintf(stderr, "ctor: %s\n", m->lastError().c_str()); return 3; }
 		m->params().window_radius = radius; m->params().weight_kind = wkind;
+		if (getenv("SRH_TEST_USE_MRF")) m->setUseMRF(true);               // the CONFIG+=mrf build of the reference
 		m->initialize(cams, images, dh[0], dh[1], D, dh[3], dh[2]);
 		m->progressUpdate = [&](int s) { steps.push_back(s); };
 		m->started = [&](const Task *) { started = true; };

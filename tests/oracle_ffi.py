@@ -96,6 +96,13 @@ def lib():
     L.sro_epipolar_preview.restype = C.c_int
     L.sro_refraction_pair_error.argtypes = [C.POINTER(Camera), C.POINTER(Camera), c_double_p, c_double_p]
     L.sro_refraction_pair_error.restype = C.c_double
+    L.sro_mrf_params_defaults.argtypes = [C.POINTER(MrfParams)]
+    L.sro_mrf_data_cost.argtypes = [C.POINTER(MrfParams), C.c_int, c_double_p, C.c_int]
+    L.sro_mrf_data_cost.restype = C.c_double
+    L.sro_mrf_smooth_cost.argtypes = [C.POINTER(MrfParams), C.c_int, c_double_p, c_double_p, C.c_int, C.c_int]
+    L.sro_mrf_smooth_cost.restype = C.c_double
+    L.sro_mvs_mrf.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, C.POINTER(C.c_uint8), C.POINTER(MrfParams),
+                              c_double_p, c_int32_p, c_double_p, c_double_p, C.POINTER(MrfInfo)]
     L.sro_back_project.argtypes = [C.POINTER(Camera), C.POINTER(Params), C.c_int, C.c_int, C.c_double, c_double_p]
     L.sro_back_project.restype = C.c_int
     L.sro_epipolar_curve.argtypes = [C.POINTER(Camera), C.POINTER(Camera), C.POINTER(Image),
@@ -226,6 +233,59 @@ def line_points(x0, y0, x1, y1, clip=False, w=0, h=0, cap=1 << 16, bounded=False
     out = np.empty((cap, 2), dtype=np.int32)
     n = lib().sro_line_points(x0, y0, x1, y1, 2 if bounded else int(clip), w, h, iptr(out), cap)
     return out[:min(n, cap)].copy()
+
+
+class MrfParams(C.Structure):
+    _fields_ = [("beta", C.c_double), ("lambda_", C.c_double), ("phi_u", C.c_double), ("psi_u", C.c_double),
+                ("max_iters", C.c_int32), ("min_energy_drop", C.c_double)]
+
+
+class MrfInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("energy_initial", C.c_double), ("energy_final", C.c_double),
+                ("lower_bound", C.c_double)]
+
+
+def mrf_params(**over):
+    m = MrfParams()
+    lib().sro_mrf_params_defaults(C.byref(m))
+    for k, v in over.items():
+        setattr(m, "lambda_" if k == "lambda" else k, v)
+    return m
+
+
+def mvs_mrf(peaks, mask, m, depth=None, data_costs=None, want_messages=False):
+    """peaks (h,w,K,2) -> dict(depth, labels, info, messages)"""
+    peaks = np.ascontiguousarray(peaks, dtype=np.float64)
+    h, w, K, _ = peaks.shape
+    depth = np.full((h, w), np.inf) if depth is None else np.ascontiguousarray(depth, dtype=np.float64).copy()
+    labels = np.zeros((h, w), dtype=np.int32)
+    msgs = np.zeros((h, w, 2, K + 1)) if want_messages else None
+    info = MrfInfo()
+    mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    dc = None if data_costs is None else np.ascontiguousarray(data_costs, dtype=np.float64)
+    lib().sro_mvs_mrf(w, h, K, dptr(peaks), None if mk is None else mk.ctypes.data_as(C.POINTER(C.c_uint8)),
+                      C.byref(m), dptr(depth), iptr(labels), None if dc is None else dptr(dc),
+                      None if msgs is None else dptr(msgs), C.byref(info))
+    return dict(depth=depth, labels=labels, messages=msgs, iterations=info.iterations,
+                energy_initial=info.energy_initial, energy_final=info.energy_final, lower_bound=info.lower_bound)
+
+
+def mrf_energy(peaks, labels, m, data_costs=None):
+    """totalEnergy of a labelling, term by term through sro_mrf_data_cost / sro_mrf_smooth_cost (python loops: small grids)."""
+    L = lib()
+    peaks = np.ascontiguousarray(peaks, dtype=np.float64)
+    h, w, K, _ = peaks.shape
+    e = 0.0
+    for y in range(h):
+        for x in range(w):
+            pk = peaks[y, x]
+            e += (data_costs[y, x, labels[y, x]] if data_costs is not None
+                  else L.sro_mrf_data_cost(C.byref(m), K, dptr(pk), int(labels[y, x])))
+            if x + 1 < w:
+                e += L.sro_mrf_smooth_cost(C.byref(m), K, dptr(pk), dptr(peaks[y, x + 1]), int(labels[y, x]), int(labels[y, x + 1]))
+            if y + 1 < h:
+                e += L.sro_mrf_smooth_cost(C.byref(m), K, dptr(pk), dptr(peaks[y + 1, x]), int(labels[y, x]), int(labels[y + 1, x]))
+    return e
 
 
 def epipolar_preview(refcam, othcam, px, py, min_depth, max_depth, num_depths):

@@ -117,6 +117,44 @@ def test_multiviewstereo_class(tmp_path):
 
 
 @pytest.mark.gpu
+def test_multiviewstereo_class_mrf_branch(tmp_path):
+    """setUseMRF(true) = the reference built with CONFIG+=mrf: peaks -> TRW-S -> depth per view, then the same
+    cross-check.  The optimiser is parity-unpinned (tests/test_gpu_mrf.py); the device's exp() may differ from
+    libm's in the last place, so a handful of label ties may fall the other way: <= 0.5 % of the pixels."""
+    exe = _build(str(tmp_path))
+    case = cases.get_mvs("mvs_geodesic")
+    views = []
+    for (rgba, mask, cam, dist, plane) in case["views"]:
+        im = rgba.copy()
+        im[..., 3] = np.where(mask == 1, 255, 51)
+        views.append((im, mask, cam, dist, plane))
+    case = dict(case, views=views)
+    h, w = views[0][0].shape[:2]
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_input(inp, case, False)
+    subprocess.check_call([exe, "mvs", inp, outp], env=dict(os.environ, SRH_TEST_USE_MRF="1"))
+    nv = len(views)
+    got, steps = _read_output(outp, nv, w, h)
+    assert steps == list(range(2 * nv))
+    imgs, ocams, op = cases.oracle_inputs(case)
+    neigh = O.mvs_neighbours(ocams, op)
+    ref, plain = [], []
+    for v in range(nv):
+        d, pk, _ = O.mvs_initial_estimate(imgs, ocams, v, neigh[v], op, want_peaks=True)
+        plain.append(d.copy())
+        ref.append(O.mvs_mrf(pk, views[v][1], O.mrf_params(), depth=d)["depth"])
+    for v in range(nv):
+        O.mvs_cross_check(imgs, ocams, v, op, ref)
+        O.mvs_cross_check(imgs, ocams, v, op, plain)
+    differs_from_wta = 0
+    for v in range(nv):
+        ok, msg, nbad = cases.compare_depth(got[v], ref[v], 1e-9)
+        assert nbad <= 0.005 * w * h, "view %d: %s" % (v, msg)
+        differs_from_wta += cases.compare_depth(got[v], plain[v], 1e-9)[2]
+    assert differs_from_wta > 0                              # the switch did something
+
+
+@pytest.mark.gpu
 def test_multiviewstereo_from_a_project_file(tmp_path):
     """The reference's own entry: initialize(project, imageSet, views, ...) on a project XML (cameras as 3x4
     projection matrices -> Camera::setP, image set -> default image per camera; the camera without an image
