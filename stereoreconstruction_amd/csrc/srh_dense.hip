@@ -382,6 +382,32 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	// shares its SIMDs with an older one that is deep in the FP64 loops, and must get its
 	// loads issued immediately so that their latency hides under the other's arithmetic.
 	__builtin_amdgcn_s_setprio(3);
+	// ---- the windows, the reference rows and the pixel constants do not depend on the candidate ranges: their global
+	// loads are issued first and travel while the ranges are worked out (the first LDS store comes after all loads)
+	constexpr int NBW = (T*DC_TP + DC_THREADS - 1)/DC_THREADS;
+	constexpr int NBL = (WS*Smem::LW + DC_THREADS - 1)/DC_THREADS;
+	constexpr int NBR = (WS*Smem::RW + DC_THREADS - 1)/DC_THREADS;
+	// tile-major window buffer: the T*DC_TP doubles of this tile are contiguous
+	static_assert(DC_TP == SRH_WTILE, "dense tile = window-buffer tile");
+	const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
+	double tw_[NBW], tl_[NBL];
+#pragma unroll
+	for (int k = 0; k < NBW; ++k) {
+		const int idx = tid + k*DC_THREADS;
+		tw_[k] = (idx < T*DC_TP && x0 + (idx % DC_TP) < W) ? wtile[idx] : 0.0;
+	}
+#pragma unroll
+	for (int k = 0; k < NBL; ++k) {
+		const int idx = tid + k*DC_THREADS;
+		const int ty = idx / Smem::LW, tx = idx % Smem::LW;
+		const int gx = x0 - R + tx, gy = y - R + ty;
+		tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
+	}
+	double pc_[4] = { 0.0, 0.0, 0.0, 0.0 };
+	if (g == 0 && x < W) {
+		const double *pc = pconst + ((size_t)trow*W + x)*4;
+		pc_[0] = pc[0]; pc_[1] = pc[1]; pc_[2] = pc[2]; pc_[3] = pc[3];
+	}
 	// ---- union of the candidate ranges of the tile (one global load, one LDS reduction)
 	__shared__ int s_cmin, s_cmax, s_need_pix, s_need_col;
 	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; s_need_pix = 0; s_need_col = 0; }
@@ -405,26 +431,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	// ---- stage the windows, the reference rows and the first chunk of the other view's rows.
 	// Every global load of the thread is issued before the first LDS store, so the whole
 	// staging costs about one memory latency.
-	constexpr int NBW = (T*DC_TP + DC_THREADS - 1)/DC_THREADS;
-	constexpr int NBL = (WS*Smem::LW + DC_THREADS - 1)/DC_THREADS;
-	constexpr int NBR = (WS*Smem::RW + DC_THREADS - 1)/DC_THREADS;
 	{
-		// tile-major window buffer: the T*DC_TP doubles of this tile are contiguous
-		static_assert(DC_TP == SRH_WTILE, "dense tile = window-buffer tile");
-		const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
-		double tw_[NBW], tl_[NBL], tr_[NBR];
-#pragma unroll
-		for (int k = 0; k < NBW; ++k) {
-			const int idx = tid + k*DC_THREADS;
-			tw_[k] = (idx < T*DC_TP && x0 + (idx % DC_TP) < W) ? wtile[idx] : 0.0;
-		}
-#pragma unroll
-		for (int k = 0; k < NBL; ++k) {
-			const int idx = tid + k*DC_THREADS;
-			const int ty = idx / Smem::LW, tx = idx % Smem::LW;
-			const int gx = x0 - R + tx, gy = y - R + ty;
-			tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
-		}
+		double tr_[NBR];
 #pragma unroll
 		for (int k = 0; k < NBR; ++k) {
 			const int idx = tid + k*DC_THREADS;
@@ -459,9 +467,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		bool all = (x < W) && (e.xmax >= e.xmin);
 		double mL = 0, tw = 0, s2 = 0;
 		if (all) {
-			const double *pc = pconst + ((size_t)trow*W + x)*4;
-			mL = pc[0]; tw = pc[1]; s2 = pc[2];
-			all = pc[3] != 0.0;
+			mL = pc_[0]; tw = pc_[1]; s2 = pc_[2];
+			all = pc_[3] != 0.0;
 		}
 		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
 		if (!all && x < W && e.xmax >= e.xmin) s_need_pix = 1;      // this pixel needs the general form
