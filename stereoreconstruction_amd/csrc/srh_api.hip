@@ -1103,7 +1103,7 @@ extern "C" int srh_mvs_mrf_estimate(srh_context *c, int slot, int K, const void 
 		if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 		prev = e;
 		{ Scope s(c, "mrf_pass_kernel");
-		  HIP_TRY(launch_mrf_sweep(c->stream, c->mrf, w, h, K, m->psi_u)); }
+		  HIP_TRY(launch_mrf_sweep(c->stream, c->mrf, w, h, K, m->psi_u, iters)); }
 		if ((rc = energy(e))) return rc;
 		++iters;
 	} while (prev - e > m->min_energy_drop && num_iters-- > 0);

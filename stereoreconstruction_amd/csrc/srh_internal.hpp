@@ -121,7 +121,8 @@ void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, i
                         double *xyz, uint8_t *rgb, uint8_t *valid, unsigned long long *counts);
 // MRF stage (srh_mrf.hip): one scratch buffer, carved the same way by every launch
 struct MrfLayout {
-	double *pz, *D, *Mh, *Mv, *carry, *partial, *energy;
+	double *pz, *D, *Mh, *Mv, *partial, *energy;
+	unsigned long long *hand; size_t hand_words;
 	unsigned *status, *sync;
 	int32_t *ans;
 	int nparts, nbands;
@@ -131,7 +132,7 @@ size_t mrf_scratch_doubles(int w, int h);
 void launch_mrf_layout(double *buf, int w, int h, MrfLayout &lay);
 hipError_t launch_mrf_setup(hipStream_t st, double *buf, int w, int h, int K, double beta, double lambda, double phiu,
                             const double *peaks, MrfLayout &lay);
-hipError_t launch_mrf_sweep(hipStream_t st, double *buf, int w, int h, int K, double psiu);
+hipError_t launch_mrf_sweep(hipStream_t st, double *buf, int w, int h, int K, double psiu, int sweep);
 hipError_t launch_mrf_energy(hipStream_t st, double *buf, int w, int h, int K, double psiu);
 hipError_t launch_mrf_depth(hipStream_t st, const ViewDev *views, int slot, double *buf, int w, int h, int K);
 void launch_epipolar_preview(hipStream_t st, const ViewDev *views, int ref, int oth, double zmin, double zmax, int nd,

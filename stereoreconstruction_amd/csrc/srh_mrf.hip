@@ -9,10 +9,16 @@
 // only parallelism inside a sweep is along anti-diagonals.  One workgroup owns a band of 16 image rows and walks it
 // diagonal by diagonal: 16 pixels per step, 16 lanes per pixel (one per label).  The message to the right-hand
 // neighbour never leaves its lanes' registers, the message to the pixel below crosses to the next 16 lanes through
-// LDS, and the message out of a band's last row goes to the next band's workgroup through device memory: write-through
-// (sc1) stores, one progress word per band, sc1 loads by the polling wave (the producer -> consumer form of the HIP
-// guide's inter-workgroup hand-off).  Bands therefore run as a pipeline, each ~6 chunks of columns behind the one
-// above, and a sweep takes about W + 26 * H/16 steps instead of W * H.
+// LDS, and the message out of a band's last row goes to the next band's workgroup through device memory as
+// self-validating granules (the HIP guide's R2 hand-off): every double travels as two 8-byte words {pass tag, half},
+// written through (sc1) and read with sc1 loads, so the data is its own flag -- no progress word, no release, no
+// drain of the storing wave.  A consumer fetches its granules a chunk ahead; only when a tag is not yet the current
+// pass's does it wait, and then until the band above is MRF_LAG columns ahead, so that the following prefetches are
+// valid at first read.  Bands therefore run as a pipeline, each ~36 columns behind the one above, and a pass takes
+// about W + 36 * H/16 steps instead of W * H (measured: 1.3 us per step averaged over the three passes of a sweep,
+// whatever the number of bands -- the dependent chain LDS -> adds -> DPP min-reductions -> LDS -> barrier of one step).
+// The four computing waves of a workgroup only load; a fifth wave writes each step's results from LDS to device
+// memory one step later (a wave that mixes prefetching loads with stores must drain both to use a prefetched value).
 //
 // Within a pixel the label vectors are exchanged with DPP row broadcasts (v_mov_b64_dpp row_newbcast: no LDS).
 // Per-step inputs (data costs, stored messages, peak depths) are fetched a chunk of 4 steps ahead into registers.
@@ -27,12 +33,14 @@ namespace {
 constexpr int MRF_ROWS = 16;            // rows per band = pixel groups per workgroup
 constexpr int MRF_LANES = 16;           // lanes per pixel = label slots (K + 1 <= 16)
 constexpr int MRF_CH = 4;               // steps per prefetched chunk
+constexpr int MRF_THREADS = 320;        // 4 waves that compute (16 rows x 16 label lanes) + 1 that stores
+constexpr int MRF_LAG = 12;             // columns a band drops behind the one above once it had to wait for it
 constexpr unsigned MRF_SPIN_LIMIT = 1u << 21;
 constexpr size_t MRF_LDS_BYTES = 96*1024;   // more than half of a CU's LDS: one band per CU (hand-off form, and 1 wave per SIMD)
 
-// sync block (unsigned words, zeroed before every pass): [0] ticket, [4 + b] progress of band b
+// sync block (4 unsigned words, zeroed before every pass): [0] ticket
 // status block (zeroed once per run): [0] abort, [1] first band that gave up + 1, [2] pass it gave up in + 1
-constexpr int SY_TICKET = 0, SY_PROGRESS = 4;
+constexpr int SY_TICKET = 0;
 constexpr int ST_ABORT = 0, ST_WHO = 1, ST_PASS = 2;
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -41,12 +49,16 @@ template <int I> __device__ __forceinline__ double bc16(double v) {
 	return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + I, 0xf, 0xf, false);      // row_newbcast:I
 }
 
-__device__ __forceinline__ void st_sc1(double *p, double v) {
-	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), RLX_AGENT);
+typedef unsigned long long u64;
+// a double as two granules {tag, low half}, {tag, high half}: each one aligned 8-byte write-through store
+__device__ __forceinline__ void put_granules(u64 *g, unsigned tag, double v) {
+	const u64 bits = (u64)__double_as_longlong(v), t = (u64)tag << 32;
+	__hip_atomic_store(g, t | (bits & 0xffffffffull), RLX_AGENT);
+	__hip_atomic_store(g + 1, t | (bits >> 32), RLX_AGENT);
 }
-__device__ __forceinline__ double ld_sc1(const double *p) {
-	return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), RLX_AGENT));
-}
+__device__ __forceinline__ u64 get_granule(const u64 *g) { return __hip_atomic_load(g, RLX_AGENT); }
+__device__ __forceinline__ bool granules_ok(u64 g0, u64 g1, unsigned tag) { return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag; }
+__device__ __forceinline__ double granules_value(u64 g0, u64 g1) { return __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32))); }
 
 // smoothnessCost (multiviewstereo.cpp:499-514) between a peak label of one pixel (depth z1) and label kd of another (z2)
 // (written as selects over an unconditional quotient: the divisions of one step are independent of each other and of
@@ -63,7 +75,8 @@ __device__ __forceinline__ double smooth_carried(double c, double z2, bool kd_un
 }
 
 struct Chunk {
-	double D[MRF_CH], oH[MRF_CH], oV[MRF_CH], zs[MRF_CH + 1], zV[MRF_CH], T[MRF_CH];
+	double D[MRF_CH], oH[MRF_CH], oV[MRF_CH], zs[MRF_CH + 1], zV[MRF_CH];
+	u64 g0[MRF_CH], g1[MRF_CH];          // first row of a band: what the band above handed down (granules)
 };
 
 // runs its body once per label KS = 0 .. L-1, KS a compile-time constant (a DPP lane select is an immediate)
@@ -88,18 +101,21 @@ struct MrfPassArgs {
 	const double *D;         // [n][16] data costs
 	double *Mh, *Mv;         // [n][16] message stored on the edge (n, n+1) / (n, n+W)
 	int32_t *ans;            // [n]
-	double *carry;           // [n] solve pass: the chosen label's depth (NaN: unknown), for the band below
+	unsigned long long *hand; // [band][logical column][16 lanes][2] granules out of each band's last row
+	unsigned epoch;          // tag of this pass: unique within a run, never 0
 	unsigned *sync, *status;
 };
 
 // MODE 0: forward sweep, 1: backward sweep (logical coordinates mirrored), 2: labels read off (forward order)
 // LT: the label count K + 1 when known at compile time (10 for the reference's K = 9: straight-line label loops), 0: any
 template <int MODE, int LT>
-__global__ __launch_bounds__(256, 1) void mrf_pass_kernel(const MrfPassArgs a)
+__global__ __launch_bounds__(MRF_THREADS, 1) void mrf_pass_kernel(const MrfPassArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	double (*down)[MRF_ROWS][MRF_LANES] = reinterpret_cast<double (*)[MRF_ROWS][MRF_LANES]>(smem);   // [2][row][label]
-	int *s_ctl = reinterpret_cast<int *>(smem + 2*MRF_ROWS*MRF_LANES*sizeof(double));                  // [0] band, [1] abort
+	double (*down)[MRF_ROWS][MRF_LANES] = reinterpret_cast<double (*)[MRF_ROWS][MRF_LANES]>(smem);   // [2][row][label]: message to the row below
+	double (*outH)[MRF_ROWS][MRF_LANES] = down + 2;                                                   // [2][row][label]: message along the row
+	int (*labs)[MRF_ROWS] = reinterpret_cast<int (*)[MRF_ROWS]>(smem + 4*MRF_ROWS*MRF_LANES*sizeof(double));   // [2][row]: chosen label
+	int *s_ctl = reinterpret_cast<int *>(smem + 4*MRF_ROWS*MRF_LANES*sizeof(double) + 2*MRF_ROWS*sizeof(int));   // [0] band, [1] abort
 
 	const int tid = threadIdx.x, r = tid >> 4, kd = tid & 15, wave = tid >> 6;
 	const int W = a.W, H = a.H, K = LT ? LT - 1 : a.K, L = K + 1;
@@ -114,44 +130,65 @@ __global__ __launch_bounds__(256, 1) void mrf_pass_kernel(const MrfPassArgs a)
 	const bool unknown = kd == K;
 	const int rlast = min(MRF_ROWS, H - b*MRF_ROWS) - 1;             // the band's last row
 	const int dstep = MODE == 1 ? -1 : 1;                            // physical step to the next logical column / row
-	unsigned known = 0;                                              // wave 0: columns the band above is known to have finished
+	const int nsteps = W + MRF_ROWS - 1;
+	const int nchunks = (nsteps + MRF_CH - 1)/MRF_CH;
+
+	// ---- the storing wave.  A wave that both prefetches (loads) and stores has to wait for ALL its memory operations
+	// whenever it needs a prefetched value (loads and stores share one counter and complete out of order against each
+	// other), i.e. for the round trip of the stores of the step just finished, every chunk.  So the four computing waves
+	// only load; what a step produced sits in LDS (the row-below hand-over is there anyway) and this wave writes the
+	// previous step's values to device memory while the others compute the next: it never waits for anything.
+	if (wave == 4) {
+		const int lane = tid & 63;
+		for (int s = 0; s <= nchunks*MRF_CH; ++s) {
+			const int t = s - 1, par = t & 1;                          // the step whose outputs are written now
+			if (t >= 0) {
+				if (MODE == 2) {
+					if (lane < MRF_ROWS) {
+						const int rr = lane, vv = b*MRF_ROWS + rr, u = t - rr;
+						if (vv < H && u >= 0 && u < W) {
+							const long n = (long)vv*W + u;
+							a.ans[n] = labs[par][rr];
+							if (rr == rlast) put_granules(a.hand + (((size_t)b*W + u)*16)*2, a.epoch, down[par][rr][0]);
+						}
+					}
+				} else {
+#pragma unroll
+					for (int k = 0; k < 2*MRF_ROWS*MRF_LANES/64; ++k) {
+						const int idx = k*64 + lane;
+						const int which = idx >> 8, rr = (idx >> 4) & 15, kk = idx & 15;
+						const int vv = b*MRF_ROWS + rr, u = t - rr;
+						if (vv < H && u >= 0 && u < W && kk < L) {
+							const int yy = MODE == 1 ? H - 1 - vv : vv;
+							const long n = (long)yy*W + (MODE == 1 ? W - 1 - u : u);
+							if (which == 0) {
+								if (u < W - 1) a.Mh[(MODE == 1 ? n - 1 : n)*16 + kk] = outH[par][rr][kk];
+							} else if (vv < H - 1) {
+								const double m = down[par][rr][kk];
+								a.Mv[(MODE == 1 ? n - W : n)*16 + kk] = m;
+								if (rr == rlast) put_granules(a.hand + (((size_t)b*W + u)*16 + kk)*2, a.epoch, m);
+							}
+						}
+					}
+				}
+			}
+			if (s == nchunks*MRF_CH) break;
+			__syncthreads();                                           // the computing waves' barrier of step s
+			if ((s % MRF_CH) == MRF_CH - 1 && s_ctl[1]) break;         // they leave here too
+		}
+		return;
+	}
+
+	const unsigned epoch = a.epoch;
+	const bool takes = r == 0 && b > 0;                              // this lane's row is fed by the band above
+	const bool hlane = MODE == 2 ? true : kd < L;                    // lanes whose granules exist (solve pass: slot 0, read by all)
 
 	// physical pixel index of logical column u in this lane's row
 	auto pix = [&](int u) -> long { return (long)y*W + (MODE == 1 ? W - 1 - u : u); };
+	// granules the band above wrote for logical column u (this lane's label; solve pass: the one value of the pixel)
+	auto hand_at = [&](int u) -> const u64 * { return a.hand + (((size_t)(b - 1)*W + u)*16 + (MODE == 2 ? 0 : kd))*2; };
 
-	// Wave 0 learns how far the band above has come.  The progress word is read one chunk AHEAD of its use (`early`,
-	// an sc1 load whose answer is only looked at when the next chunk starts), so that in the steady state -- this band
-	// a chunk or two further behind than it strictly has to be -- no step ever waits for the ~2 us round trip of a poll;
-	// only when that early answer is not enough does lane 0 spin, which also puts the band that much further behind.
-	unsigned early = 0;
-	auto wait_above = [&](unsigned need) -> bool {                    // wave 0 only; uniform result
-		if (b == 0) return true;
-		known = max(known, early);
-		int ok = 1;
-		if (known < need) {
-			if (tid == 0) {
-				unsigned spins = 0;
-				for (;;) {
-					known = __hip_atomic_load(&a.sync[SY_PROGRESS + b - 1], RLX_AGENT);
-					if (known >= need) break;
-					if (++spins > MRF_SPIN_LIMIT || __hip_atomic_load(&a.status[ST_ABORT], RLX_AGENT)) { ok = 0; break; }
-					__builtin_amdgcn_s_sleep(8);
-				}
-				if (!ok) {
-					__hip_atomic_store(&a.status[ST_ABORT], 1u, RLX_AGENT);
-					if (atomicCAS(&a.status[ST_WHO], 0u, (unsigned)b + 1u) == 0u) a.status[ST_PASS] = MODE + 1;
-					s_ctl[1] = 1;
-				}
-			}
-			known = __shfl(known, 0);
-			ok = __shfl(ok, 0);
-		}
-		early = __hip_atomic_load(&a.sync[SY_PROGRESS + b - 1], RLX_AGENT);   // for the next call; not waited for here
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // keeps the sc1 loads below the poll
-		return ok != 0;
-	};
-
-	auto load_chunk = [&](int c, Chunk &B, bool top_ready) {
+	auto load_chunk = [&](int c, Chunk &B) {
 #pragma unroll
 		for (int j = 0; j <= MRF_CH; ++j) {
 			const int u = c*MRF_CH + j - r;
@@ -165,43 +202,64 @@ __global__ __launch_bounds__(256, 1) void mrf_pass_kernel(const MrfPassArgs a)
 			B.oH[j] = (ok && u < W - 1) ? a.Mh[eh*16 + kd] : 0.0;
 			B.oV[j] = (ok && hasV) ? a.Mv[ev*16 + kd] : 0.0;
 			B.zV[j] = (ok && hasV) ? a.pz[(n + (long)dstep*W)*16 + kd] : 0.0;
-			B.T[j] = 0.0;
-			if (r == 0 && b > 0 && ok && top_ready) {
-				// what the band above handed down for this column: its edge towards us
-				if (MODE == 2)      B.T[j] = ld_sc1(&a.carry[n - W]);
-				else if (MODE == 0) B.T[j] = ld_sc1(&a.Mv[(n - W)*16 + kd]);
-				else                B.T[j] = ld_sc1(&a.Mv[n*16 + kd]);
-			}
+			B.g0[j] = 0; B.g1[j] = 0;
+			if (takes && ok && hlane) { const u64 *g = hand_at(u); B.g0[j] = get_granule(g); B.g1[j] = get_granule(g + 1); }
 		}
 	};
 
-	const int nsteps = W + MRF_ROWS - 1;
-	const int nchunks = (nsteps + MRF_CH - 1)/MRF_CH;
+	// wave 0, before a chunk is used: are the granules of its MRF_CH columns this pass's?  If not: wait until the band
+	// above is MRF_LAG columns further, fetch them again (until they are: stores of one wave need not land in order).
+	auto settle = [&](int c, Chunk &B) {
+		if (b == 0) return;
+		bool good = true;
+#pragma unroll
+		for (int j = 0; j < MRF_CH; ++j) {
+			const int u = c*MRF_CH + j;
+			if (takes && hlane && u < W) good = good && granules_ok(B.g0[j], B.g1[j], epoch);
+		}
+		if (__all(good)) return;
+		const int ufar = min(c*MRF_CH + MRF_CH - 1 + MRF_LAG, W - 1);
+		unsigned spins = 0;
+		int ok = 1;
+		for (;;) {
+			bool far = true;
+			if (takes && hlane) { const u64 *g = hand_at(ufar); far = granules_ok(get_granule(g), get_granule(g + 1), epoch); }
+			good = true;
+#pragma unroll
+			for (int j = 0; j < MRF_CH; ++j) {
+				const int u = c*MRF_CH + j;
+				if (takes && hlane && u < W) {
+					const u64 *g = hand_at(u);
+					B.g0[j] = get_granule(g); B.g1[j] = get_granule(g + 1);
+					good = good && granules_ok(B.g0[j], B.g1[j], epoch);
+				}
+			}
+			if (__all(far && good)) break;
+			if (++spins > MRF_SPIN_LIMIT || __hip_atomic_load(&a.status[ST_ABORT], RLX_AGENT)) { ok = 0; break; }   // uniform
+			__builtin_amdgcn_s_sleep(4);
+		}
+		if (!ok && tid == 0) {
+			__hip_atomic_store(&a.status[ST_ABORT], 1u, RLX_AGENT);
+			if (atomicCAS(&a.status[ST_WHO], 0u, (unsigned)b + 1u) == 0u) a.status[ST_PASS] = MODE + 1;
+			s_ctl[1] = 1;
+		}
+	};
+
 	Chunk cur, nxt;
-	{
-		bool ok = true;
-		if (wave == 0) ok = wait_above((unsigned)min(MRF_CH, W));
-		load_chunk(0, nxt, ok);
-	}
+	load_chunk(0, nxt);
 	double carryL = 0.0;                                             // message (or chosen depth) handed along the row
 
 	for (int c = 0; c < nchunks; ++c) {
 		cur = nxt;
-		if (c + 1 < nchunks) {
-			bool ok = true;
-			if (wave == 0) ok = wait_above((unsigned)min((c + 2)*MRF_CH, W));
-			load_chunk(c + 1, nxt, ok);
-		}
+		if (wave == 0) settle(c, cur);
+		if (c + 1 < nchunks) load_chunk(c + 1, nxt);
 #pragma unroll
 		for (int j = 0; j < MRF_CH; ++j) {
 			const int s = c*MRF_CH + j;
 			const int u = s - r;
-			const bool act = rowok && u >= 0 && u < W;
-			const bool hasH = u < W - 1;
-			const long n = pix(u);
 			const double fromL = u > 0 ? carryL : 0.0;
 			const double lds_top = down[(s + 1) & 1][(r + MRF_ROWS - 1) & (MRF_ROWS - 1)][MODE == 2 ? 0 : kd];
-			const double fromT = r == 0 ? cur.T[j] : lds_top;       // v == 0: T is 0
+			const double fromT = r == 0 ? (b > 0 ? granules_value(cur.g0[j], cur.g1[j]) : 0.0) : lds_top;
 			const double zs = cur.zs[j], zH = cur.zs[j + 1], zV = cur.zV[j];
 
 			if (MODE == 2) {
@@ -219,13 +277,7 @@ __global__ __launch_bounds__(256, 1) void mrf_pass_kernel(const MrfPassArgs a)
 				)
 				if (lab == K) cbest = __builtin_nan("");
 				carryL = cbest;
-				if (kd == 0) {
-					down[s & 1][r][0] = cbest;
-					if (act) {
-						a.ans[n] = lab;
-						if (r == rlast) st_sc1(&a.carry[n], cbest);
-					}
-				}
+				if (kd == 0) { down[s & 1][r][0] = cbest; labs[s & 1][r] = lab; }
 			} else {
 				double Di = cur.D[j];
 				if (MODE == 0) { Di += fromL; Di += fromT; Di += cur.oH[j]; Di += cur.oV[j]; }   // left, up, right, down
@@ -259,22 +311,9 @@ __global__ __launch_bounds__(256, 1) void mrf_pass_kernel(const MrfPassArgs a)
 				mH -= dH; mV -= dV;
 				carryL = mH;
 				down[s & 1][r][kd] = mV;
-				if (act && kd < L) {
-					if (hasH) a.Mh[(MODE == 1 ? n - 1 : n)*16 + kd] = mH;
-					if (hasV) {
-						double *dst = &a.Mv[(MODE == 1 ? n - W : n)*16 + kd];
-						if (r == rlast) st_sc1(dst, mV); else *dst = mV;
-					}
-				}
+				outH[s & 1][r][kd] = mH;
 			}
 			__syncthreads();
-		}
-		// the band below may now read what the last row has finished: every sc1 store of this wave has landed first
-		if (wave == (rlast >> 2)) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			const int done = min(max(c*MRF_CH + MRF_CH - rlast, 0), W);
-			if (done > 0 && tid == rlast*MRF_LANES)
-				__hip_atomic_store(&a.sync[SY_PROGRESS + b], (unsigned)done, RLX_AGENT);
 		}
 		if (s_ctl[1]) break;                                         // a wait gave up: leave (results are reported invalid)
 	}
@@ -355,19 +394,20 @@ static MrfPassArgs carve(double *buf, int w, int h, int K, double psi, MrfLayout
 {
 	const size_t n = (size_t)w*h, nr = (n + 1) & ~(size_t)1;           // every block starts 16-byte aligned
 	lay.pz = buf; lay.D = buf + n*16; lay.Mh = buf + n*32; lay.Mv = buf + n*48;
-	lay.carry = buf + n*64;
-	lay.partial = lay.carry + nr;
+	lay.nbands = (h + MRF_ROWS - 1)/MRF_ROWS;
+	lay.hand = reinterpret_cast<unsigned long long *>(buf + n*64);
+	lay.hand_words = (size_t)lay.nbands*w*32;
+	lay.partial = buf + n*64 + lay.hand_words;
 	lay.nparts = (int)((n + 255)/256);
 	lay.energy = lay.partial + ((lay.nparts + 1) & ~1);                // [0] energy, [1] unused
 	lay.status = reinterpret_cast<unsigned *>(lay.energy + 2);         // 4 words
 	lay.ans = reinterpret_cast<int32_t *>(lay.energy + 4);
 	lay.sync = reinterpret_cast<unsigned *>(lay.ans + nr);
-	lay.nbands = (h + MRF_ROWS - 1)/MRF_ROWS;
-	lay.sync_words = (size_t)((SY_PROGRESS + lay.nbands + 3) & ~3);
+	lay.sync_words = 4;
 	lay.total_doubles = (size_t)(reinterpret_cast<double *>(lay.sync) - buf) + lay.sync_words/2;
 	MrfPassArgs a;
 	a.W = w; a.H = h; a.K = K; a.psi = psi; a.psi2 = 2*psi;
-	a.pz = lay.pz; a.D = lay.D; a.Mh = lay.Mh; a.Mv = lay.Mv; a.ans = lay.ans; a.carry = lay.carry;
+	a.pz = lay.pz; a.D = lay.D; a.Mh = lay.Mh; a.Mv = lay.Mv; a.ans = lay.ans; a.hand = lay.hand; a.epoch = 0;
 	a.sync = lay.sync; a.status = lay.status;
 	return a;
 }
@@ -390,6 +430,7 @@ hipError_t launch_mrf_setup(hipStream_t st, double *buf, int w, int h, int K, do
 	if ((e = hipMemsetAsync(lay.Mh, 0, n*32*sizeof(double), st)) != hipSuccess) return e;        // initialize(): messages 0
 	if ((e = hipMemsetAsync(lay.ans, 0, n*sizeof(int32_t), st)) != hipSuccess) return e;         // clearAnswer(): label 0
 	if ((e = hipMemsetAsync(lay.energy, 0, 4*sizeof(double), st)) != hipSuccess) return e;       // energy + status words
+	if ((e = hipMemsetAsync(lay.hand, 0, lay.hand_words*sizeof(unsigned long long), st)) != hipSuccess) return e;   // no tag is 0
 	hipLaunchKernelGGL(mrf_data_kernel, dim3((unsigned)((n*16 + 255)/256)), dim3(256), 0, st, (long)n, K, beta, lambda, phiu, peaks, lay.D, lay.pz);
 	return hipGetLastError();
 }
@@ -400,7 +441,7 @@ template <int MODE, int LT> static hipError_t launch_pass_lt(hipStream_t st, con
 	if ((e = hipMemsetAsync(lay.sync, 0, lay.sync_words*sizeof(unsigned), st)) != hipSuccess) return e;
 	if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mrf_pass_kernel<MODE, LT>), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                             (int)MRF_LDS_BYTES)) != hipSuccess) return e;
-	hipLaunchKernelGGL((mrf_pass_kernel<MODE, LT>), dim3((unsigned)lay.nbands), dim3(256), MRF_LDS_BYTES, st, a);
+	hipLaunchKernelGGL((mrf_pass_kernel<MODE, LT>), dim3((unsigned)lay.nbands), dim3(MRF_THREADS), MRF_LDS_BYTES, st, a);
 	return hipGetLastError();
 }
 template <int MODE> static hipError_t launch_pass(hipStream_t st, const MrfPassArgs &a, const MrfLayout &lay)
@@ -408,14 +449,18 @@ template <int MODE> static hipError_t launch_pass(hipStream_t st, const MrfPassA
 	return a.K == 9 ? launch_pass_lt<MODE, 10>(st, a, lay) : launch_pass_lt<MODE, 0>(st, a, lay);
 }
 
-// one optimize(1): forward sweep, backward sweep, labels read off
-hipError_t launch_mrf_sweep(hipStream_t st, double *buf, int w, int h, int K, double psiu)
+// one optimize(1): forward sweep, backward sweep, labels read off.  `sweep` (0, 1, ...) numbers the calls of one run:
+// every pass gets a granule tag of its own
+hipError_t launch_mrf_sweep(hipStream_t st, double *buf, int w, int h, int K, double psiu, int sweep)
 {
 	MrfLayout lay;
-	const MrfPassArgs a = carve(buf, w, h, K, psiu, lay);
+	MrfPassArgs a = carve(buf, w, h, K, psiu, lay);
 	hipError_t e;
+	a.epoch = 1u + 3u*(unsigned)sweep;
 	if ((e = launch_pass<0>(st, a, lay)) != hipSuccess) return e;
+	a.epoch += 1;
 	if ((e = launch_pass<1>(st, a, lay)) != hipSuccess) return e;
+	a.epoch += 1;
 	return launch_pass<2>(st, a, lay);
 }
 
