@@ -256,7 +256,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the CPU-baseline band (0 = skip)")
-    ap.add_argument("--arith", default="exact", choices=["exact", "fma"],
+    ap.add_argument("--arith", default="exact", choices=["exact", "fma", "f32"],
                     help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
                          "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
     args = ap.parse_args()
@@ -324,12 +324,12 @@ def main():
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
     mismatch = None
-    if args.arith == "fma":
+    if args.arith in ("fma", "f32"):
         if args.workload in ("c1", "c4", "c5"):
             sys.exit("--arith fma applies to the dense row-aligned TwoView path (c2, c3, small)")
         ctx.twoview_wta(0, 1, p)
         exact_l = ctx.download_depth(0)
-        ctx.set_option("arith", 1)
+        ctx.set_option("arith", 1 if args.arith == "fma" else 2)
         ctx.twoview_wta(0, 1, p)
         fma_l = ctx.download_depth(0)
         mismatch = float((exact_l.view(np.uint64) != fma_l.view(np.uint64)).mean())
@@ -416,14 +416,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic" if args.workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
+            "dtype": ("f32" if args.arith == "f32" else "f64"), "data": "synthetic" if args.workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
             "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
                        "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
                        "pairs_per_gpu": 1, "parallelism": ("pairs sharded, %s gather" % ("RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                        "dense_path": bool(stats["used_dense_path"]),
                        "arithmetic": ("exact: the reference's operation order, no contraction (bit parity)" if args.arith == "exact"
-                                      else "fma: multiply-adds of the cost loops fused (opt-in, NOT the parity mode)"),
+                                      else "fma: multiply-adds of the cost loops fused (opt-in, NOT the parity mode)" if args.arith == "fma"
+                                      else "f32: cost loops in packed single precision (opt-in, NOT the parity mode, NOT the reference's precision)"),
                        "winner_mismatch_vs_exact": mismatch,
                        "n_eval_reference_last_pass": stats["n_eval"],
                        "n_eval_device_last_pass": stats["n_eval_device"]},

@@ -140,7 +140,10 @@ int  srh_synchronize(srh_context *ctx);
  *   "arith"           0 (default): the reference's arithmetic, operation by operation (bit parity).  1: opt-in "fma"
  *                     mode -- the multiply-adds of the dense cost loops are fused (half the FP64 instructions);
  *                     costs move in their last bits, a winner can change only between near-tied candidates
- *                     (mismatch rate measured by bench.py --arith fma).  THE ONE OPTION THAT CHANGES RESULTS.
+ *                     (mismatch rate measured by bench.py --arith fma).  2: opt-in "f32" mode -- the dense cost loops
+ *                     run in single precision, two candidates per packed instruction (srh_dense_f32.hip); costs agree
+ *                     with the reference's to ~6 digits, winners change where candidates are that close (rate measured
+ *                     by bench.py --arith f32).  THE ONE OPTION THAT CHANGES RESULTS; row-aligned TwoView path only.
  *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
  *                     not only for rigs the host check accepts (the device verifies every candidate and the
  *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)

@@ -87,7 +87,7 @@ struct srh_context {
 	bool profiling = false;
 	bool force_generic = false;
  	bool use_fused = false;                             // option "fused": single fused kernel for row-aligned pairs
-	int arith = 0;                                      // option "arith": 0 = the reference's arithmetic, 1 = fused multiply-add in the dense cost loops
+	int arith = 0;                                      // option "arith": 0 = the reference's arithmetic, 1 = fused multiply-add, 2 = packed single precision in the dense cost loops
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
@@ -446,7 +446,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "fused")) { c->use_fused = value != 0; return SRH_OK; }
 	if (!strcmp(name, "arith")) {
-		if (value != 0 && value != 1) return fail(SRH_E_INVALID, "arith must be 0 (exact) or 1 (fma)");
+		if (value < 0 || value > 2) return fail(SRH_E_INVALID, "arith must be 0 (exact), 1 (fma) or 2 (f32)");
 		c->arith = (int)value; return SRH_OK;
 	}
 	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
@@ -825,8 +825,12 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr);
 			if (dense) {
 				{ Scope s(c, "twoview_dense_cost_kernel");
-				  launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-				                            c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith); }
+				  if (c->arith == 2)
+					launch_twoview_dense_cost_f32(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
+					                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst);
+				  else
+					launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
+					                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith); }
 				{ Scope s(c, "twoview_scan_kernel");
 				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
 				                      c->wbuf, wstride, c->d_cnt); }

@@ -1,0 +1,349 @@
+// srh_dense_f32.hip -- the row-aligned TwoView cost kernel in single precision (option "arith" = 2).
+//
+// NOT the parity mode.  The reference computes cost_ncc in double (twoviewstereo.cpp:909-977); this variant keeps the
+// same sums but holds the windows, the gray rows and every partial sum in float, two candidates per instruction
+// (v_pk_fma_f32 / v_pk_mul_f32 on gfx950: packed FP32 runs at twice the FP64 lane rate, and with every multiply-add
+// fused the block loops need 17 instructions per tap and 8 candidates where the exact form needs 66).  Costs differ
+// from the reference's around the 6th digit, so a winner can change wherever two candidates are that close: the
+// rate is measured against the exact mode (bench.py --arith f32, tests/test_gpu_arith_modes.py), never assumed.
+// Everything outside the block loops is the exact kernel's: the candidate ranges, which columns are computed, the
+// cost-row layout the scan kernel reads (costs are stored as doubles), the general form for windows with unusable
+// taps (evaluated in double on the float tiles).
+//
+// LDS image (floats): windows 32 x 11 x 12, other view 11 x (CHUNK + 24), reference rows 11 x 42: 36 KB instead of
+// 68, and ~150 VGPRs instead of 243: three to four workgroups per CU.
+#include "srh_internal.hpp"
+#include "srh_walk.hpp"
+
+namespace srh {
+
+#define DF_TP 32
+#define DF_G 8
+#define DF_THREADS (DF_TP*DF_G)
+#define DF_NCB 8
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int R, int CHUNK>
+struct DenseSmemF {
+	static constexpr int WS = 2*R + 1;
+	static constexpr int T = WS*WS;
+	static constexpr int WP = (WS + 3) & ~3;                 // taps per window row, padded to 16 bytes
+	static constexpr int WPIX = WS*WP;
+	static constexpr int NRF = (DF_NCB + 2*R + 3) & ~3;      // other-view values a block reads per row (whole b128s)
+	static constexpr int RW = (CHUNK + NRF + 3) & ~3;        // other-view tile width
+	static constexpr int LW = DF_TP + 2*R;
+	float w[DF_TP][WPIX];
+	float rt[WS][RW];
+	float lt[WS][LW];
+	float meanL[DF_TP], totalW[DF_TP], sum2[DF_TP];
+	int lall[DF_TP];
+	int pxmin[DF_TP], pxmax[DF_TP];
+	unsigned char rfull[RW];
+	unsigned char colok[RW];
+	static constexpr int GL_CAP = 2048;
+	unsigned short glist[GL_CAP];
+	int glist_n;
+};
+
+// any validity pattern, in double on the float tiles (same selects as dense_cost_general of srh_dense.hip)
+template <int R, int CHUNK>
+__device__ __noinline__ double dense_cost_general_f32(const DenseSmemF<R, CHUNK> &S, int i, int rc,
+                                                      double weight_cutoff, double bad_ret, double max_color_diff)
+{
+	constexpr int WS = 2*R + 1;
+	constexpr int WP = DenseSmemF<R, CHUNK>::WP;
+	double meanL = 0, meanR = 0, totalWeight = 0.0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row)
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const double gl = S.lt[row][i + col], gr = S.rt[row][rc + col], wt = S.w[i][row*WP + col];
+			const bool ok = gl == gl && gr == gr && wt > weight_cutoff;
+			meanL += ok ? wt*gl : 0.0;
+			meanR += ok ? wt*gr : 0.0;
+			totalWeight += ok ? wt : 0.0;
+		}
+	if (totalWeight < 1e-10) return bad_ret;
+	meanL /= totalWeight;
+	meanR /= totalWeight;
+	double sum1 = 0, sum2 = 0, sum3 = 0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row)
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const double gl = S.lt[row][i + col], gr = S.rt[row][rc + col], wt = S.w[i][row*WP + col];
+			const bool ok = gl == gl && gr == gr && wt > weight_cutoff;
+			const double a = wt*gl - meanL, b = wt*gr - meanR;
+			sum1 += ok ? a*b : 0.0;
+			sum2 += ok ? a*a : 0.0;
+			sum3 += ok ? b*b : 0.0;
+		}
+	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
+	return (v < max_color_diff) ? v : max_color_diff;
+}
+
+template <int R, int CHUNK>
+__global__ __launch_bounds__(DF_THREADS, 3)
+void twoview_dense_cost_f32_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                                   int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
+                                   const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
+                                   Counters *__restrict__ cnt, const double *__restrict__ pconst)
+{
+	typedef DenseSmemF<R, CHUNK> Smem;
+	constexpr int WS = Smem::WS, T = Smem::T, WP = Smem::WP, NRF = Smem::NRF;
+	constexpr int NCB = DF_NCB;
+	static_assert(NCB == 8 && WS % 2 == 1 && CHUNK % 4 == 0, "block = 4 packed pairs; rows in whole b128s");
+	extern __shared__ __align__(16) unsigned char smem_raw[];
+	Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w, H = L.h;
+	const int tiles_per_row = (W + DF_TP - 1)/DF_TP;
+	const int trow = blockIdx.x / tiles_per_row;
+	const int x0 = (blockIdx.x % tiles_per_row)*DF_TP;
+	const int y = y0 + trow;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int i = (tid >> 6)*8 + (lane & 7);
+	const int g = lane >> 3;
+	const int x = x0 + i;
+	const float nanf_ = __builtin_nanf("");
+
+	__shared__ int s_cmin, s_cmax, s_need_pix, s_need_col;
+	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; s_need_pix = 0; s_need_col = 0; }
+	// windows, reference rows, pixel constants: loads issued before the ranges are worked out
+	constexpr int NBW = (T*DF_TP + DF_THREADS - 1)/DF_THREADS;
+	constexpr int NBL = (WS*Smem::LW + DF_THREADS - 1)/DF_THREADS;
+	constexpr int NBR = (WS*Smem::RW + DF_THREADS - 1)/DF_THREADS;
+	static_assert(DF_TP == SRH_WTILE, "tile = window-buffer tile");
+	const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
+	double tw_[NBW], tl_[NBL];
+#pragma unroll
+	for (int k = 0; k < NBW; ++k) {
+		const int idx = tid + k*DF_THREADS;
+		tw_[k] = (idx < T*DF_TP && x0 + (idx % DF_TP) < W) ? wtile[idx] : 0.0;
+	}
+#pragma unroll
+	for (int k = 0; k < NBL; ++k) {
+		const int idx = tid + k*DF_THREADS;
+		const int ty = idx / Smem::LW, tx = idx % Smem::LW;
+		const int gx = x0 - R + tx, gy = y - R + ty;
+		tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : __builtin_nan("");
+	}
+	double pc_[4] = { 0.0, 0.0, 0.0, 0.0 };
+	if (g == 0 && x < W) {
+		const double *pc = pconst + ((size_t)trow*W + x)*4;
+		pc_[0] = pc[0]; pc_[1] = pc[1]; pc_[2] = pc[2]; pc_[3] = pc[3];
+	}
+	__syncthreads();
+	if (g == 0) {
+		int lo = 0, hi = -1;
+		if (x < W && L.mask[(size_t)y*W + x] == 1) {
+			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+			pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
+			if (hi >= lo) hi = dense_cover_hi(lo, hi, NCB, DF_G);   // the same columns as the exact kernel leaves to the scan
+		}
+		S.pxmin[i] = lo; S.pxmax[i] = hi;
+		if (hi >= lo) { atomicMin(&s_cmin, lo); atomicMax(&s_cmax, hi); }
+	}
+	__syncthreads();
+	const int exmin = S.pxmin[i], exmax = S.pxmax[i];
+	const int cmin = s_cmin & ~3, cmax = s_cmax;            // chunks and blocks start on multiples of 4 columns (b128 of floats)
+
+	auto stage_rt = [&](int cs) {
+		float tr_[NBR];
+#pragma unroll
+		for (int k = 0; k < NBR; ++k) {
+			const int idx = tid + k*DF_THREADS;
+			const int ty = idx / Smem::RW, tx = idx % Smem::RW;
+			const int gx = cs - R + tx, gy = y - R + ty;
+			tr_[k] = (cmin <= cmax && idx < WS*Smem::RW && gx >= 0 && gy >= 0 && gx < Rv.w && gy < Rv.h)
+			       ? (float)Rv.gray_tv[(size_t)gy*Rv.w + gx] : nanf_;
+		}
+#pragma unroll
+		for (int k = 0; k < NBR; ++k) {
+			const int idx = tid + k*DF_THREADS;
+			if (idx < WS*Smem::RW) S.rt[idx / Smem::RW][idx % Smem::RW] = tr_[k];
+		}
+	};
+	stage_rt(cmin);
+#pragma unroll
+	for (int k = 0; k < NBW; ++k) {
+		const int idx = tid + k*DF_THREADS;
+		const int t = idx / DF_TP, pi = idx % DF_TP;
+		if (idx < T*DF_TP) S.w[pi][(t / WS)*WP + (t % WS)] = (float)tw_[k];
+	}
+	for (int idx = tid; idx < WS*DF_TP; idx += DF_THREADS)           // the pad taps (read as part of a b128, never used)
+		for (int c = WS; c < WP; ++c) S.w[idx % DF_TP][(idx / DF_TP)*WP + c] = 0.0f;
+#pragma unroll
+	for (int k = 0; k < NBL; ++k) {
+		const int idx = tid + k*DF_THREADS;
+		if (idx < WS*Smem::LW) S.lt[idx / Smem::LW][idx % Smem::LW] = (float)tl_[k];
+	}
+	if (g == 0) {
+		bool all = (x < W) && (exmax >= exmin);
+		float mL = 0, tw = 0, s2 = 0;
+		if (all) { mL = (float)pc_[0]; tw = (float)pc_[1]; s2 = (float)pc_[2]; all = pc_[3] != 0.0; }
+		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
+		if (!all && x < W && exmax >= exmin) s_need_pix = 1;
+	}
+	__syncthreads();
+
+	unsigned n_dev = 0;
+	const Smem &CS = S;
+	for (int cs = cmin; cs <= cmax; cs += CHUNK) {
+		if (cs != cmin) {
+			__syncthreads();
+			stage_rt(cs);
+			__syncthreads();
+		}
+		for (int tx = tid; tx < Smem::RW; tx += DF_THREADS) {
+			bool ok = true;
+#pragma unroll
+			for (int ty = 0; ty < WS; ++ty) { const float v = S.rt[ty][tx]; ok = ok && (v == v); }
+			S.colok[tx] = ok ? 1 : 0;
+		}
+		if (tid == 0) s_need_col = 0;
+		__syncthreads();
+		for (int tx = tid; tx < Smem::RW; tx += DF_THREADS) {
+			bool ok = tx + 2*R < Smem::RW;
+			if (ok) {
+#pragma unroll
+				for (int k = 0; k < WS; ++k) ok = ok && S.colok[tx + k] != 0;
+			}
+			S.rfull[tx] = ok ? 1 : 0;
+			const int c = cs + tx;
+			if (!ok && c >= s_cmin && c <= cmax && tx < CHUNK) s_need_col = 1;
+		}
+		__syncthreads();
+
+		if (x < W && exmax >= exmin) {
+			const int lo = exmin > cs ? exmin : cs;
+			const int hi = exmax < cs + CHUNK - 1 ? exmax : cs + CHUNK - 1;
+			const int lo_e = lo & ~3;
+			const int nblocks = hi >= lo ? (hi - lo_e + NCB)/NCB : 0;
+			double *crow = cost + (size_t)blockIdx.x*cstride*DF_TP + i;      // the exact kernel's tile-transposed rows
+			for (int b = g; b < (CS.lall[i] ? nblocks : 0); b += DF_G) {
+				const int c0 = lo_e + b*NCB;
+				const int rc = c0 - cs;                                      // multiple of 4
+				bool fast = false;
+#pragma unroll
+				for (int j = 0; j < NCB; ++j) {
+					const int c = c0 + j;
+					if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) { fast = true; ++n_dev; }
+				}
+				if (!fast) continue;
+				const float mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
+				// sweep 1: meanR.  acc[m] holds candidates 2m, 2m+1.  A tap at an even window column multiplies the
+				// aligned pairs (r[2k], r[2k+1]); at an odd column the pairs (r[2k+1], r[2k+2]), built once per row.
+				v2f acc[4] = { {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f} };
+#pragma unroll 1
+				for (int row = 0; row < WS; ++row) {
+					float r[NRF], wv[WP];
+					const v4f *rp = reinterpret_cast<const v4f *>(&CS.rt[row][rc]);
+					const v4f *wp = reinterpret_cast<const v4f *>(&CS.w[i][row*WP]);
+#pragma unroll
+					for (int m = 0; m < NRF/4; ++m) { const v4f v = rp[m]; r[4*m] = v.x; r[4*m + 1] = v.y; r[4*m + 2] = v.z; r[4*m + 3] = v.w; }
+#pragma unroll
+					for (int m = 0; m < WP/4; ++m) { const v4f v = wp[m]; wv[4*m] = v.x; wv[4*m + 1] = v.y; wv[4*m + 2] = v.z; wv[4*m + 3] = v.w; }
+#pragma unroll
+					for (int col = 0; col < WS; ++col) {
+						const v2f ww = { wv[col], wv[col] };
+#pragma unroll
+						for (int m = 0; m < 4; ++m) {
+							const v2f rr = { r[col + 2*m], r[col + 2*m + 1] };
+							acc[m] = __builtin_elementwise_fma(ww, rr, acc[m]);
+						}
+					}
+				}
+				v2f mR[4], s1[4], s3[4];
+#pragma unroll
+				for (int m = 0; m < 4; ++m) { mR[m] = -(acc[m]/tw); s1[m] = (v2f){0.f, 0.f}; s3[m] = (v2f){0.f, 0.f}; }
+#pragma unroll 1
+				for (int row = 0; row < WS; ++row) {
+					float r[NRF], wv[WP], av[WS];
+					const v4f *rp = reinterpret_cast<const v4f *>(&CS.rt[row][rc]);
+					const v4f *wp = reinterpret_cast<const v4f *>(&CS.w[i][row*WP]);
+#pragma unroll
+					for (int m = 0; m < NRF/4; ++m) { const v4f v = rp[m]; r[4*m] = v.x; r[4*m + 1] = v.y; r[4*m + 2] = v.z; r[4*m + 3] = v.w; }
+#pragma unroll
+					for (int m = 0; m < WP/4; ++m) { const v4f v = wp[m]; wv[4*m] = v.x; wv[4*m + 1] = v.y; wv[4*m + 2] = v.z; wv[4*m + 3] = v.w; }
+#pragma unroll
+					for (int col = 0; col < WS; ++col) av[col] = CS.lt[row][i + col];
+#pragma unroll
+					for (int col = 0; col < WS; ++col) {
+						const float a = __builtin_fmaf(wv[col], av[col], -mL);        // pixel_gray_l - meanL
+						const v2f ww = { wv[col], wv[col] }, aa = { a, a };
+#pragma unroll
+						for (int m = 0; m < 4; ++m) {
+							const v2f rr = { r[col + 2*m], r[col + 2*m + 1] };
+							const v2f bb = __builtin_elementwise_fma(ww, rr, mR[m]);     // pixel_gray_r - meanR
+							s1[m] = __builtin_elementwise_fma(aa, bb, s1[m]);
+							s3[m] = __builtin_elementwise_fma(bb, bb, s3[m]);
+						}
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < NCB; ++j) {
+					const int c = c0 + j;
+					if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
+						const float q1 = (j & 1) ? s1[j >> 1].y : s1[j >> 1].x, q3 = (j & 1) ? s3[j >> 1].y : s3[j >> 1].x;
+						const float v = 255.0f*(1.0f - fabsf(q1) / sqrtf(s2 * q3));
+						crow[(size_t)(c - exmin)*DF_TP] = (v < (float)P.max_color_diff) ? (double)v : P.max_color_diff;
+					}
+				}
+			}
+		}
+		// the remaining candidates (a tap unusable on either side): select form, spread over the workgroup
+		const bool need_general = s_need_pix != 0 || s_need_col != 0;
+		for (int base = 0; need_general && base < DF_TP*CHUNK; base += Smem::GL_CAP) {
+			if (tid == 0) S.glist_n = 0;
+			__syncthreads();
+			for (int p = base + tid; p < base + Smem::GL_CAP && p < DF_TP*CHUNK; p += DF_THREADS) {
+				const int pi = p / CHUNK, k = p % CHUNK;
+				const int c = cs + k;
+				if (c < S.pxmin[pi] || c > S.pxmax[pi]) continue;
+				if (CS.lall[pi] && CS.rfull[k]) continue;
+				S.glist[atomicAdd(&S.glist_n, 1)] = (unsigned short)(pi*512 + k);
+			}
+			__syncthreads();
+			const int nl = S.glist_n;
+			for (int q = tid; q < nl; q += DF_THREADS) {
+				const int pi = S.glist[q] >> 9, k = S.glist[q] & 511;
+				++n_dev;
+				cost[((size_t)blockIdx.x*cstride + (cs + k - S.pxmin[pi]))*DF_TP + pi] =
+					dense_cost_general_f32<R, CHUNK>(CS, pi, k, P.weight_cutoff, P.bad_ret, P.max_color_diff);
+			}
+		}
+	}
+	block_count_add(&cnt->n_eval_device, n_dev);
+}
+
+template <int R>
+static void launch_f32(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
+                       int y0, int nrows, const double *wbuf, size_t wstride, const double *tnum, double *cost, int cstride,
+                       Counters *cnt, const double *pconst)
+{
+	typedef DenseSmemF<R, 320> Smem;
+	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_f32_kernel<R, 320>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+	hipLaunchKernelGGL((twoview_dense_cost_f32_kernel<R, 320>), grid, dim3(DF_THREADS), sizeof(Smem), st,
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst);
+}
+
+bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                                   int y0, int nrows, const double *wbuf, size_t wstride,
+                                   const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst)
+{
+	const int tiles = (width + DF_TP - 1)/DF_TP;
+	const dim3 grid((unsigned)(tiles*nrows));
+	switch (P.window_radius) {
+	case 5: launch_f32<5>(st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst); return true;
+	case 2: launch_f32<2>(st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst); return true;
+	default: return false;
+	}
+}
+
+} // namespace srh

@@ -86,6 +86,9 @@ void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, doub
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr);
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
+bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                                   int y0, int nrows, const double *wbuf, size_t wstride,
+                                   const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst);
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
                                const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
