@@ -14,6 +14,13 @@ done
 SRH_BENCH_FUSED=1 timeout -k 10 300 $B --workload c3 --steps 5 --warmup 2 --cpu-rows 0 > "$OUT/c3_fused_bench.json" 2>/dev/null
 timeout -k 10 300 $B --workload c3 --arith fma --steps 5 --warmup 2 --cpu-rows 0 > "$OUT/c3_fma_bench.json" 2>/dev/null
 timeout -k 10 300 $B --workload c2 --arith fma --steps 5 --warmup 2 --cpu-rows 0 > "$OUT/c2_fma_bench.json" 2>/dev/null
+timeout -k 10 300 $B --workload c3 --arith f32 --steps 5 --warmup 2 --cpu-rows 0 > "$OUT/c3_f32_bench.json" 2>/dev/null
+timeout -k 10 300 $B --workload c2 --arith f32 --steps 5 --warmup 2 --cpu-rows 0 > "$OUT/c2_f32_bench.json" 2>/dev/null
+# MRF stage (1280x960, K = 9): wall clock per sweep count + per-kernel times
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_mrf" --output-format csv -- python3 profiles/mrf_timing.py > "$OUT/mrf_timing.log" 2>&1
+cp "$(find "$OUT/stats_mrf" -name '*kernel_stats.csv' | head -1)" "$OUT/mrf_kernel_stats.csv" 2>/dev/null
+grep -E "sweeps|stopping" "$OUT/mrf_timing.log" > "$OUT/mrf_timing.txt"
+rm -rf "$OUT/stats_mrf"
 # per-kernel time
 for w in c3 c4 c5; do
 	rocprofv3 --kernel-trace --stats -d "$OUT/stats_$w" --output-format csv -- $B --workload $w --steps 3 --warmup 1 --cpu-rows 0 > "$OUT/stats_$w.log" 2>&1

@@ -54,6 +54,8 @@ json.dump(instr, open(os.path.join(HERE, "pmc_instr.json"), "w"), indent=1, sort
 for name in os.listdir(SRC):
     if name.endswith("_bench.json") or name.endswith("_kernel_stats.csv") or name.endswith("_instruction_mix.txt"):
         shutil.copy(os.path.join(SRC, name), os.path.join(HERE, "r02_" + name))
+if os.path.exists(os.path.join(SRC, "mrf_timing.txt")):
+    shutil.copy(os.path.join(SRC, "mrf_timing.txt"), os.path.join(HERE, "r02_mrf_timing.txt"))
 shutil.copy(os.path.join(SRC, "fp64_sustained_mi355x.txt"), os.path.join(HERE, "microbench", "fp64_sustained_mi355x.txt"))
 print(json.dumps({k: v for k, v in traffic.items() if k != "_source"}, indent=1)[:3000])
 print(json.dumps(instr, indent=1)[:1500])
