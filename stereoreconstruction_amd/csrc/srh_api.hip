@@ -712,13 +712,17 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				launch_full_window(c->stream, O.gray_tv, O.w, O.h, R, O.full);
 				O.full_r = R;
 			}
+			// the label-only part of pointFromDepth, once per pass instead of once per pixel and label
+			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
+			{ Scope s(c, "label_plane_table_kernel");
+			  launch_label_plane_table(c->stream, c->d_views, ref, *p, false, c->tnum); }
 			// list capacity: the longest list seen so far on this context (hint), or a counting
 			// pass the first time; a run that overflows its capacity is repeated with the true maximum
 			int cmax = c->list_cmax_hint;
 			if (cmax <= 0) {
 				HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
 				{ Scope s(c, "twoview_count_kernel");
-				  launch_twoview_count(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->lcount, c->d_cnt, c->d_span); }
+				  launch_twoview_count(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->lcount, c->d_cnt, c->d_span, c->tnum); }
 				int maxc = 0;
 				HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
 				HIP_TRY(hipStreamSynchronize(c->stream));
@@ -753,7 +757,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 					if (rows_mode) {
 						{ Scope s(c, "twoview_rows_list_kernel");
 						  launch_twoview_rows_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
-						                           cnt_band, c->lrowinfo, c->lmeta, smax, c->d_cnt, c->d_span); }
+						                           cnt_band, c->lrowinfo, c->lmeta, smax, c->d_cnt, c->d_span, c->tnum); }
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
@@ -764,7 +768,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 					}
 					{ Scope s(c, "twoview_list_kernel");
 					  launch_twoview_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
-					                      cnt_band, c->d_cnt, c->d_span); }
+					                      cnt_band, c->d_cnt, c->d_span, c->tnum); }
 					{ Scope s(c, "twoview_list_cost_kernel");
 					  launch_twoview_list_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
 					                           cnt_band, c->lcand, c->cost, cmax, c->d_cnt); }

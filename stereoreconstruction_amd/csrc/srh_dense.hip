@@ -234,6 +234,19 @@ __global__ void pinhole_label_table_kernel(const ViewDev *__restrict__ views, in
 	if (d < P.num_depth_levels) tnum[d] = pinhole_label_tnum(views[ref].cam, P, mvs != 0, d);
 }
 
+// per-label plane distance of pointFromDepth for the general walker (any camera model)
+__global__ void label_plane_table_kernel(const ViewDev *__restrict__ views, int ref, srh_params P, int mvs,
+                                         double *__restrict__ tdist)
+{
+	const int d = blockIdx.x*blockDim.x + threadIdx.x;
+	if (d < P.num_depth_levels) tdist[d] = label_plane_dist(views[ref].cam, P, mvs != 0, d);
+}
+
+void launch_label_plane_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tdist) {
+	hipLaunchKernelGGL(label_plane_table_kernel, dim3((unsigned)((P.num_depth_levels + 63)/64)), dim3(64), 0, st,
+	                   views, ref, P, mvs ? 1 : 0, tdist);
+}
+
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum) {
 	hipLaunchKernelGGL(pinhole_label_table_kernel, dim3((unsigned)((P.num_depth_levels + 63)/64)), dim3(64), 0, st,
 	                   views, ref, P, mvs ? 1 : 0, tnum);

@@ -124,8 +124,9 @@ SRH_HD bool quartic_root_0r(double a, double b, double c, double d, double e, do
 	return true;
 }
 
-SRH_HD bool project_refraction(Vec3 &p, Vec3 pn, double pdist, double n) {
-	const Vec3 bn = normalized(pn);
+// bn_pre: normalized(pn) computed by the caller once (it depends on the camera only), or null
+SRH_HD bool project_refraction(Vec3 &p, Vec3 pn, double pdist, double n, const Vec3 *bn_pre = nullptr) {
+	const Vec3 bn = bn_pre ? *bn_pre : normalized(pn);
 	const Vec3 proj = dot(bn, p)*bn;
 	Vec3 dir = p - proj;
 	const double y = dir.y;
@@ -133,7 +134,7 @@ SRH_HD bool project_refraction(Vec3 &p, Vec3 pn, double pdist, double n) {
 	const double r = norm(dir);
 	const double d = pdist;
 	const double rr = r*r, nn = n*n, dd = d*d;
-	dir = normalized(dir);
+	dir = v3(dir.x/r, dir.y/r, dir.z/r);                      // normalized(dir): its norm is r, the same sqrt of the same sum
 	if (isnan_d(dir.x) || isnan_d(dir.y) || isnan_d(dir.z)) return false;
 
 	const double qa = nn - 1;
@@ -155,10 +156,10 @@ SRH_HD bool project_refraction(Vec3 &p, Vec3 pn, double pdist, double n) {
 }
 
 // ---- Camera::project (camera.cpp:380-419); p in/out (x, y, 1)
-SRH_HD bool cam_project(const srh_camera &cam, Vec3 &p) {
+SRH_HD bool cam_project(const srh_camera &cam, Vec3 &p, const Vec3 *plane_bn = nullptr) {
 	Vec3 point = matvec(cam.R, p) + load3(cam.t);
 	if (cam.is_refractive) {
-		if (!project_refraction(point, load3(cam.plane_normal), cam.plane_dist, cam.refr_index)) {
+		if (!project_refraction(point, load3(cam.plane_normal), cam.plane_dist, cam.refr_index, plane_bn)) {
 			p = v3(NAN, NAN, NAN);
 			return false;
 		}

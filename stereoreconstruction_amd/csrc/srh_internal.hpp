@@ -85,6 +85,7 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr);
+void launch_label_plane_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tdist);
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                    int y0, int nrows, const double *wbuf, size_t wstride,
@@ -104,9 +105,10 @@ bool launch_twoview_fused(hipStream_t st, const ViewDev *views, int ref, int oth
 
 // Candidate-list TwoView path for arbitrary geometry, srh_list.hip
 void launch_twoview_count(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                          int y0, int nrows, int32_t *count, Counters *cnt, int *max_count);
+                          int y0, int nrows, int32_t *count, Counters *cnt, int *max_count, const double *tdist);
 void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                         int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count);
+                         int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count,
+                         const double *tdist);
 void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full);
 bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
@@ -148,7 +150,7 @@ void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int o
 #define SRH_ROWS_NR 32
 void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, uint32_t *rowinfo,
-                              int32_t *meta, int smax, Counters *cnt, int *maxes);
+                              int32_t *meta, int smax, Counters *cnt, int *maxes, const double *tdist);
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
                               const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt);

@@ -28,7 +28,7 @@ struct CountVisitor {
 
 __global__ void twoview_count_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                      int y0, int nrows, int32_t *__restrict__ count, Counters *__restrict__ cnt,
-                                     int *__restrict__ max_count)
+                                     int *__restrict__ max_count, const double *__restrict__ tdist)
 {
 	const ViewDev &L = views[ref];
 	const int W = L.w;
@@ -40,7 +40,7 @@ __global__ void twoview_count_kernel(const ViewDev *__restrict__ views, int ref,
 			n_pix = 1;
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 			CountVisitor vis = { 0 };
-			walk_curve<false>(ray, L.cam, views[oth], P, vis);
+			walk_curve<false>(ray, L.cam, views[oth], P, vis, tdist);
 			n_eval = vis.n;
 		}
 		count[q] = (int32_t)n_eval;
@@ -56,11 +56,11 @@ __global__ void twoview_count_kernel(const ViewDev *__restrict__ views, int ref,
 }
 
 void launch_twoview_count(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                          int y0, int nrows, int32_t *count, Counters *cnt, int *max_count)
+                          int y0, int nrows, int32_t *count, Counters *cnt, int *max_count, const double *tdist)
 {
 	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(twoview_count_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-	                   views, ref, oth, P, y0, nrows, count, cnt, max_count);
+	                   views, ref, oth, P, y0, nrows, count, cnt, max_count, tdist);
 }
 
 struct ListVisitor {
@@ -77,7 +77,8 @@ struct ListVisitor {
 // earlier run on the same rig) turns out too small, it reruns with the reported maximum.
 __global__ void twoview_list_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                     int y0, int nrows, uint32_t *__restrict__ cand, int cmax,
-                                    int32_t *__restrict__ count, Counters *__restrict__ cnt, int *__restrict__ max_count)
+                                    int32_t *__restrict__ count, Counters *__restrict__ cnt, int *__restrict__ max_count,
+                                    const double *__restrict__ tdist)
 {
 	const ViewDev &L = views[ref];
 	const int W = L.w;
@@ -89,7 +90,7 @@ __global__ void twoview_list_kernel(const ViewDev *__restrict__ views, int ref, 
 			n_pix = 1;
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 			ListVisitor vis = { cand + q*(size_t)cmax, cmax, 0 };
-			walk_curve<false>(ray, L.cam, views[oth], P, vis);
+			walk_curve<false>(ray, L.cam, views[oth], P, vis, tdist);
 			n_eval = (unsigned)vis.n;
 		}
 		count[q] = (int32_t)n_eval;
@@ -105,11 +106,12 @@ __global__ void twoview_list_kernel(const ViewDev *__restrict__ views, int ref, 
 }
 
 void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
-                         int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count)
+                         int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count,
+                         const double *tdist)
 {
 	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(twoview_list_kernel, dim3((unsigned)((n + 127)/128)), dim3(128), 0, st,
-	                   views, ref, oth, P, y0, nrows, cand, cmax, count, cnt, max_count);
+	                   views, ref, oth, P, y0, nrows, cand, cmax, count, cnt, max_count, tdist);
 }
 
 // ------------------------------------------------------------------ fully usable windows of a view

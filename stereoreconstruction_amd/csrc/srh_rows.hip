@@ -56,7 +56,8 @@ __global__ __launch_bounds__(RW_LT)
 void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                               int y0, int nrows_band, uint32_t *__restrict__ cand, int cmax,
                               int32_t *__restrict__ count, uint32_t *__restrict__ rowinfo, int32_t *__restrict__ meta, int smax,
-                              Counters *__restrict__ cnt, int *__restrict__ maxes /* [0] list length, [1] slots, [2] too many rows */)
+                              Counters *__restrict__ cnt, int *__restrict__ maxes /* [0] list length, [1] slots, [2] too many rows */,
+                              const double *__restrict__ tdist)
 {
 	const ViewDev &L = views[ref];
 	const int W = L.w;
@@ -73,7 +74,7 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			uint32_t *mine = cand + (q >> 6)*(size_t)cmax*64 + (q & 63);
 			for (int r = 0; r < RW_NR; ++r) { s_lo[r][threadIdx.x] = 32767; s_hi[r][threadIdx.x] = -1; }
 			RowsListVisitor vis = { mine, cmax, 0, 0, 0xffffffffu, 2147483647, -1, &s_lo[0][threadIdx.x], &s_hi[0][threadIdx.x] };
-			walk_curve<false>(ray, L.cam, views[oth], P, vis);
+			walk_curve<false>(ray, L.cam, views[oth], P, vis, tdist);
 			n_eval = vis.visited;
 			n_kept = vis.n;
 			const int nr = vis.n > 0 ? vis.ymax - vis.ymin + 1 : 0;
@@ -108,11 +109,11 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 
 void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, uint32_t *rowinfo,
-                              int32_t *meta, int smax, Counters *cnt, int *maxes)
+                              int32_t *meta, int smax, Counters *cnt, int *maxes, const double *tdist)
 {
 	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(twoview_rows_list_kernel, dim3((unsigned)((n + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
-	                   views, ref, oth, P, y0, nrows, cand, cmax, count, rowinfo, meta, smax, cnt, maxes);
+	                   views, ref, oth, P, y0, nrows, cand, cmax, count, rowinfo, meta, smax, cnt, maxes, tdist);
 }
 
 // ------------------------------------------------------------------ blocked cost

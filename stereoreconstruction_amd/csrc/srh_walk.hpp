@@ -13,20 +13,45 @@
 
 namespace srh {
 
+// Plane3d::dist_ of label d's depth plane: dot(n, C + normal*depth_d), n = normalized(normal) -- the part of
+// pointFromDepth (point_from_depth above) that depends on the label only; walk_curve takes it from a table
+// (label_plane_table_kernel) instead of recomputing two divisions, a square root and three more divisions
+// per pixel and label.  The operations are point_from_depth's own, so nothing changes in the results.
+__device__ __forceinline__ double label_plane_dist(const srh_camera &refcam, const srh_params &P, bool mvs, int label) {
+	const Vec3 normal = load3(refcam.pdir);
+	const Vec3 n = normalized(normal);
+	const Vec3 x0 = load3(refcam.C) + normal*depth_from_label(P, mvs, label);
+	return dot(n, x0);
+}
+
+// tdist: label_plane_dist per label, or null (computed in place)
 template <bool MVS, class Visitor>
 __device__ __forceinline__ void walk_curve(const Ray &ray, const srh_camera &refcam, const ViewDev &oth,
-                                           const srh_params &P, Visitor &vis)
+                                           const srh_params &P, Visitor &vis, const double *__restrict__ tdist = nullptr)
 {
 	const Vec3 camC = load3(refcam.C);
 	const Vec3 normal = load3(refcam.pdir);
 	const int OW = oth.w, OH = oth.h;
 	double x1 = __builtin_nan(""), y1 = __builtin_nan("");
 	int lastx = -2147483647, lasty = -2147483647;               // MVS std::unique state
+	// label-independent parts of intersect(ray, plane) and of the other camera's refraction
+	const Vec3 pn = normalized(normal);
+	const double nd = dot(pn, ray.dir);
+	const Vec3 oth_bn = normalized(load3(oth.cam.plane_normal));
 	for (int d = 0; d < P.num_depth_levels; ++d) {
 		Vec3 point = camC;
-		const double depth = depth_from_label(P, MVS, d);
-		if (!point_from_depth(ray, normal, depth, point)) continue;
-		if (!cam_project(oth.cam, point)) continue;
+		if (tdist) {
+			// intersect_plane(ray, pn, tdist[d], point) with n . dir taken out of the loop
+			if (fabs(nd) < 1e-10) continue;
+			const Vec3 x0 = tdist[d]*pn;
+			const double t = dot(pn, x0 - ray.src) / nd;
+			if (t < 1e-10) continue;
+			point = ray.src + t*ray.dir;
+		} else {
+			const double depth = depth_from_label(P, MVS, d);
+			if (!point_from_depth(ray, normal, depth, point)) continue;
+		}
+		if (!cam_project(oth.cam, point, &oth_bn)) continue;
 		const double x2 = point.x*P.image_scale;
 		const double y2 = point.y*P.image_scale;
 		if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
