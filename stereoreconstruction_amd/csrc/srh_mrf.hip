@@ -48,6 +48,13 @@ constexpr int ST_ABORT = 0, ST_WHO = 1, ST_PASS = 2;
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// The per-step barrier.  __syncthreads() carries a workgroup-scope release, which makes a wave wait for its own
+// device-memory operations before it may arrive; what the step barrier has to order is LDS only (the two hand-over
+// buffers): the device-memory results go to other workgroups as granules or to the next launch.
+__device__ __forceinline__ void mrf_step_barrier() {
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int I> __device__ __forceinline__ double bc16(double v) {
 	return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + I, 0xf, 0xf, false);      // row_newbcast:I
 }
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(MRF_THREADS, 1) void mrf_pass_kernel(const MrfPassA
 				}
 			}
 			if (s == nchunks*MRF_CH) break;
-			__syncthreads();                                           // the computing waves' barrier of step s
+			mrf_step_barrier();                                        // the computing waves' barrier of step s
 			if ((s % MRF_CH) == MRF_CH - 1 && s_ctl[1]) break;         // they leave here too
 		}
 		return;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(MRF_THREADS, 1) void mrf_pass_kernel(const MrfPassA
 				down[s & 1][r][kd] = mV;
 				outH[s & 1][r][kd] = mH;
 			}
-			__syncthreads();
+			mrf_step_barrier();
 		}
 		if (s_ctl[1]) break;                                         // a wait gave up: leave (results are reported invalid)
 	}
