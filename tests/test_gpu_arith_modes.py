@@ -84,6 +84,35 @@ def test_f32_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed, radius):
     assert (np.isnan(exact) == np.isnan(f32)).all()                           # no candidate at all: not a matter of precision
 
 
+def test_f32_mode_on_masked_views_bands_and_row_ranges(hip_ctx):
+    """The f32 kernel goes through the same plan as the exact one: masks, a band split, a row range."""
+    import cases
+    case = cases.get_twoview("geodesic_masks", w=96, h=60, D=24)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.twoview_wta(0, 1, p)
+    exact = hip_ctx.download_depth(0)
+    hip_ctx.set_option("arith", 2)
+    try:
+        hip_ctx.twoview_wta(0, 1, p)
+        whole = hip_ctx.download_depth(0)
+        hip_ctx.set_option("band_budget_mb", 1)
+        hip_ctx.twoview_wta(0, 1, p)
+        banded = hip_ctx.download_depth(0)
+        hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.upload_depth(0, np.full_like(whole, -3.0))
+        hip_ctx.twoview_wta(0, 1, p, 7, 41)
+        part = hip_ctx.download_depth(0)
+    finally:
+        hip_ctx.set_option("arith", 0)
+        hip_ctx.set_option("band_budget_mb", 8192)
+    assert np.array_equal(whole.view(np.uint64), banded.view(np.uint64))          # deterministic, band-independent
+    assert np.array_equal(part[7:41].view(np.uint64), whole[7:41].view(np.uint64))
+    assert (part[:7] == -3.0).all() and (part[41:] == -3.0).all()
+    assert (np.isnan(exact) == np.isnan(whole)).all()
+    assert (exact.view(np.uint64) != whole.view(np.uint64)).mean() < 0.10
+
+
 def test_arith_option_validation(hip_ctx):
     with pytest.raises(capi.StereoHipError):
         hip_ctx.set_option("arith", 3)
