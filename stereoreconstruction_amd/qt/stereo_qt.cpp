@@ -137,6 +137,7 @@ MultiViewStereo::MultiViewStereo(int deviceOrdinal)
 	: minDepth(0), maxDepth(0), crossCheckThreshold(0), imageScale(1), numDepthLevels(0), ctx_(nullptr)
 {
 	srh_params_mvs_defaults(&params_);
+	srh_mrf_params_defaults(&mrfParams_);
 	if (srh_create(deviceOrdinal, &ctx_) != SRH_OK) { error_ = srh_last_error(); ctx_ = nullptr; }
 }
 
@@ -203,7 +204,9 @@ void MultiViewStereo::runTask() {
 		if (isCancelled()) return;
 		emit progressUpdate(step++);
 		emit stageUpdate(tr("Computing cost volume for camera %1").arg(views_[v].name));
-		if (srh_mvs_initial_estimate(ctx_, v, &neigh[static_cast<size_t>(v)*nn], count[v], &params_, 0, 0, nullptr) != SRH_OK ||
+		const int32_t *nb = &neigh[static_cast<size_t>(v)*nn];
+		if ((useMrf_ ? srh_mvs_initial_estimate_mrf(ctx_, v, nb, count[v], &params_, &mrfParams_, nullptr)     // #ifdef USE_MRF
+		             : srh_mvs_initial_estimate(ctx_, v, nb, count[v], &params_, 0, 0, nullptr)) != SRH_OK ||
 		    srh_view_depth_download(ctx_, v, computedDepths[v].data()) != SRH_OK) { error_ = srh_last_error(); return; }
 	}
 	emit stageUpdate(tr("Constructing depth maps"));

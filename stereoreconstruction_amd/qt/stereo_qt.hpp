@@ -93,6 +93,9 @@ public:
 	const srq::Raster &image(int viewIndex) const { return images[viewIndex]; }
 	const std::vector<unsigned char> &mask(int viewIndex) const { return masks[viewIndex]; }
 	srh_params &params() { return params_; }
+	// CONFIG+=mrf of the reference (USE_MRF, StereoReconstruction.pro:100-103) as a run-time switch; off by default
+	void setUseMRF(bool on) { useMrf_ = on; }
+	srh_mrf_params &mrfParams() { return mrfParams_; }
 	QString lastError() const { return error_; }
 
 protected:
@@ -108,6 +111,8 @@ private:
 	double minDepth, maxDepth, crossCheckThreshold, imageScale;
 	int numDepthLevels;
 	srh_params params_;
+	srh_mrf_params mrfParams_;
+	bool useMrf_ = false;
 	srh_context *ctx_;
 	QString error_;
 };
