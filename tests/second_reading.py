@@ -585,3 +585,149 @@ def refraction_pair_error(view1, view2, p1, p2):
     e1 = (0.5 * view1.K[0, 0] * out) / view1.to_local(mid)[2]
     e2 = (0.5 * view2.K[0, 0] * out) / view2.to_local(mid)[2]
     return e1 + e2
+
+
+# ------------------------------------------------------------------ MRF branch of computeInitialEstimate
+# stereo/multiviewstereo.cpp:481-516 (the two cost functions), 610-652 (optimisation loop, labels -> depths); the
+# optimiser itself is the reference's third-party -lMRF (absent): sequential tree-reweighted message passing
+# (Kolmogorov 2006) on the 4-connected grid, written here from the paper's Figure 3 with numpy label vectors --
+# node potentials theta_hat = D + sum of incoming messages, gamma = 1/2 for a grid (two monotonic chains per node),
+# M_st(k) = min_j { gamma*theta_hat_s(j) - M_ts(j) + V(j, k) }, normalised by its minimum; forward sweep in scan
+# order, backward sweep in reverse order accumulating the lower bound, labels by a final forward sweep.
+class MrfParams:
+    def __init__(self, beta=1.0, lam=1.0, phi_u=0.5, psi_u=0.002, max_iters=50, min_drop=5.0):
+        self.beta, self.lam, self.phi_u, self.psi_u, self.max_iters, self.min_drop = beta, lam, phi_u, psi_u, max_iters, min_drop
+
+
+def mrf_data_costs(peaks, m):
+    """peaks (h, w, K, 2) -> D (h, w, K+1)"""
+    h, w, K, _ = peaks.shape
+    D = np.empty((h, w, K + 1))
+    D[..., :K] = np.where(peaks[..., 1] < 0, m.lam, m.lam * np.exp(-m.beta * peaks[..., 0]))
+    D[..., K] = m.phi_u
+    return D
+
+
+def mrf_smooth_matrix(z1, z2, m):
+    """V[j, k]: label j of the pixel with peak depths z1, label k of the pixel with z2 (last label = unknown)."""
+    K = len(z1)
+    V = np.empty((K + 1, K + 1))
+    for j in range(K + 1):
+        for k in range(K + 1):
+            if j == K and k == K:
+                V[j, k] = 0.0
+            elif j == K or k == K:
+                V[j, k] = m.psi_u
+            elif z1[j] < 0 or z2[k] < 0:
+                V[j, k] = 2 * m.psi_u
+            else:
+                V[j, k] = 2.0 * abs(z1[j] - z2[k]) / (z1[j] + z2[k])
+    return V
+
+
+class Trws:
+    def __init__(self, peaks, m, D=None):
+        self.h, self.w, self.K, _ = peaks.shape
+        self.z = peaks[..., 1]
+        self.m = m
+        self.D = mrf_data_costs(peaks, m) if D is None else np.array(D, dtype=np.float64)
+        L = self.K + 1
+        self.right = np.zeros((self.h, self.w, L))      # message living on the edge (x,y)-(x+1,y)
+        self.down = np.zeros((self.h, self.w, L))       # message living on the edge (x,y)-(x,y+1)
+        self.labels = np.zeros((self.h, self.w), dtype=np.int64)
+
+    def V(self, p, q):
+        return mrf_smooth_matrix(self.z[p[1], p[0]], self.z[q[1], q[0]], self.m)
+
+    def theta_hat(self, x, y):
+        t = self.D[y, x].copy()
+        if x > 0:
+            t = t + self.right[y, x - 1]
+        if y > 0:
+            t = t + self.down[y - 1, x]
+        if x < self.w - 1:
+            t = t + self.right[y, x]
+        if y < self.h - 1:
+            t = t + self.down[y, x]
+        return t
+
+    @staticmethod
+    def send(theta, reverse, V):
+        """new message over an edge whose stored (reverse-direction) message is `reverse`; V[j, k] source j -> dest k"""
+        buf = 0.5 * theta - reverse
+        msg = np.array([min(buf[j] + V[j, k] for j in range(len(buf))) for k in range(V.shape[1])])
+        delta = msg.min()
+        return msg - delta, delta
+
+    def sweep(self):
+        w, h = self.w, self.h
+        for y in range(h):
+            for x in range(w):
+                t = self.theta_hat(x, y)
+                if x < w - 1:
+                    self.right[y, x], _ = self.send(t, self.right[y, x], self.V((x, y), (x + 1, y)))
+                if y < h - 1:
+                    self.down[y, x], _ = self.send(t, self.down[y, x], self.V((x, y), (x, y + 1)))
+        bound = 0.0
+        for y in range(h - 1, -1, -1):
+            for x in range(w - 1, -1, -1):
+                t = self.theta_hat(x, y)
+                lo = t.min()
+                t = t - lo
+                bound += lo
+                if x > 0:
+                    self.right[y, x - 1], d = self.send(t, self.right[y, x - 1], self.V((x, y), (x - 1, y)))
+                    bound += d
+                if y > 0:
+                    self.down[y - 1, x], d = self.send(t, self.down[y - 1, x], self.V((x, y), (x, y - 1)))
+                    bound += d
+        for y in range(h):
+            for x in range(w):
+                t = self.D[y, x].copy()
+                if x > 0:
+                    t = t + self.V((x - 1, y), (x, y))[self.labels[y, x - 1]]
+                if y > 0:
+                    t = t + self.V((x, y - 1), (x, y))[self.labels[y - 1, x]]
+                if x < w - 1:
+                    t = t + self.right[y, x]
+                if y < h - 1:
+                    t = t + self.down[y, x]
+                self.labels[y, x] = int(np.argmin(t))               # first minimum
+        return bound
+
+    def energy(self):
+        e = 0.0
+        for y in range(self.h):
+            for x in range(self.w):
+                e += self.D[y, x, self.labels[y, x]]
+                if x + 1 < self.w:
+                    e += self.V((x, y), (x + 1, y))[self.labels[y, x], self.labels[y, x + 1]]
+                if y + 1 < self.h:
+                    e += self.V((x, y), (x, y + 1))[self.labels[y, x], self.labels[y + 1, x]]
+        return e
+
+    def run(self):
+        """multiviewstereo.cpp:627-641 -> (iterations, initial energy, final energy, lower bound)"""
+        energy = self.energy()
+        e0, iters, bound, left = energy, 0, 0.0, self.m.max_iters
+        while True:
+            prev = energy
+            bound = self.sweep()
+            energy = self.energy()
+            iters += 1
+            cont = prev - energy > self.m.min_drop and left > 0
+            left -= 1
+            if not cont:
+                break
+        return iters, e0, energy, bound
+
+    def depths(self, mask, before):
+        """multiviewstereo.cpp:645-652"""
+        out = np.array(before, dtype=np.float64)
+        for y in range(self.h):
+            for x in range(self.w):
+                if mask[y, x]:
+                    lab = self.labels[y, x]
+                    d = np.inf if lab == self.K else self.z[y, x, lab]
+                    out[y, x] = d if d > 0 else np.inf
+        return out

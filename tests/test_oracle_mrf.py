@@ -101,3 +101,24 @@ def test_data_cost_override_is_what_the_engine_uses():
     assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["messages"].view(np.uint64), b["messages"].view(np.uint64))
     c = O.mvs_mrf(peaks, mask, m, data_costs=D * 3.0)
     assert not np.array_equal(a["labels"], c["labels"])
+
+
+@pytest.mark.parametrize("w,h,K,seed", [(7, 5, 3, 1), (6, 9, 4, 2), (1, 8, 2, 3), (9, 1, 5, 4), (5, 5, 9, 5)])
+def test_oracle_against_the_second_reading(w, h, K, seed):
+    """tests/second_reading.py::Trws is a second implementation of the same published algorithm, typed from the
+    paper with numpy label vectors (it shares no text with oracle/sr_oracle.c or the kernels): sweep counts, labels and
+    depths identical, every stored message, the energies and the lower bound within 1e-12."""
+    import second_reading as S2
+    peaks, mask = mrf_cases.peaks_case(w, h, K=K, seed=40 + seed, fill=0.6, mask_frac=0.8)
+    for over in (dict(), dict(min_energy_drop=-1.0, max_iters=2)):
+        m = O.mrf_params(**over)
+        ref = O.mvs_mrf(peaks, mask, m, depth=np.full((h, w), -5.0), want_messages=True)
+        s2 = S2.Trws(peaks, S2.MrfParams(max_iters=m.max_iters, min_drop=m.min_energy_drop))
+        iters, e0, e1, bound = s2.run()
+        assert iters == ref["iterations"]
+        assert np.array_equal(s2.labels, ref["labels"])
+        assert np.allclose(s2.right, ref["messages"][:, :, 0], rtol=0, atol=1e-12)
+        assert np.allclose(s2.down, ref["messages"][:, :, 1], rtol=0, atol=1e-12)
+        for a, b in ((e0, ref["energy_initial"]), (e1, ref["energy_final"]), (bound, ref["lower_bound"])):
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+        assert np.array_equal(s2.depths(mask, np.full((h, w), -5.0)).view(np.uint64), ref["depth"].view(np.uint64))
