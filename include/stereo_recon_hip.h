@@ -230,6 +230,12 @@ int  srh_mvs_mrf_estimate(srh_context *ctx, int view_slot, int top_k, const void
  * context's own scratch, then srh_mvs_mrf_estimate on them. */
 int  srh_mvs_initial_estimate_mrf(srh_context *ctx, int view_slot, const int32_t *neigh_slots, int nneigh,
                                   const srh_params *p, const srh_mrf_params *m, srh_mrf_info *info);
+/* The same for several views at once: srh_mvs_initial_estimate_peaks keeps a view's peaks in the context, then
+ * srh_mvs_mrf_estimate_views runs the MRF stage of all listed views side by side (a sweep fills a quarter of the
+ * chip and is bound by its own dependency chain; each view stops by the reference's rule for itself) and writes
+ * their depth maps.  infos: nviews entries, may be NULL. */
+int  srh_mvs_initial_estimate_peaks(srh_context *ctx, int view_slot, const int32_t *neigh_slots, int nneigh, const srh_params *p);
+int  srh_mvs_mrf_estimate_views(srh_context *ctx, const int32_t *view_slots, int nviews, const srh_mrf_params *m, srh_mrf_info *infos);
 /* State of the last srh_mvs_mrf_estimate on this context, to HOST buffers (each may be NULL): labels (w*h, what
  * getLabel(p) returns), data_costs (w*h*(top_k+1)), messages (w*h*2*(top_k+1): [pixel][towards x+1, towards y+1][label],
  * the message currently stored on that edge). */

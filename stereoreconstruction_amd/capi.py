@@ -82,6 +82,7 @@ EXPORTS = [
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
     "srh_epipolar_preview", "srh_refraction_error",
     "srh_mrf_params_defaults", "srh_mvs_mrf_estimate", "srh_mvs_mrf_state", "srh_mvs_initial_estimate_mrf",
+    "srh_mvs_initial_estimate_peaks", "srh_mvs_mrf_estimate_views",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
     "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
@@ -134,6 +135,8 @@ def lib():
     L.srh_mrf_params_defaults.restype = None
     L.srh_mvs_mrf_estimate.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
     L.srh_mvs_initial_estimate_mrf.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
+    L.srh_mvs_initial_estimate_peaks.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params)]
+    L.srh_mvs_mrf_estimate_views.argtypes = [vp, c_int32_p, C.c_int, C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
     L.srh_mvs_mrf_state.argtypes = [vp, c_int32_p, c_double_p, c_double_p]
     L.srh_epipolar_preview.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p, c_int32_p]
     L.srh_refraction_error.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
@@ -389,6 +392,19 @@ class Context:
         _check(lib().srh_mvs_initial_estimate_mrf(self._h, view_slot, nb.ctypes.data_as(c_int32_p), len(nb), C.byref(p),
                                                   C.byref(m), C.byref(info)))
         return dict(iterations=info.iterations, energy_initial=info.energy_initial, energy_final=info.energy_final)
+
+    def mvs_initial_estimate_peaks(self, view_slot, neigh_slots, p):
+        """Initial estimate of one view, its top-K peaks kept in the context for mvs_mrf_estimate_views."""
+        nb = np.ascontiguousarray(neigh_slots, dtype=np.int32)
+        _check(lib().srh_mvs_initial_estimate_peaks(self._h, view_slot, nb.ctypes.data_as(c_int32_p), len(nb), C.byref(p)))
+
+    def mvs_mrf_estimate_views(self, view_slots, m=None):
+        """MRF stage of several views side by side -> list of dict(iterations, energy_initial, energy_final)."""
+        m = m if m is not None else mrf_params()
+        sl = np.ascontiguousarray(view_slots, dtype=np.int32)
+        infos = (SrhMrfInfo * len(sl))()
+        _check(lib().srh_mvs_mrf_estimate_views(self._h, sl.ctypes.data_as(c_int32_p), len(sl), C.byref(m), infos))
+        return [dict(iterations=i.iterations, energy_initial=i.energy_initial, energy_final=i.energy_final) for i in infos]
 
     def mvs_mrf_state(self, w, h, top_k):
         """(labels (h,w) int32, data_costs (h,w,K+1), messages (h,w,2,K+1)) of the last MRF run."""

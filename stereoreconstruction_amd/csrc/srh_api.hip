@@ -49,6 +49,9 @@ struct ViewHost {
 	// 0 unknown, 1 row runs (srh_rows.hip), 2 list order (srh_list.hip: steep curves)
 	uint8_t   list_mode[SRH_MAX_VIEWS] = {0};
 	srh_camera cam;
+	// MRF branch over several views (srh_mvs_initial_estimate_peaks / srh_mvs_mrf_estimate_views)
+	double   *peaks = nullptr; size_t peaks_cap = 0; int peaks_k = 0;   // top-K peaks of the last initial estimate
+	double   *mrf = nullptr;   size_t mrf_cap = 0;                      // this view's own TRW-S scratch
 };
 
 struct ProfEntry { double ms = 0; int64_t n = 0; };
@@ -66,6 +69,8 @@ struct srh_context {
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
 	double *cost = nullptr;   size_t cost_cap = 0;      // doubles
 	double *tnum = nullptr;   size_t tnum_cap = 0;      // per-label table of the pinhole walk
+	hipStream_t mrf_stream[SRH_MAX_VIEWS] = { nullptr };            // one stream per view of srh_mvs_mrf_estimate_views
+	void *mrf_host = nullptr;                                       // pinned: per view {energy, pad, status[4]}
 	double *mrf_peaks = nullptr; size_t mrf_peaks_cap = 0;   // top-K peaks of srh_mvs_initial_estimate_mrf
 	double *mrf = nullptr;    size_t mrf_cap = 0;       // MRF stage scratch (srh_mrf.hip); mrf_w/h/k: what the last run left in it
 	int mrf_w = 0, mrf_h = 0, mrf_k = 0;
@@ -157,6 +162,12 @@ static int check_params(const srh_params *p) {
 }
 
 // ------------------------------------------------------------------ library
+// srh_mvs_mrf_estimate_views keeps one stream per view busy; the HIP runtime multiplexes streams onto 4 hardware
+// queues unless told otherwise, which caps that at ~2.5 views in flight (measured: 8 views 277 ms with 4 queues,
+// 212 with 8, 151 with 16).  The variable is read when the runtime initialises, so it is set -- never overwritten --
+// when this library is loaded; a process that has initialised HIP before that keeps its own setting.
+__attribute__((constructor)) static void srh_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" int srh_abi_version(void) { return SRH_ABI_VERSION; }
 extern "C" const char *srh_last_error(void) { return g_err; }
 
@@ -400,6 +411,8 @@ static void free_view(ViewHost &v) {
 	if (v.depth) hipFree(v.depth);
 	if (v.edges) hipFree(v.edges);
 	if (v.full) hipFree(v.full);
+	if (v.peaks) hipFree(v.peaks);
+	if (v.mrf) hipFree(v.mrf);
 	v = ViewHost();
 }
 
@@ -419,6 +432,8 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->pconst) hipFree(c->pconst);
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
+	for (int i = 0; i < SRH_MAX_VIEWS; ++i) if (c->mrf_stream[i]) hipStreamDestroy(c->mrf_stream[i]);
+	if (c->mrf_host) hipHostFree(c->mrf_host);
 	if (c->lcount) hipFree(c->lcount);
 	if (c->lcand) hipFree(c->lcand);
 	if (c->lrowinfo) hipFree(c->lrowinfo);
@@ -1135,6 +1150,95 @@ extern "C" int srh_mvs_initial_estimate_mrf(srh_context *c, int slot, const int3
 	if ((rc = ensure(c->mrf_peaks, c->mrf_peaks_cap, (size_t)v.w*v.h*p->top_k*2))) return rc;
 	if ((rc = srh_mvs_initial_estimate(c, slot, neigh, nneigh, p, 0, 0, c->mrf_peaks))) return rc;
 	return srh_mvs_mrf_estimate(c, slot, p->top_k, c->mrf_peaks, m, info);
+}
+
+extern "C" int srh_mvs_initial_estimate_peaks(srh_context *c, int slot, const int32_t *neigh, int nneigh, const srh_params *p)
+{
+	int rc;
+	if ((rc = check_slot(c, slot, true)) || (rc = check_params(p))) return rc;
+	if (p->top_k < 1 || p->top_k > 15) return fail(SRH_E_UNSUPPORTED, "top_k %d outside [1,15]", p->top_k);
+	HIP_TRY(hipSetDevice(c->device));
+	ViewHost &v = c->views[slot];
+	v.peaks_k = 0;
+	if ((rc = ensure(v.peaks, v.peaks_cap, (size_t)v.w*v.h*p->top_k*2))) return rc;
+	if ((rc = srh_mvs_initial_estimate(c, slot, neigh, nneigh, p, 0, 0, v.peaks))) return rc;
+	v.peaks_k = p->top_k;
+	return SRH_OK;
+}
+
+// The MRF stage of several views at once.  A sweep occupies one workgroup per 16 image rows and is bound by its own
+// dependency chain (60 of 256 CUs at 1280x960), so the views' sweeps run side by side, each on a stream of its own with
+// its own scratch; every view keeps the reference's stopping rule for itself (multiviewstereo.cpp:627-641).
+extern "C" int srh_mvs_mrf_estimate_views(srh_context *c, const int32_t *slots, int nviews, const srh_mrf_params *m, srh_mrf_info *infos)
+{
+	int rc;
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (!slots || nviews < 1 || nviews > SRH_MAX_VIEWS || !m) return fail(SRH_E_INVALID, "bad view list / params");
+	for (int i = 0; i < nviews; ++i) {
+		if ((rc = check_slot(c, slots[i], true))) return rc;
+		if (c->views[slots[i]].peaks_k < 1) return fail(SRH_E_INVALID, "view slot %d has no peaks (srh_mvs_initial_estimate_peaks first)", slots[i]);
+		for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) return fail(SRH_E_INVALID, "view slot %d listed twice", slots[i]);
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	struct HostState { double energy, pad; unsigned status[4]; };
+	if (!c->mrf_host) HIP_TRY(hipHostMalloc(&c->mrf_host, sizeof(HostState)*SRH_MAX_VIEWS, hipHostMallocDefault));
+	HostState *hs = static_cast<HostState *>(c->mrf_host);
+	hipEvent_t ev = nullptr;
+	HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(ev, c->stream));                         // the peaks were written on the context's stream
+	struct Run { int slot, w, h, K, iters, left; double e, prev, e0; bool active; MrfLayout lay; hipStream_t st; double *buf; };
+	std::vector<Run> runs(nviews);
+	auto cleanup = [&](int code) { for (int i = 0; i < nviews; ++i) if (runs[i].st) hipStreamSynchronize(runs[i].st); hipEventDestroy(ev); return code; };
+	for (int i = 0; i < nviews; ++i) {
+		Run &r = runs[i];
+		ViewHost &v = c->views[slots[i]];
+		r.slot = slots[i]; r.w = v.w; r.h = v.h; r.K = v.peaks_k; r.iters = 0; r.left = m->max_iters; r.active = true; r.st = nullptr;
+		if (!c->mrf_stream[i]) { if (hipStreamCreateWithFlags(&c->mrf_stream[i], hipStreamNonBlocking) != hipSuccess) return cleanup(fail(SRH_E_DEVICE, "stream creation failed")); }
+		r.st = c->mrf_stream[i];
+		if ((rc = ensure(v.mrf, v.mrf_cap, mrf_scratch_doubles(r.w, r.h)))) return cleanup(rc);
+		r.buf = v.mrf;
+		if (hipStreamWaitEvent(r.st, ev, 0) != hipSuccess ||
+		    launch_mrf_setup(r.st, r.buf, r.w, r.h, r.K, m->beta, m->lambda, m->phi_u, v.peaks, r.lay) != hipSuccess ||
+		    launch_mrf_energy(r.st, r.buf, r.w, r.h, r.K, m->psi_u) != hipSuccess ||
+		    hipMemcpyAsync(&hs[i], r.lay.energy, sizeof(HostState), hipMemcpyDeviceToHost, r.st) != hipSuccess)
+			return cleanup(fail(SRH_E_DEVICE, "MRF setup of view slot %d failed: %s", r.slot, hipGetErrorString(hipGetLastError())));
+	}
+	for (int i = 0; i < nviews; ++i) {
+		if (hipStreamSynchronize(runs[i].st) != hipSuccess) return cleanup(fail(SRH_E_DEVICE, "MRF setup of view slot %d failed", runs[i].slot));
+		runs[i].e = runs[i].e0 = hs[i].energy;
+	}
+	for (int nactive = nviews; nactive > 0; ) {
+		if (cancelled(c)) return cleanup(fail(SRH_E_CANCELLED, "cancelled"));
+		for (int i = 0; i < nviews; ++i) {
+			Run &r = runs[i];
+			if (!r.active) continue;
+			r.prev = r.e;
+			if (launch_mrf_sweep(r.st, r.buf, r.w, r.h, r.K, m->psi_u, r.iters) != hipSuccess ||
+			    launch_mrf_energy(r.st, r.buf, r.w, r.h, r.K, m->psi_u) != hipSuccess ||
+			    hipMemcpyAsync(&hs[i], r.lay.energy, sizeof(HostState), hipMemcpyDeviceToHost, r.st) != hipSuccess)
+				return cleanup(fail(SRH_E_DEVICE, "MRF sweep of view slot %d failed: %s", r.slot, hipGetErrorString(hipGetLastError())));
+		}
+		for (int i = 0; i < nviews; ++i) {
+			Run &r = runs[i];
+			if (!r.active) continue;
+			if (hipStreamSynchronize(r.st) != hipSuccess) return cleanup(fail(SRH_E_DEVICE, "MRF sweep of view slot %d failed", r.slot));
+			if (hs[i].status[0])
+				return cleanup(fail(SRH_E_DEVICE, "MRF sweep %u of view slot %d: band %u waited too long for the band above", hs[i].status[2], r.slot, hs[i].status[1] - 1));
+			r.e = hs[i].energy;
+			++r.iters;
+			if (!(r.prev - r.e > m->min_energy_drop && r.left-- > 0)) {     // do { ... } while (prev - energy > 5 && numIters-- > 0)
+				r.active = false; --nactive;
+				if (launch_mrf_depth(r.st, c->d_views, r.slot, r.buf, r.w, r.h, r.K) != hipSuccess)
+					return cleanup(fail(SRH_E_DEVICE, "MRF depth of view slot %d failed", r.slot));
+			}
+		}
+	}
+	for (int i = 0; i < nviews; ++i) {
+		if (hipStreamSynchronize(runs[i].st) != hipSuccess) return cleanup(fail(SRH_E_DEVICE, "MRF depth of view slot %d failed", runs[i].slot));
+		if (infos) { infos[i].iterations = runs[i].iters; infos[i].energy_initial = runs[i].e0; infos[i].energy_final = runs[i].e; }
+	}
+	hipEventDestroy(ev);
+	return SRH_OK;
 }
 
 extern "C" int srh_mvs_mrf_state(srh_context *c, int32_t *labels, double *data_costs, double *messages)

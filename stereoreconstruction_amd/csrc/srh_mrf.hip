@@ -39,7 +39,8 @@ constexpr int MRF_CH = 4;               // steps per prefetched chunk
 constexpr int MRF_THREADS = 320;        // 4 waves that compute (16 rows x 16 label lanes) + 1 that stores
 constexpr int MRF_LAG = 12;             // columns a band drops behind the one above once it had to wait for it
 constexpr unsigned MRF_SPIN_LIMIT = 1u << 21;
-constexpr size_t MRF_LDS_BYTES = 96*1024;   // more than half of a CU's LDS: one band per CU (hand-off form, and 1 wave per SIMD)
+constexpr size_t MRF_LDS_BYTES = 12*1024;   // two hand-over buffers of 2 x 2 KB, labels, control words (several bands may share a CU:
+                                            // bands of other views' sweeps running at the same time fill each other's waits)
 
 // sync block (4 unsigned words, zeroed before every pass): [0] ticket
 // status block (zeroed once per run): [0] abort, [1] first band that gave up + 1, [2] pass it gave up in + 1

@@ -121,8 +121,17 @@ void MultiViewStereo::runTask() {
 		emitProgress(current_step++);
 		emitStage("Computing cost volume for camera " + views[v]->name());
 		const int32_t *nb = &neigh[static_cast<size_t>(v)*params_.num_neighbours];
-		const int rc = useMrf_ ? srh_mvs_initial_estimate_mrf(ctx_, v, nb, count[v], &params_, &mrfParams_, nullptr)   // #ifdef USE_MRF, :610-652
+		// #ifdef USE_MRF (:610-652): the peaks are kept and the MRF stage of all views runs afterwards, side by side
+		// (the views' estimates do not depend on each other: the same results as one view after the other)
+		const int rc = useMrf_ ? srh_mvs_initial_estimate_peaks(ctx_, v, nb, count[v], &params_)
 		                       : srh_mvs_initial_estimate(ctx_, v, nb, count[v], &params_, 0, 0, nullptr);
+		if (rc == SRH_E_CANCELLED || isCancelled()) { srh_set_hooks(ctx_, nullptr, nullptr, nullptr); return; }
+		if (rc != SRH_OK) { error_ = srh_last_error(); srh_set_hooks(ctx_, nullptr, nullptr, nullptr); return; }
+	}
+	if (useMrf_) {
+		std::vector<int32_t> all(nv);
+		for (int v = 0; v < nv; ++v) all[v] = v;
+		const int rc = srh_mvs_mrf_estimate_views(ctx_, all.data(), nv, &mrfParams_, nullptr);
 		if (rc == SRH_E_CANCELLED || isCancelled()) { srh_set_hooks(ctx_, nullptr, nullptr, nullptr); return; }
 		if (rc != SRH_OK) { error_ = srh_last_error(); srh_set_hooks(ctx_, nullptr, nullptr, nullptr); return; }
 	}

@@ -205,10 +205,16 @@ void MultiViewStereo::runTask() {
 		emit progressUpdate(step++);
 		emit stageUpdate(tr("Computing cost volume for camera %1").arg(views_[v].name));
 		const int32_t *nb = &neigh[static_cast<size_t>(v)*nn];
-		if ((useMrf_ ? srh_mvs_initial_estimate_mrf(ctx_, v, nb, count[v], &params_, &mrfParams_, nullptr)     // #ifdef USE_MRF
-		             : srh_mvs_initial_estimate(ctx_, v, nb, count[v], &params_, 0, 0, nullptr)) != SRH_OK ||
-		    srh_view_depth_download(ctx_, v, computedDepths[v].data()) != SRH_OK) { error_ = srh_last_error(); return; }
+		if ((useMrf_ ? srh_mvs_initial_estimate_peaks(ctx_, v, nb, count[v], &params_)                        // #ifdef USE_MRF: peaks kept,
+		             : srh_mvs_initial_estimate(ctx_, v, nb, count[v], &params_, 0, 0, nullptr)) != SRH_OK) { error_ = srh_last_error(); return; }
 	}
+	if (useMrf_) {                                                                                            // ... the MRF stage of all views side by side
+		std::vector<int32_t> all(V);
+		for (int v = 0; v < V; ++v) all[v] = v;
+		if (srh_mvs_mrf_estimate_views(ctx_, all.data(), V, &mrfParams_, nullptr) != SRH_OK) { error_ = srh_last_error(); return; }
+	}
+	for (int v = 0; v < V; ++v)
+		if (srh_view_depth_download(ctx_, v, computedDepths[v].data()) != SRH_OK) { error_ = srh_last_error(); return; }
 	emit stageUpdate(tr("Constructing depth maps"));
 	for (int v = 0; v < V; ++v) colorize(v);
 	emit stageUpdate(tr("Cross-checking"));

@@ -137,3 +137,31 @@ def test_mrf_argument_errors(hip_ctx):
         hip_ctx.mvs_mrf_estimate(0, 0, pk.data_ptr())
     with pytest.raises(capi.StereoHipError):
         hip_ctx.mvs_mrf_estimate(41, 3, pk.data_ptr())
+
+
+def test_mrf_of_several_views_side_by_side(hip_ctx):
+    """srh_mvs_initial_estimate_peaks + srh_mvs_mrf_estimate_views: the MRF stage of all views in flight together
+    (one stream and one scratch buffer per view) gives each view exactly what the one-view entry point gives it."""
+    case = cases.get_mvs("mvs_geodesic", w=48, h=36, D=20, nviews=3)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    neigh = O.mvs_neighbours(ocams, op)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    one = []
+    for v in range(3):
+        info = hip_ctx.mvs_initial_estimate_mrf(v, neigh[v], p)
+        one.append((info, hip_ctx.download_depth(v)))
+    for v in range(3):
+        hip_ctx.upload_depth(v, np.full((36, 48), -9.0))
+        hip_ctx.mvs_initial_estimate_peaks(v, neigh[v], p)
+    infos = hip_ctx.mvs_mrf_estimate_views([0, 1, 2])
+    for v in range(3):
+        assert infos[v] == one[v][0], (v, infos[v], one[v][0])
+        assert np.array_equal(hip_ctx.download_depth(v).view(np.uint64), one[v][1].view(np.uint64))
+    # a subset, in another order, with its own stopping parameters
+    infos = hip_ctx.mvs_mrf_estimate_views([2, 0], capi.mrf_params(min_energy_drop=-1.0, max_iters=1))
+    assert [i["iterations"] for i in infos] == [2, 2]
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.mvs_mrf_estimate_views([0, 0])
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.mvs_mrf_estimate_views([0, 7])                   # a slot without an image / without peaks
