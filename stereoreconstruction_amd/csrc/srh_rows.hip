@@ -400,7 +400,10 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				if (fast) {
 					// blocked fast form (srh_dense.hip): a row segment of NCB+2R values of the other view is
 					// read once per window row and shared by the NCB candidates and 2R+1 taps
-					const double *rbase = Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R);
+					// (a global pointer, not a generic one: flat loads would share the LDS counter, and every wait for a
+					// weight would then also wait for the row segments in flight)
+					typedef const __attribute__((address_space(1))) double *gptr;
+					const gptr rbase = (gptr)(Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R));
 					double acc[RC_NCB];
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) acc[j] = 0.0;
