@@ -404,52 +404,85 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					// weight would then also wait for the row segments in flight)
 					typedef const __attribute__((address_space(1))) double *gptr;
 					const gptr rbase = (gptr)(Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R));
-					double acc[RC_NCB];
+					// Both sweeps are scheduled by hand like the dense kernel's (srh_dense.hip): r[] / wv[] / av[] hold the
+					// current window row; as soon as a value has had its last use its register is refilled with the next
+					// row's value (the other view's segment from L1/L2, the weights and the reference row from LDS), so the
+					// loads are always a row ahead; products first, sums second, so that no instruction waits on its neighbour.
+					static_assert(WS % 2 == 1 && WP % 2 == 0, "odd window, window rows padded to 16 bytes");
+					double r[NR_], wv[WS], acc[RC_NCB];
+					{
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
+#pragma unroll
+						for (int k = 0; k < NR_; ++k) r[k] = rbase[k];
+#pragma unroll
+						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][WS - 1];
+					}
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) acc[j] = 0.0;
-					// the next window row's segment is in flight while the current one is consumed
-					double rn[NR_];
-#pragma unroll
-					for (int k = 0; k < NR_; ++k) rn[k] = rbase[k];
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
-						double rr[NR_], wv[WS];
-#pragma unroll
-						for (int k = 0; k < NR_; ++k) rr[k] = rn[k];
-						const int nrow = row + 1 < WS ? row + 1 : 0;           // after the last row: row 0 for the second sweep
-#pragma unroll
-						for (int k = 0; k < NR_; ++k) rn[k] = rbase[(size_t)nrow*OW + k];
-#pragma unroll
-						for (int col = 0; col < WS; ++col) wv[col] = CS.w[i][row*WP + col];
+						const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for the second sweep
+						const gptr rp = rbase + (size_t)nrow*OW;
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
+							double pr[RC_NCB];
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) acc[j] += wv[col]*rr[col + j];   // meanR += weight*gray
+							for (int j = 0; j < RC_NCB; ++j) pr[j] = wv[col]*r[col + j];
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) acc[j] += pr[j];            // meanR += weight*gray
+							__builtin_amdgcn_sched_barrier(0);                  // keep each refill where it is written
+							if (col & 1) {                                      // r[col-1], r[col], wv[col-1], wv[col] are dead
+								r[col - 1] = rp[col - 1]; r[col] = rp[col];
+								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
+								__builtin_amdgcn_sched_barrier(0);
+							}
 						}
+#pragma unroll
+						for (int k = WS - 1; k < NR_; ++k) r[k] = rp[k];
+						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
 					}
-					double mR[RC_NCB], s1[RC_NCB], s3[RC_NCB];
+					double mR[RC_NCB], s1[RC_NCB], s3[RC_NCB], av[WS];
+#pragma unroll
+					for (int col = 0; col < WS; ++col) av[col] = CS.lt[0][i + col];
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) { mR[j] = acc[j]/tw; s1[j] = 0.0; s3[j] = 0.0; }
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
-						double rr[NR_], wv[WS], av[WS];
-#pragma unroll
-						for (int k = 0; k < NR_; ++k) rr[k] = rn[k];
-						const int nrow = row + 1 < WS ? row + 1 : row;
-#pragma unroll
-						for (int k = 0; k < NR_; ++k) rn[k] = rbase[(size_t)nrow*OW + k];
-#pragma unroll
-						for (int col = 0; col < WS; ++col) { wv[col] = CS.w[i][row*WP + col]; av[col] = CS.lt[row][i + col]; }
+						const int nrow = row + 1 < WS ? row + 1 : 0;
+						const gptr rp = rbase + (size_t)nrow*OW;
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const double *lp = &CS.lt[nrow][i];
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
-							const double a = wv[col]*av[col] - mL;                    // pixel_gray_l - meanL
+							const double wt = wv[col];
+							double bb[RC_NCB], u1[RC_NCB], u3[RC_NCB];
+							const double pa = wt*av[col];
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) {
-								const double bb = wv[col]*rr[col + j] - mR[j];        // pixel_gray_r - meanR
-								s1[j] += a*bb;
-								s3[j] += bb*bb;
+							for (int j = 0; j < RC_NCB; ++j) bb[j] = wt*r[col + j];
+							__builtin_amdgcn_sched_barrier(0);
+							const double a = pa - mL;                           // pixel_gray_l - meanL
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+							__builtin_amdgcn_sched_barrier(0);
+							av[col] = lp[col];
+							if (col & 1) {
+								r[col - 1] = rp[col - 1]; r[col] = rp[col];
+								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
 							}
+							__builtin_amdgcn_sched_barrier(0);
 						}
+#pragma unroll
+						for (int k = WS - 1; k < NR_; ++k) r[k] = rp[k];
+						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
 					}
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
