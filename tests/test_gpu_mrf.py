@@ -165,3 +165,10 @@ def test_mrf_of_several_views_side_by_side(hip_ctx):
         hip_ctx.mvs_mrf_estimate_views([0, 0])
     with pytest.raises(capi.StereoHipError):
         hip_ctx.mvs_mrf_estimate_views([0, 7])                   # a slot without an image / without peaks
+
+
+def test_trws_at_the_size_of_a_c4_view(hip_ctx):
+    """1280x960, K = 9 (60 bands): two sweeps, every label, message and depth against the oracle (about 10 s of it)."""
+    peaks, mask = mrf_cases.peaks_case_fast(1280, 960, K=9, seed=21)
+    info, ref = _check_against_oracle(hip_ctx, peaks, mask, dict(min_energy_drop=-1.0, max_iters=1), "1280x960")
+    assert info["iterations"] == 2 and info["energy_final"] < info["energy_initial"]
