@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--arith", default="exact", choices=["exact", "fma", "f32"],
                     help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
                          "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline line only: skip the short driver-timed legs of the other BASELINE configurations")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -318,7 +320,7 @@ def main():
 
     ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    for opt in ("fused",):                     # tuning knobs (timing only / path choice; results are identical)
+    for opt in ("fused", "exp_repeat", "exp_lds_pad", "strip"):   # tuning knobs (timing only / path choice; results are identical)
         if os.environ.get("SRH_BENCH_" + opt.upper()):
             ctx.set_option(opt, int(os.environ["SRH_BENCH_" + opt.upper()]))
     ctx.upload_view(0, L, ml, cl)

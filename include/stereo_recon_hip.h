@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 2
+#define SRH_ABI_VERSION 3
 
 enum {
 	SRH_OK = 0,
@@ -90,6 +90,8 @@ typedef struct srh_stats {
 	int64_t n_eval_device;   /* cost evaluations actually performed on the device */
 	int32_t used_dense_path; /* 1 if the row-aligned dense kernels ran */
 	int32_t used_fused_kernel; /* 1 if that was the single fused kernel (cost rows never leave the CU) */
+	int32_t used_strip_kernel; /* 1 if the cost kernel was the persistent strip form (srh_strip.hip) */
+	int32_t reserved;
 } srh_stats;
 
 typedef struct srh_context srh_context;
@@ -102,6 +104,11 @@ typedef void (*srh_progress_fn)(int step, const char *stage, void *user);
 int         srh_abi_version(void);
 const char *srh_last_error(void);
 int         srh_device_count(int *count);
+/* Hardware queues the HIP runtime was asked for (GPU_MAX_HW_QUEUES in the process environment, else the runtime's
+ * default of 4).  srh_mvs_mrf_estimate_views keeps one stream per view busy: with 16 queues the MRF stage of 8 views
+ * takes 150 ms, with the default 4 queues 277 ms (profiles/r02_mrf_views.txt).  The variable is read when HIP
+ * initialises, so the HOST APPLICATION sets it before its first HIP call; this library never alters the environment. */
+int         srh_hw_queues_requested(void);
 
 /* ---- parameters and cameras (host-side math only) ---- */
 void srh_params_twoview_defaults(srh_params *p);   /* twoviewstereo.cpp:64-80 */
@@ -147,6 +154,9 @@ int  srh_synchronize(srh_context *ctx);
  *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
  *                     not only for rigs the host check accepts (the device verifies every candidate and the
  *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)
+ *   "strip"           1 (default): the dense cost kernel runs in its persistent strip form (one workgroup walks a
+ *                     tile column down the rows, every input enters LDS by LDS-DMA); 0: one workgroup per tile;
+ *                     4 / 8: force the 4-wave / 8-wave form of the strip kernel.  Results are identical bits.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
  *   "band_budget_mb"  device scratch per row band (default 8192) */
 int  srh_set_option(srh_context *ctx, const char *name, long value);

@@ -43,7 +43,7 @@ int main() {
 	double *d, *seed; unsigned long long *st;
 	hipMalloc(&d, sizeof(double)*256*256*16); hipMalloc(&seed, sizeof(double)*2048); hipMalloc(&st, 16*256*16);
 	hipMemcpy(seed, h.data(), sizeof(double)*2048, hipMemcpyHostToDevice);
-	for (int wpc : {2, 4}) {
+	for (int wpc : {1, 2, 4}) {
 		const int blocks = 256*wpc;
 		hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 		// >= 2 s of back-to-back launches first, then the measured launch

@@ -65,14 +65,15 @@ class SrhMrfInfo(C.Structure):
 class Stats(C.Structure):
     """srh_stats"""
     _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
-                ("used_dense_path", C.c_int32), ("used_fused_kernel", C.c_int32)]
+                ("used_dense_path", C.c_int32), ("used_fused_kernel", C.c_int32),
+                ("used_strip_kernel", C.c_int32), ("reserved", C.c_int32)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 
 # every symbol include/stereo_recon_hip.h declares
 EXPORTS = [
-    "srh_abi_version", "srh_last_error", "srh_device_count",
+    "srh_abi_version", "srh_last_error", "srh_device_count", "srh_hw_queues_requested",
     "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_camera_from_p",
     "srh_mvs_neighbours",
     "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
@@ -473,7 +474,8 @@ class Context:
         s = Stats()
         _check(lib().srh_get_stats(self._h, C.byref(s)))
         return dict(n_pixels=s.n_pixels, n_eval=s.n_eval, n_eval_device=s.n_eval_device,
-                    used_dense_path=bool(s.used_dense_path), used_fused_kernel=bool(s.used_fused_kernel))
+                    used_dense_path=bool(s.used_dense_path), used_fused_kernel=bool(s.used_fused_kernel),
+                    used_strip_kernel=bool(s.used_strip_kernel))
 
     def profile_enable(self, on=True):
         _check(lib().srh_profile_enable(self._h, int(on)))

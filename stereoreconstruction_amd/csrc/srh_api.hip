@@ -45,6 +45,9 @@ struct ViewHost {
 	double   *edges = nullptr;     // 4 planes of neighbour colour distances (geodesic windows)
 	uint8_t  *full = nullptr;      // 1 where the whole (2*full_r+1)^2 TwoView window is usable
 	int       full_r = 0;
+	// strip kernel (srh_strip.hip): NaN-bordered copy of gray_tv, zero-bordered "window fully usable" plane for radius fullp_r
+	double   *tvp = nullptr;   bool tvp_valid = false;
+	uint8_t  *fullp = nullptr; int fullp_r = 0;
 	// how the candidate lists of this view against slot j are best evaluated, learnt from the last run:
 	// 0 unknown, 1 row runs (srh_rows.hip), 2 list order (srh_list.hip: steep curves)
 	uint8_t   list_mode[SRH_MAX_VIEWS] = {0};
@@ -75,6 +78,9 @@ struct srh_context {
 	double *mrf = nullptr;    size_t mrf_cap = 0;       // MRF stage scratch (srh_mrf.hip); mrf_w/h/k: what the last run left in it
 	int mrf_w = 0, mrf_h = 0, mrf_k = 0;
 	double *pconst = nullptr; size_t pconst_cap = 0;    // per-pixel constants of the dense kernel's fast form (4 doubles per pixel of a band)
+	PixRange *prange = nullptr; size_t prange_cap = 0;  // per-pixel candidate column range of a band (strip kernel, scan)
+	int strip = 1;                                      // option "strip": 1 = persistent strip cost kernel (default), 0 = one workgroup per tile, 4 / 8 = force the 4- / 8-wave form
+	int num_cus = 256;
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
@@ -163,10 +169,14 @@ static int check_params(const srh_params *p) {
 
 // ------------------------------------------------------------------ library
 // srh_mvs_mrf_estimate_views keeps one stream per view busy; the HIP runtime multiplexes streams onto 4 hardware
-// queues unless told otherwise, which caps that at ~2.5 views in flight (measured: 8 views 277 ms with 4 queues,
-// 212 with 8, 151 with 16).  The variable is read when the runtime initialises, so it is set -- never overwritten --
-// when this library is loaded; a process that has initialised HIP before that keeps its own setting.
-__attribute__((constructor)) static void srh_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// queues unless the process asks for more BEFORE HIP initialises (GPU_MAX_HW_QUEUES=16; measured: 8 views 277 ms
+// with 4 queues, 212 with 8, 151 with 16).  The library never touches the environment: the host application sets
+// the variable (bench.py and profiles/mrf_views.py do), srh_hw_queues_requested() reports what applies.
+extern "C" int srh_hw_queues_requested(void) {
+	const char *s = getenv("GPU_MAX_HW_QUEUES");
+	const int n = s ? atoi(s) : 0;
+	return n > 0 ? n : 4;                                       // the HIP runtime's default
+}
 
 extern "C" int srh_abi_version(void) { return SRH_ABI_VERSION; }
 extern "C" const char *srh_last_error(void) { return g_err; }
@@ -382,6 +392,8 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (const char *s = getenv("SRH_WBUF_MB")) { long mb = atol(s); if (mb > 0) c->wbuf_budget = (size_t)mb << 20; }
 	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
 	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
+	if (const char *s = getenv("SRH_STRIP")) c->strip = atoi(s);
+	{ int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
 	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
 	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
 	c->stream = c->own_stream;
@@ -411,6 +423,8 @@ static void free_view(ViewHost &v) {
 	if (v.depth) hipFree(v.depth);
 	if (v.edges) hipFree(v.edges);
 	if (v.full) hipFree(v.full);
+	if (v.tvp) hipFree(v.tvp);
+	if (v.fullp) hipFree(v.fullp);
 	if (v.peaks) hipFree(v.peaks);
 	if (v.mrf) hipFree(v.mrf);
 	v = ViewHost();
@@ -430,6 +444,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->cost) hipFree(c->cost);
 	if (c->tnum) hipFree(c->tnum);
 	if (c->pconst) hipFree(c->pconst);
+	if (c->prange) hipFree(c->prange);
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
 	for (int i = 0; i < SRH_MAX_VIEWS; ++i) if (c->mrf_stream[i]) hipStreamDestroy(c->mrf_stream[i]);
@@ -465,11 +480,19 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		c->arith = (int)value; return SRH_OK;
 	}
 	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
+	if (!strcmp(name, "strip")) {
+		if (value != 0 && value != 1 && value != 4 && value != 8) return fail(SRH_E_INVALID, "strip must be 0, 1, 4 or 8");
+		c->strip = (int)value; return SRH_OK;
+	}
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
 		return SRH_OK;
 	}
+#ifdef SRH_EXPERIMENT
+	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
+	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
+#endif
 	return fail(SRH_E_INVALID, "unknown option '%s'", name);
 }
 
@@ -504,6 +527,9 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	}
 	v.cam = *cam;
 	v.full_r = 0;                                               // recomputed on demand for the new pixels
+	v.tvp_valid = false; v.fullp_r = 0;
+	v.peaks_k = 0;                                              // the top-K peaks belonged to the previous image
+	if (c->mrf_w == w && c->mrf_h == h) c->mrf_w = c->mrf_h = c->mrf_k = 0;
 	for (int j = 0; j < SRH_MAX_VIEWS; ++j) { v.list_mode[j] = 0; c->views[j].list_mode[slot] = 0; }   // new geometry
 	HIP_TRY(hipMemcpyAsync(v.rgba, rgba, n*4, hipMemcpyHostToDevice, c->stream));
 	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
@@ -594,11 +620,25 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.used_dense_path = used_dense;
 	c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 #ifdef SRH_PROFILE_PHASES
+	if (h.dbg_waves && h.dbg_blocks && h.dbg_phase[3] && h.strip_ticket) {
+		const double nw = (double)h.dbg_waves, nt = (double)h.dbg_blocks/nw;
+		fprintf(stderr, "[srh dbg] strip: waves %llu, tiles/wave %.1f (%.1f with phase 2), cycles/wave %.0f | per tile: ticket %.0f  own requests %.0f  barriers %.0f  setup %.0f  "
+		        "block loops %.0f  p2 lists %.0f  p2 blocks %.0f  p2 singles %.0f\n", h.dbg_waves, nt, (double)h.dbg_cycles/nw, (double)h.dbg_total_cycles/nw,
+		        h.dbg_phase[0]/nw/nt, h.dbg_phase[1]/nw/nt, h.dbg_phase[2]/nw/nt, h.dbg_phase[3]/nw/nt, h.dbg_phase[4]/nw/nt,
+		        h.dbg_phase[5]/nw/nt, h.dbg_phase[6]/nw/nt, h.dbg_phase[7]/nw/nt);
+		static const char *names[8] = { "ticket", "own requests", "barriers", "setup", "block loops", "p2 lists", "p2 blocks", "p2 singles" };
+		const int nwv = h.dbg_wave[8*4 + 4] ? 8 : 4;
+		for (int k = 0; k < 8; ++k) {
+			fprintf(stderr, "[srh dbg]   %-13s by wave:", names[k]);
+			for (int w = 0; w < nwv; ++w) fprintf(stderr, " %8.0f", h.dbg_wave[8*k + w]/((double)h.dbg_blocks/nwv));
+			fprintf(stderr, "\n");
+		}
+	} else
 	if (h.dbg_waves && !c->last_fused)
 		fprintf(stderr, "[srh dbg] dense: waves %llu, cycles/wave %.0f, fast blocks/wave %.1f, cycles/fast block %.0f\n",
 		        h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_blocks/h.dbg_waves,
 		        h.dbg_blocks ? (double)h.dbg_cycles/h.dbg_blocks : 0.0);
-	if (h.dbg_waves && !c->last_fused)
+	if (h.dbg_waves && !c->last_fused && !h.strip_ticket)
 		fprintf(stderr, "[srh dbg] phases/wave: stage_w %.0f prologue %.0f sync %.0f stage_rt %.0f compute %.0f tail %.0f\n",
 		        (double)h.dbg_phase[0]/h.dbg_waves, (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
 		        (double)h.dbg_phase[3]/h.dbg_waves, (double)h.dbg_phase[4]/h.dbg_waves, (double)h.dbg_phase[5]/h.dbg_waves);
@@ -621,13 +661,13 @@ static int fetch_counters(srh_context *c, int used_dense) {
 
 // support windows of rows [by, by+nr) of view `ref` into c->wbuf
 static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int by, int nr, size_t wstride,
-                        double *pconst = nullptr) {
+                        double *pconst = nullptr, bool wimg = false) {
 	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic) {
 		Scope s(c, "geodesic_reg_kernel");
-		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride, pconst)) return;
+		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride, pconst, wimg)) return;
 	}
 	Scope s(c, "weights_kernel");
-	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride, pconst);
+	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride, pconst, wimg);
 }
 
 // Can every epipolar curve of `a` in `b` stay on its own image row?  Undistorted, non-refractive
@@ -715,7 +755,10 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		}
 	}
 
-	for (int attempt = 0; attempt < 2; ++attempt) {
+	// the persistent strip form of the cost kernel (srh_strip.hip): exact / fma arithmetic, candidate ranges of a
+	// 32-pixel tile inside one LDS chunk; anything else, or a range that turns out wider, takes the per-tile kernel
+	bool strip = dense && c->strip != 0 && c->arith != 2 && cstride + SRH_WTILE <= strip_chunk_columns();
+	for (int attempt = 0; attempt < 3; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		// ---- arbitrary geometry: candidate lists (the one-thread-per-pixel walk kernel is the last resort)
 		if (!dense && !c->force_walk && R <= 5 && W < 65536 && H < 65536) {
@@ -829,20 +872,55 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 			Scope s(c, "pinhole_label_table_kernel");
 			launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum);
 		}
-		size_t per_pixel = (size_t)T*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
+		const int wdoubles = strip ? (2*R + 1)*wimg_wp(R) : T;         // doubles per pixel window in the band buffer
+		size_t per_pixel = (size_t)wdoubles*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
 		size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
 		if (rows < 1) rows = 1;
 		if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
 		const size_t wstride = SRH_WTILE;
-		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
+		if ((rc = ensure(c->wbuf, c->wbuf_cap, strip ? wimg_doubles(W, (int)rows, R) : wbuf_doubles(W, (int)rows, T)))) return rc;
 		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*(size_t)((W + 31)/32)*32*(size_t)cstride))) return rc;   // 32-pixel tiles
-		if (dense && (rc = ensure(c->pconst, c->pconst_cap, rows*(size_t)W*4))) return rc;
+		// (+ one tile of slack: the strip kernel copies whole 32-pixel pieces of these rows)
+		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*4))) return rc;
+		int lanes = 8;
+		if (strip) {
+			if ((rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
+			lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);
+			// NaN-bordered gray_tv planes of both views, zero-bordered "window fully usable" plane of the other view
+			for (int k = 0; k < 2; ++k) {
+				ViewHost &v = c->views[k == 0 ? ref : oth];
+				if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
+				if (!v.tvp_valid) {
+					Scope s(c, "padded_plane_kernel");
+					launch_padded_plane(c->stream, v.gray_tv, v.w, v.h, v.tvp);
+					v.tvp_valid = true;
+				}
+			}
+			ViewHost &O = c->views[oth];
+			if (!O.fullp) HIP_TRY(hipMalloc((void **)&O.fullp, padded_size(O.w, O.h)));
+			if (O.fullp_r != R) {
+				Scope s(c, "padded_full_kernel");
+				launch_padded_full(c->stream, O.gray_tv, O.w, O.h, R, O.fullp);
+				O.fullp_r = R;
+			}
+		}
 
 		for (int by = y0; by < y1; by += (int)rows) {
 			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 			const int nr = std::min((int)rows, y1 - by);
-			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr);
-			if (dense) {
+			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr, strip);
+			if (dense && strip) {
+				{ Scope s(c, "pixel_range_kernel");
+				  launch_pixel_range(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, cstride, c->prange); }
+				HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));
+				{ Scope s(c, "twoview_strip_cost_kernel");
+				  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
+				                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
+				                            c->d_cnt, c->arith, c->num_cus, lanes); }
+				{ Scope s(c, "twoview_scan_kernel");
+				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
+				                      c->wbuf, wstride, c->d_cnt, c->prange, lanes, true); }
+			} else if (dense) {
 				{ Scope s(c, "twoview_dense_cost_kernel");
 				  if (c->arith == 2)
 					launch_twoview_dense_cost_f32(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
@@ -864,9 +942,12 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		Counters hc;
 		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (strip && hc.strip_overflow != 0) { strip = false; continue; }   // a tile's ranges did not fit one chunk: per-tile kernel
 		if (hc.not_row_aligned == 0) break;
 		dense = false;                                              // redo with the general kernel
+		strip = false;
 	}
+	c->stats.used_strip_kernel = strip ? 1 : 0;
 	c->stats.used_dense_path = dense ? 1 : 0;
 	return SRH_OK;
 }

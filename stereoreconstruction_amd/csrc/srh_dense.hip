@@ -55,12 +55,13 @@ void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, doub
 // image keep geodesic_init because all their edges are +inf.
 #define GW_TW 64
 
-template <int R>
+template <int R, bool WIMG>
 __global__ __launch_bounds__(GW_TW)
 void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const double *__restrict__ edges,
                          srh_params P, int y0, int nrows, double *__restrict__ wbuf, size_t wstride,
                          double *__restrict__ pconst)
 {
+	constexpr bool wimg = WIMG;
 	constexpr int WS = 2*R + 1;
 	constexpr int TWD = GW_TW + 2*R;            // tile width
 	const ViewDev &V = views[ref];
@@ -111,8 +112,12 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 
 	const int i = threadIdx.x;
 	const int cx = x0 + i;
-	if (cx >= W) return;
-	if (V.mask[(size_t)cy*W + cx] != 1) return;
+	// masked pixels never reach init_weights (twoviewstereo.cpp:268-272): their lanes sit out, their windows stay unwritten
+	const bool active = cx < W && V.mask[(size_t)cy*W + (cx < W ? cx : 0)] == 1;
+	const unsigned long long amask = WIMG ? __ballot(active) : 0ull;
+	// (WIMG: every lane runs the sweeps -- the stores at the end are a joint effort of the wave -- on the staged edges,
+	// which are finite or +inf for any tile cell; only lanes of masked-in pixels store)
+	if (!WIMG && !active) return;
 
 	double w[WS][WS];
 #pragma unroll
@@ -175,18 +180,55 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			}
 		}
 	}
-	double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
 	// exponential weighting (geodesicweight.cpp:128-130)
+	if constexpr (WIMG) {
+		// the strip kernel's LDS-image layout [tile][row][pixel][WP]: the 32 pixels' taps of one window row are 3 KB of
+		// contiguous bytes.  Stored as they stand (a lane's 96 bytes, 16 at a time) every store instruction touches 64
+		// cache lines (measured: +25 % kernel time); so each window row goes through LDS -- a 6 KB staging row --
+		// and leaves as whole kilobytes.  The workgroup is one wave; the barriers only order its LDS traffic.
+		constexpr int WP = (WS + 1) & ~1;
+		static_assert(GW_TW == 2*SRH_WTILE, "a workgroup covers two window-buffer tiles");
+		__shared__ __align__(16) double stage_buf[GW_TW*WP];
+		double *stage = stage_buf;
+		double *wt = wbuf + wimg_offset(W, R, trow, x0);     // first of the two window-buffer tiles of this workgroup
+		constexpr size_t TILE_D = (size_t)SRH_WTILE*WS*WP;   // doubles per tile
 #pragma unroll
-	for (int a = 0; a < WS; ++a) {
+		for (int a = 0; a < WS; ++a) {
+			__syncthreads();
 #pragma unroll
-		for (int b = 0; b < WS; ++b) {
-			w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
-			wb[(size_t)(a*WS + b)*wstride] = w[a][b];
+			for (int b = 0; b < WS; ++b) w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
+#pragma unroll
+			for (int b = 0; b + 1 < WS; b += 2) {
+				double2 v; v.x = w[a][b]; v.y = w[a][b + 1];
+				*reinterpret_cast<double2 *>(stage + i*WP + b) = v;
+			}
+			stage[i*WP + WS - 1] = w[a][WS - 1];
+			__syncthreads();
+			// 16-byte pieces of the staged row: piece q = doubles 2q, 2q+1 of pixel 2q / WP
+#pragma unroll
+			for (int k = 0; k < (GW_TW*WP/2 + GW_TW - 1)/GW_TW; ++k) {
+				const int q = i + k*GW_TW;
+				const int pix = (2*q)/WP;
+				if (q < GW_TW*WP/2 && ((amask >> pix) & 1ull)) {
+					const double2 v = *reinterpret_cast<const double2 *>(stage + 2*q);
+					const int half = pix/SRH_WTILE;          // which of the two tiles
+					*reinterpret_cast<double2 *>(wt + half*TILE_D + (size_t)a*(SRH_WTILE*WP) + (2*q - half*SRH_WTILE*WP)) = v;
+				}
+			}
 		}
-		asm volatile("" ::: "memory");
+	} else {
+		double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
+#pragma unroll
+		for (int a = 0; a < WS; ++a) {
+#pragma unroll
+			for (int b = 0; b < WS; ++b) {
+				w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
+				wb[(size_t)(a*WS + b)*wstride] = w[a][b];
+			}
+			asm volatile("" ::: "memory");
+		}
 	}
-	if (pconst) {
+	if (pconst && active) {
 		// Per-pixel constants of the dense kernel's fast cost form, while the window is in registers: when every tap
 		// is usable (gray value valid, weight above the cut-off), meanL, totalWeight and sum2 of
 		// twoviewstereo.cpp:917-976 do not depend on the candidate.  Same tap order, same operations.
@@ -215,13 +257,20 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 }
 
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
-                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst)
+                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst, bool wimg)
 {
 	const int tiles = (width + GW_TW - 1)/GW_TW;
 	const dim3 grid((unsigned)(tiles*nrows)), block(GW_TW);
+	const int wi = wimg ? 1 : 0;
 	switch (P.window_radius) {
-	case 5: hipLaunchKernelGGL(geodesic_reg_kernel<5>, grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst); return true;
-	case 2: hipLaunchKernelGGL(geodesic_reg_kernel<2>, grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst); return true;
+	case 5:
+		if (wi) hipLaunchKernelGGL((geodesic_reg_kernel<5, true>), grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst);
+		else    hipLaunchKernelGGL((geodesic_reg_kernel<5, false>), grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst);
+		return true;
+	case 2:
+		if (wi) hipLaunchKernelGGL((geodesic_reg_kernel<2, true>), grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst);
+		else    hipLaunchKernelGGL((geodesic_reg_kernel<2, false>), grid, block, 0, st, views, ref, edges, P, y0, nrows, wbuf, wstride, pconst);
+		return true;
 	default: return false;
 	}
 }
@@ -342,6 +391,18 @@ __device__ __noinline__ double dense_cost_general(const DenseSmem<R, DC_NCB, DC_
 	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
 	return (v < max_color_diff) ? v : max_color_diff;
 }
+
+#ifdef SRH_EXPERIMENT
+// timing experiments only (make exp): repeat the block loops of every tile `g_exp_repeat` times (the marginal
+// time of a repetition is the pure loop time), pad the dynamic LDS so that fewer workgroups fit a CU
+__device__ int g_exp_repeat = 1;
+int g_exp_lds_pad = 0;
+void strip_exp_set(int repeat);
+void exp_set(int repeat, int lds_pad) {
+	if (repeat >= 0) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_repeat), &repeat, sizeof(int)); strip_exp_set(repeat); }
+	if (lds_pad >= 0) g_exp_lds_pad = lds_pad;
+}
+#endif
 
 // FMA = false: the reference's arithmetic, operation by operation (the default and the parity mode).
 // FMA = true : the opt-in "fma" mode (option "arith" = 1): the same sums with every multiply-add of the block loops
@@ -545,6 +606,10 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			// phase 1: blocks of DC_NCB candidates in the fast form.  Candidates whose window is
 			// not fully usable still ride along in the block but are not stored; phase 2 below
 			// evaluates them (and every candidate of a pixel that has unusable taps itself).
+#ifdef SRH_EXPERIMENT
+			const int exp_rep = g_exp_repeat;
+			for (int rep = 0; rep < exp_rep; ++rep)
+#endif
 			for (int b = g; b < (CS.lall[i] ? nblocks : 0); b += DC_G) {
 				const int c0 = lo_e + b*DC_NCB;
 				const int rc = c0 - cs;                 // tile column of the window's left edge (even)
@@ -724,9 +789,13 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
 	typedef DenseSmem<R, NCB, CHUNK> Smem;
 	// a function attribute belongs to the CURRENT device: set it on every launch (a host-side table update),
 	// so contexts on several GPUs of one process all get their dynamic LDS
+	size_t lds = sizeof(Smem);
+#ifdef SRH_EXPERIMENT
+	lds += (size_t)g_exp_lds_pad;
+#endif
 	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>,
-	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>), grid, dim3(DC_THREADS), sizeof(Smem), st,
+	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>), grid, dim3(DC_THREADS), lds, st,
 	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst);
 }
 
@@ -770,7 +839,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
                          int y0, int nrows, const double *__restrict__ tnum,
                          const double *__restrict__ cost, int cstride,
                          const double *__restrict__ wbuf, size_t wstride, int ncb, int lanes,
-                         Counters *__restrict__ cnt)
+                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange, int wimg)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
@@ -792,7 +861,8 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	int lo = 0, hi = -1, cover_hi = -1;
 	if (active) {
 		ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-		pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
+		if (prange) { const PixRange pr = prange[(size_t)trow*W + x]; lo = pr.lo; hi = pr.hi; }   // pixel_range_kernel: the same function
+		else pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
 		if (hi >= lo) cover_hi = dense_cover_hi(lo, hi, ncb, lanes);
 	}
 	if (tid == 0) s_umin = 2147483647;
@@ -812,7 +882,8 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 		n_pix = 1;
 		const double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 		const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
-		const double *wq = wbuf + wbuf_offset(W, T, trow, x);
+		const double *wq = wbuf + (wimg ? wimg_offset(W, P.window_radius, trow, x) : wbuf_offset(W, T, trow, x));
+		const size_t wq_col = wimg ? 1 : wstride, wq_row = wimg ? (size_t)wimg_row_stride(P.window_radius) : 0;
 		TwoViewScanState st = { __builtin_inf(), __builtin_inf(), -1 };
 		int qn = 0;
 
@@ -830,7 +901,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 				if (k < count) {
 					double cv = c[k];
 					if (lo + col[k] > cover_hi) {                   // column left out by the dense kernel
-						cv = tv_cost(L, Rv, wq, wstride, P, x, y, lo + col[k], y);
+						cv = tv_cost(L, Rv, wq, wq_col, P, x, y, lo + col[k], y, wq_row);
 						++n_lazy;
 					}
 					if (cv + P.wta_margin < st.minCost) {           // twoviewstereo.cpp:293-301
@@ -906,15 +977,14 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         const double *wbuf, size_t wstride, Counters *cnt)
+                         const double *wbuf, size_t wstride, Counters *cnt, const PixRange *prange, int lanes, bool wimg)
 {
-	const size_t n = (size_t)nrows*width;
-	// block geometry of the dense kernel (dense_cover_hi must agree on both sides)
-	const int ncb = 8, lanes = DC_G;
-	(void)n;
+	// block geometry of the cost kernel (dense_cover_hi must agree on both sides): 8 columns per block,
+	// `lanes` lanes per pixel (8: twoview_dense_cost_kernel and the 256-thread strip kernel; 16: the 512-thread one)
+	const int ncb = 8;
 	const int tiles = (width + SC_TW - 1)/SC_TW;
 	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, wbuf, wstride, ncb, lanes, cnt);
+	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, wbuf, wstride, ncb, lanes, cnt, prange, wimg ? 1 : 0);
 }
 
 } // namespace srh

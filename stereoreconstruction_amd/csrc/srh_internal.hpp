@@ -38,6 +38,32 @@ __host__ __device__ inline size_t wbuf_offset(int W, int T, int band_row, int x)
 	return tile*(size_t)T*SRH_WTILE + (x % SRH_WTILE);
 }
 
+// ---- the strip kernel's inputs (srh_strip.hip) ------------------------------------------------------------
+// Window buffer, layout B ("LDS image"): wbuf[tile][row][pixel 0..31][WP], WP = taps per row padded to an even
+// count -- exactly the bytes the strip kernel keeps in LDS, so a tile moves global -> LDS as one linear
+// LDS-DMA copy (global_load_lds_dwordx4 writes lane-linear destinations only), and the 32 pixels' taps of one
+// window row are 3 KB of contiguous bytes for the weights kernel's stores.  Tap (row, col) of a pixel is
+// base + row*wimg_row_stride(R) + col; the pad tap is never read.
+__host__ __device__ inline int wimg_wp(int R) { return ((2*R + 1) + 1) & ~1; }
+__host__ __device__ inline int wimg_row_stride(int R) { return SRH_WTILE*wimg_wp(R); }
+__host__ __device__ inline size_t wimg_doubles(int W, int nrows, int R) {
+	return (size_t)nrows*((W + SRH_WTILE - 1)/SRH_WTILE)*SRH_WTILE*(size_t)((2*R + 1)*wimg_wp(R));
+}
+__host__ __device__ inline size_t wimg_offset(int W, int R, int band_row, int x) {
+	const size_t tile = (size_t)band_row*((W + SRH_WTILE - 1)/SRH_WTILE) + x/SRH_WTILE;
+	return tile*SRH_WTILE*(size_t)((2*R + 1)*wimg_wp(R)) + (size_t)(x % SRH_WTILE)*wimg_wp(R);
+}
+// NaN-bordered copy of a view's gray_tv plane (and zero-bordered copy of its "window fully usable" plane):
+// every row piece a tile stages lies inside the allocation, so the LDS-DMA needs no bounds handling and the
+// border taps arrive as NaN (= "tap skipped", vectorimage.cpp:115-119,129-155).
+#define SRH_PADL 8
+#define SRH_PADR 344          // >= CHUNK + R + NCB + 2 of the strip kernel
+#define SRH_PADY 8
+__host__ __device__ inline int padded_stride(int w) { return w + SRH_PADL + SRH_PADR; }
+__host__ __device__ inline size_t padded_size(int w, int h) { return (size_t)padded_stride(w)*(size_t)(h + 2*SRH_PADY); }
+// candidate column range of a reference pixel on its own row of the other view (empty: hi < lo)
+struct PixRange { int32_t lo, hi; };
+
 // Work counters accumulated by the kernels (device memory, zeroed per run).
 struct Counters {
 	unsigned long long n_pixels;
@@ -45,8 +71,11 @@ struct Counters {
 	unsigned long long n_eval_device;
 	unsigned long long not_row_aligned;   // pixels whose curve leaves their own row
 	unsigned long long n_listed, n_slots; // row-run lists: distinct candidates / cost slots (8-column blocks) they occupy
+	unsigned long long strip_overflow;    // strip kernel: tiles whose candidate range does not fit one LDS chunk
+	unsigned int strip_ticket, strip_pad; // strip kernel: work-item counter of the current launch
 	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
 	unsigned long long dbg_phase[8];
+	unsigned long long dbg_wave[64];      // diagnostic build: phase k of wave w of a workgroup at [8*k + w]
 };
 
 // Neighbour views of one MultiViewStereo estimate, passed to the kernels by value
@@ -70,7 +99,7 @@ void launch_fill(hipStream_t st, double *p, size_t n, double v);
 // pconst (optional): 4 doubles per pixel of the band -- meanL, totalWeight, sum2, all-taps-usable -- the per-pixel
 // constants of the dense cost kernel's fast form, computed while the window is at hand
 void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
-                    int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr);
+                    int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr, bool wimg = false);
 void launch_twoview_generic(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                             int y0, int nrows, const double *wbuf, size_t wstride, Counters *cnt);
 void launch_twoview_cross_check(hipStream_t st, const ViewDev *views, int self, int other, int w, int h,
@@ -84,7 +113,8 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 // Dense (row-aligned) TwoView path, srh_dense.hip
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
-                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr);
+                         const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr,
+                         bool wimg = false);
 void launch_label_plane_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tdist);
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -95,7 +125,25 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         const double *wbuf, size_t wstride, Counters *cnt);
+                         const double *wbuf, size_t wstride, Counters *cnt,
+                         const PixRange *prange = nullptr, int lanes = 8, bool wimg = false);
+
+// Persistent strip form of the dense cost kernel, srh_strip.hip
+void launch_padded_plane(hipStream_t st, const double *gray_tv, int w, int h, double *out);
+void launch_padded_full(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *out);
+void launch_pixel_range(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                        int y0, int nrows, const double *tnum, int cstride, PixRange *prange);
+int  strip_chunk_columns();
+int  strip_block_lanes(int cstride, int form);
+bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, int height,
+                               const srh_params &P, int y0, int nrows, const double *wimg, const double *pconst,
+                               const PixRange *prange, const double *ref_tvp, const double *oth_tvp,
+                               const uint8_t *oth_fullp, double *cost, int cstride, Counters *cnt, int arith, int num_cus,
+                               int lanes);
+
+#ifdef SRH_EXPERIMENT
+void exp_set(int repeat, int lds_pad);
+#endif
 
 // Fused row-aligned TwoView kernel (geometry + cost + WTA per 16-pixel tile), srh_fused.hip.
 // SRH_FUSED_MAXC: cost-row columns (and labels) a pixel may have in LDS.

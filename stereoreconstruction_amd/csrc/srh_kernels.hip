@@ -71,9 +71,11 @@ __device__ __forceinline__ double color_dist(uint32_t a, uint32_t b) {
 }
 
 // Any-radius version: the window lives in the global weight buffer
-// (tile-major layout of srh_internal.hpp: wb[tap*wstride], wstride = SRH_WTILE).
+// (tile-major layout of srh_internal.hpp: wb[tap*wstride], wstride = SRH_WTILE; or, wimg != 0, the
+// strip kernel's LDS-image layout: wb[row*32*WP + col]).
 __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_params P,
-                               int y0, int nrows, double *__restrict__ wbuf, size_t wstride, double *__restrict__ pconst)
+                               int y0, int nrows, double *__restrict__ wbuf, size_t wstride, double *__restrict__ pconst,
+                               int wimg)
 {
 	const ViewDev &V = views[ref];
 	const int W = V.w, H = V.h;
@@ -82,12 +84,15 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 	const int cx = (int)(q % W), cy = y0 + (int)(q / W);
 	if (V.mask[(size_t)cy*W + cx] != 1) return;                 // masked pixels never reach init_weights
 	const int R = P.window_radius, WS = 2*R + 1;
-	double *wb = wbuf + wbuf_offset(W, WS*WS, (int)(q / W), cx);
+	double *wb = wbuf + (wimg ? wimg_offset(W, R, (int)(q / W), cx) : wbuf_offset(W, WS*WS, (int)(q / W), cx));
+	// tap (r, c) of the window at wb[r*wrs + c*wcs]
+	const size_t wrs = wimg ? (size_t)wimg_row_stride(R) : (size_t)WS*wstride, wcs = wimg ? 1 : wstride;
+#define WTAP(r, c) wb[(size_t)(r)*wrs + (size_t)(c)*wcs]
 
 	if (P.weight_kind == SRH_WEIGHT_GEODESIC) {
 		// geodesicweight.cpp:59-131
-		for (int i = 0; i < WS*WS; ++i) wb[(size_t)i*wstride] = P.geodesic_init;
-		wb[(size_t)(R*WS + R)*wstride] = 0.0;
+		for (int i = 0; i < WS*WS; ++i) WTAP(i / WS, i % WS) = P.geodesic_init;
+		WTAP(R, R) = 0.0;
 		for (int iter = 0; iter < P.geodesic_iters; ++iter) {
 			for (int pass = 0; pass < 2; ++pass) {
 				// K1 = (-1,-1)(0,-1)(1,-1)(-1,0) forward; K2 = (-1,1)(0,1)(1,1)(1,0) backward
@@ -100,8 +105,7 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 						const int px = cx + x;
 						if (px < 0 || py < 0 || px >= W || py >= H) continue;
 						const uint32_t c1 = V.rgba[(size_t)py*W + px];
-						const size_t idx = (size_t)((y + R)*WS + (x + R));
-						double weight = wb[idx*wstride];
+						double weight = WTAP(y + R, x + R);
 						for (int k = 0; k < 4; ++k) {
 							const int dx = (k == 3) ? (pass == 0 ? -1 : 1) : (k - 1);
 							const int dy = (k == 3) ? 0 : sy;
@@ -109,16 +113,16 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 							const int qx = px + dx, qy = py + dy;
 							if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
 							const double diff = color_dist(V.rgba[(size_t)qy*W + qx], c1);
-							const double cost = wb[(size_t)((y + dy + R)*WS + (x + dx + R))*wstride];
+							const double cost = WTAP(y + dy + R, x + dx + R);
 							const double cand = cost + diff;
 							if (cand < weight) weight = cand;
 						}
-						wb[idx*wstride] = weight;
+						WTAP(y + R, x + R) = weight;
 					}
 				}
 			}
 		}
-		for (int i = 0; i < WS*WS; ++i) wb[(size_t)i*wstride] = exp(-wb[(size_t)i*wstride] / P.geodesic_sigma);
+		for (int i = 0; i < WS*WS; ++i) WTAP(i / WS, i % WS) = exp(-WTAP(i / WS, i % WS) / P.geodesic_sigma);
 	} else {
 		// adaptiveweight.cpp:33-79 (the centre pixel is always in bounds here)
 		const uint32_t crgb = V.rgba[(size_t)cy*W + cx];
@@ -134,7 +138,7 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 					weight = w1*w2;
 					if (isnan_d(weight)) weight = 0.0;
 				}
-				wb[(size_t)((row + R)*WS + (col + R))*wstride] = weight;
+				WTAP(row + R, col + R) = weight;
 			}
 		}
 	}
@@ -146,7 +150,7 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 			for (int col = -R; col <= R; ++col) {
 				const int px = cx + col, py = cy + row;
 				const double gl = (px < 0 || py < 0 || px >= W || py >= H) ? __builtin_nan("") : V.gray_tv[(size_t)py*W + px];
-				const double wt = wb[(size_t)((row + R)*WS + (col + R))*wstride];
+				const double wt = WTAP(row + R, col + R);
 				if (!(gl == gl && wt > P.weight_cutoff)) all = false;
 				mL += wt*gl;
 				tw += wt;
@@ -156,21 +160,22 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 			mL /= tw;
 			for (int row = -R; row <= R; ++row)
 				for (int col = -R; col <= R; ++col) {
-					const double t = wb[(size_t)((row + R)*WS + (col + R))*wstride]*V.gray_tv[(size_t)(cy + row)*W + (cx + col)] - mL;
+					const double t = WTAP(row + R, col + R)*V.gray_tv[(size_t)(cy + row)*W + (cx + col)] - mL;
 					s2 += t*t;
 				}
 		} else all = false;
 		double *pc = pconst + ((size_t)(q / W)*W + cx)*4;
 		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
 	}
+#undef WTAP
 }
 
 void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
-                    int y0, int nrows, double *wbuf, size_t wstride, double *pconst)
+                    int y0, int nrows, double *wbuf, size_t wstride, double *pconst, bool wimg)
 {
 	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(weights_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
-	                   views, ref, P, y0, nrows, wbuf, wstride, pconst);
+	                   views, ref, P, y0, nrows, wbuf, wstride, pconst, wimg ? 1 : 0);
 }
 
 // ------------------------------------------------------------------ TwoView, general geometry

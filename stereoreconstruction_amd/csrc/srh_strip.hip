@@ -1,0 +1,809 @@
+// srh_strip.hip -- TwoViewStereo::cost_ncc (stereo/twoviewstereo.cpp:909-977) for row-aligned rigs as a
+// PERSISTENT kernel: the same block loops, sums and operation order as twoview_dense_cost_kernel (srh_dense.hip),
+// so the same bits -- what changes is everything around the loops.
+//
+// twoview_dense_cost_kernel starts one workgroup per 32-pixel tile; each of them works out its candidate ranges,
+// stages 11 rows of both views and its windows through registers, derives which candidate windows are complete
+// (three barriers) and only then reaches the FP64 loops.  Measured on C3 (profiles/r03_repeat_experiment.txt): the
+// loops cost 15.1 ms per launch, everything else 4.45 ms, and the two do not overlap.  Here
+//
+//   * a workgroup owns a vertical strip -- one tile column, 4..16 consecutive rows (work items drawn from a
+//     ticket counter, tall items first) -- and keeps the rows of both views in an LDS ring: going one row down
+//     costs ONE new row per view instead of eleven;
+//   * every byte enters LDS by LDS-DMA (global_load_lds): the windows (the weights kernels write them in the
+//     LDS image's own layout, srh_internal.hpp "layout B"), the per-pixel constants, the per-pixel candidate
+//     ranges (pixel_range_kernel) and the "window fully usable" bytes of the other view (padded_full_kernel);
+//     the image rows come from NaN-bordered copies of gray_tv, so no lane ever tests a bound;
+//   * the next tile's row, constants and (512-thread form) windows are requested while the current tile
+//     computes; one barrier per tile.
+//
+// Two forms: 4 waves (32 px x 8 block lanes, one window buffer, 2 workgroups per CU) and 8 waves (32 px x 16
+// block lanes, two window buffers, 1 workgroup per CU).  Both keep 2 waves per SIMD.
+#include "srh_internal.hpp"
+#include "srh_geom.hpp"
+#include "srh_walk.hpp"
+
+namespace srh {
+
+#ifdef SRH_EXPERIMENT
+// timing experiments only (make exp): repeat the block loops of every tile (srh_dense.hip, exp_set)
+__device__ int g_strip_exp_repeat = 1;
+void strip_exp_set(int repeat) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_strip_exp_repeat), &repeat, sizeof(int)); }
+#endif
+
+#define ST_TP 32                       // pixels per tile (= SRH_WTILE)
+#define ST_NCB 8                       // candidate columns per block
+#define ST_CHUNK 320                   // candidate columns a tile can hold in LDS
+
+typedef __attribute__((address_space(3))) void st_lds_void;
+typedef __attribute__((address_space(1))) const void st_gbl_void;
+typedef __attribute__((address_space(3))) volatile int st_lds_vint;
+
+// ------------------------------------------------------------------ padded planes
+__global__ void padded_plane_kernel(const double *__restrict__ gray_tv, int W, int H, double *__restrict__ out)
+{
+	const int SP = padded_stride(W), HP = H + 2*SRH_PADY;
+	const size_t n = (size_t)SP*HP;
+	const double nan = __builtin_nan("");
+	for (size_t k = (size_t)blockIdx.x*blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x*blockDim.x) {
+		const int x = (int)(k % (size_t)SP) - SRH_PADL, y = (int)(k / (size_t)SP) - SRH_PADY;
+		out[k] = (x >= 0 && y >= 0 && x < W && y < H) ? gray_tv[(size_t)y*W + x] : nan;
+	}
+}
+
+void launch_padded_plane(hipStream_t st, const double *gray_tv, int w, int h, double *out) {
+	size_t n = padded_size(w, h);
+	size_t b = (n + 255)/256; if (b > 4096) b = 4096;
+	hipLaunchKernelGGL(padded_plane_kernel, dim3((unsigned)b), dim3(256), 0, st, gray_tv, w, h, out);
+}
+
+// out[(y+PADY)*SP + x+PADL] = 1 where the whole (2R+1)^2 TwoView window centred on (x, y) is usable
+// (inside the image, every gray_tv tap valid), 0 elsewhere -- full_window_kernel (srh_list.hip) on the padded raster
+__global__ void padded_full_kernel(const double *__restrict__ gray_tv, int W, int H, int R, uint8_t *__restrict__ out)
+{
+	const int SP = padded_stride(W), HP = H + 2*SRH_PADY;
+	const size_t n = (size_t)SP*HP;
+	for (size_t k = (size_t)blockIdx.x*blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x*blockDim.x) {
+		const int x = (int)(k % (size_t)SP) - SRH_PADL, y = (int)(k / (size_t)SP) - SRH_PADY;
+		bool ok = x - R >= 0 && y - R >= 0 && x + R < W && y + R < H;
+		for (int row = -R; ok && row <= R; ++row)
+			for (int col = -R; col <= R; ++col) {
+				const double v = gray_tv[(size_t)(y + row)*W + (x + col)];
+				ok = ok && (v == v);
+			}
+		out[k] = ok ? 1 : 0;
+	}
+}
+
+void launch_padded_full(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *out) {
+	size_t n = padded_size(w, h);
+	size_t b = (n + 255)/256; if (b > 4096) b = 4096;
+	hipLaunchKernelGGL(padded_full_kernel, dim3((unsigned)b), dim3(256), 0, st, gray_tv, w, h, R, out);
+}
+
+// ------------------------------------------------------------------ candidate ranges
+// The column range of every reference pixel of the band (pinhole_column_range, srh_walk.hpp), once, with every lane
+// busy: twoview_dense_cost_kernel works it out on one lane in eight per tile, twoview_scan_kernel again per pixel.
+__global__ void pixel_range_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0, int nrows,
+                                   const double *__restrict__ tnum, int cstride, PixRange *__restrict__ prange)
+{
+	const ViewDev &L = views[ref];
+	const int W = L.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if (q >= (size_t)nrows*W) return;
+	const int x = (int)(q % W), y = y0 + (int)(q / W);
+	int lo = 0, hi = -1;
+	if (L.mask[(size_t)y*W + x] == 1) {
+		const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		pinhole_column_range(ray, L.cam, views[oth], P, tnum, cstride, lo, hi);
+	}
+	PixRange r; r.lo = lo; r.hi = hi;
+	prange[q] = r;
+}
+
+void launch_pixel_range(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                        int y0, int nrows, const double *tnum, int cstride, PixRange *prange)
+{
+	const size_t n = (size_t)nrows*width;
+	hipLaunchKernelGGL(pixel_range_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st,
+	                   views, ref, oth, P, y0, nrows, tnum, cstride, prange);
+}
+
+int strip_chunk_columns() { return ST_CHUNK; }
+
+// ------------------------------------------------------------------ the strip kernel
+struct StripArgs {
+	int W, H, y0, nrows;                    // reference view size; rows [y0, y0 + nrows) of it
+	const double *wimg;                     // windows of the band, layout B
+	const double *pconst;                   // 4 doubles per pixel of the band: meanL, totalWeight, sum2, all-taps-usable
+	const PixRange *prange;                 // candidate column range per pixel of the band
+	const double *ref_tvp, *oth_tvp;        // NaN-bordered gray_tv planes
+	const uint8_t *oth_fullp;               // zero-bordered "window fully usable" plane of the other view
+	double *cost; int cstride;              // cost rows, tile-transposed: ((tile*cstride) + k)*32 + pixel
+	Counters *cnt;
+	int n1, n2;                             // rows [0,n1) in 16-row items, [n1,n2) in 8-row items, the rest in 4-row items
+	int nitems;
+	double weight_cutoff, bad_ret, max_color_diff;
+};
+
+template <int R, int NBUF>
+struct StripSmem {
+	static constexpr int WS = 2*R + 1;
+	static constexpr int T = WS*WS;
+	static constexpr int WP = (WS + 1) & ~1;                 // taps per window row, padded even
+	static constexpr int WPIX = WS*WP;                       // doubles per pixel window
+	static constexpr int RW = ST_CHUNK + 2*R + ST_NCB + 2;   // staged width of the other view's rows (even)
+	static constexpr int LW = (ST_TP + 2*R + 1) & ~1;        // staged width of the reference rows (even)
+	static constexpr int NS = WS + 1;                        // row slots of the rings: the window's rows + the next one
+	static constexpr int FW = (RW + 4 + 15) & ~15;           // bytes of a staged "full" row piece (dword granules + slack)
+	// phase-2 work lists in one array: 8-column blocks for the blocked select form from the front
+	// (at most ST_TP*(CHUNK/NCB + 1) of them), single candidates for the per-candidate form from the back
+	static constexpr int NBMAX = ST_CHUNK/ST_NCB + 1;
+	static constexpr int GL_CAP = 3072;
+	static constexpr int GL_SINGLES = GL_CAP - ST_TP*NBMAX;
+	alignas(16) double w[NBUF][WS][ST_TP][WP];         // LDS image of the windows: [row][pixel][tap], as in the band buffer
+	alignas(16) double rt[NS][RW];
+	alignas(16) double lt[NS][LW];
+	alignas(16) double pc[2][ST_TP][4];
+	alignas(16) PixRange pr[2][ST_TP];
+	alignas(16) unsigned char full[2][FW];
+	unsigned short glist[GL_CAP];
+	int glist_n, gsingle_n;
+	int item;
+	int simd[8];                  // SIMD of each wave of the workgroup (8-wave form: which two waves share one)
+	int prog[NBUF == 2 ? 8 : 1][64];   // progress of each wave inside the current tile, in window rows (pass 2 rows count 3); one copy per lane: no lane masking in the hot loops
+	static_assert(ST_CHUNK <= 512 && ST_TP <= 64, "work-list entry = pixel*512 + column in 16 bits");
+	static_assert(RW % 2 == 0 && LW % 2 == 0 && WP % 2 == 0, "16-byte rows");
+	static_assert(RW - R + 4 <= SRH_PADR + 1, "padded planes cover every staged piece");
+};
+
+// lanes [0, nbytes/16) of the wave copy 16 bytes each from src + 16*lane to LDS dst + 16*lane, 1 KiB per instruction
+__device__ __forceinline__ void st_dma16(const void *src, void *dst, int nbytes, int lane) {
+	for (int off = 0; off < nbytes; off += 1024) {
+		if (off + lane*16 < nbytes)
+			__builtin_amdgcn_global_load_lds((st_gbl_void *)((const char *)src + off + lane*16),
+			                                 (st_lds_void *)((char *)dst + off), 16, 0, 0);
+	}
+}
+// the same in 4-byte granules (sources that are only 4-byte aligned)
+__device__ __forceinline__ void st_dma4(const void *src, void *dst, int nbytes, int lane) {
+	for (int off = 0; off < nbytes; off += 256) {
+		if (off + lane*4 < nbytes)
+			__builtin_amdgcn_global_load_lds((st_gbl_void *)((const char *)src + off + lane*4),
+			                                 (st_lds_void *)((char *)dst + off), 4, 0, 0);
+	}
+}
+
+// general (any validity pattern) cost of one candidate from the LDS tiles: dense_cost_general of srh_dense.hip
+// with the rows taken from the rings.  Skipped taps add +0.0 to every sum (twoviewstereo.cpp:920-938, 955-972).
+template <int R, int NBUF>
+__device__ __noinline__ double strip_cost_general(const StripSmem<R, NBUF> &S, int wb, int s0, int i, int rc,
+                                                  double weight_cutoff, double bad_ret, double max_color_diff)
+{
+	typedef StripSmem<R, NBUF> Smem;
+	constexpr int WS = Smem::WS, WP = Smem::WP, NS = Smem::NS;
+	double meanL = 0, meanR = 0, totalWeight = 0.0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = S.lt[sl][i + col]; gr[col] = S.rt[sl][rc + col]; wt[col] = S.w[wb][row][i][col]; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > weight_cutoff;
+			const double pl = wt[col]*gl[col], pr = wt[col]*gr[col];
+			meanL += ok ? pl : 0.0;
+			meanR += ok ? pr : 0.0;
+			totalWeight += ok ? wt[col] : 0.0;
+		}
+	}
+	if (totalWeight < 1e-10) return bad_ret;
+	meanL /= totalWeight;
+	meanR /= totalWeight;
+	double sum1 = 0, sum2 = 0, sum3 = 0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = S.lt[sl][i + col]; gr[col] = S.rt[sl][rc + col]; wt[col] = S.w[wb][row][i][col]; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > weight_cutoff;
+			const double a = wt[col]*gl[col] - meanL;
+			const double b = wt[col]*gr[col] - meanR;
+			const double ab = a*b, aa = a*a, bb = b*b;
+			sum1 += ok ? ab : 0.0;
+			sum2 += ok ? aa : 0.0;
+			sum3 += ok ? bb : 0.0;
+		}
+	}
+	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
+	return (v < max_color_diff) ? v : max_color_diff;
+}
+
+// One 8-column block of pixel `pi` in the BLOCKED select form: any validity pattern (image border, masked taps,
+// cut-off weights), the same sums as strip_cost_general with every tap guarded -- a skipped tap adds +0.0 -- but
+// the other view's row segment is read once per window row and shared by the 8 candidates, as in the fast form
+// (the per-candidate form reads 3 LDS values per tap and candidate).  Candidates whose bit is set in `store` are written.
+template <int R, int NBUF>
+__device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int wb, int s0, int pi, int rc, unsigned store,
+                                                double *__restrict__ dst, double weight_cutoff, double bad_ret, double max_color_diff)
+{
+	typedef StripSmem<R, NBUF> Smem;
+	constexpr int WS = Smem::WS, NS = Smem::NS, NCB = ST_NCB, NR = NCB + 2*R;
+	double mLs[NCB], mRs[NCB], tws[NCB];
+#pragma unroll
+	for (int j = 0; j < NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
+		double rr[NR];
+		const double2 *rp = reinterpret_cast<const double2 *>(&S.rt[sl][rc]);
+#pragma unroll
+		for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; rr[2*m] = v.x; rr[2*m + 1] = v.y; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const double gl = S.lt[sl][pi + col], wt = S.w[wb][row][pi][col];
+			const bool okl = gl == gl && wt > weight_cutoff;
+			const double pl = wt*gl;
+#pragma unroll
+			for (int j = 0; j < NCB; ++j) {
+				const double gr = rr[col + j];
+				const bool ok = okl && gr == gr;
+				const double pr = wt*gr;
+				mLs[j] += ok ? pl : 0.0;
+				mRs[j] += ok ? pr : 0.0;
+				tws[j] += ok ? wt : 0.0;
+			}
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < NCB; ++j) { mLs[j] /= tws[j]; mRs[j] /= tws[j]; }   // unused when tws < 1e-10
+	double s1[NCB], s2v[NCB], s3[NCB];
+#pragma unroll
+	for (int j = 0; j < NCB; ++j) { s1[j] = 0.0; s2v[j] = 0.0; s3[j] = 0.0; }
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
+		double rr[NR];
+		const double2 *rp = reinterpret_cast<const double2 *>(&S.rt[sl][rc]);
+#pragma unroll
+		for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; rr[2*m] = v.x; rr[2*m + 1] = v.y; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const double gl = S.lt[sl][pi + col], wt = S.w[wb][row][pi][col];
+			const bool okl = gl == gl && wt > weight_cutoff;
+			const double pl = wt*gl;
+#pragma unroll
+			for (int j = 0; j < NCB; ++j) {
+				const double gr = rr[col + j];
+				const bool ok = okl && gr == gr;
+				const double a = pl - mLs[j], bq = wt*gr - mRs[j];
+				const double ab = a*bq, aa = a*a, bb = bq*bq;
+				s1[j] += ok ? ab : 0.0;
+				s2v[j] += ok ? aa : 0.0;
+				s3[j] += ok ? bb : 0.0;
+			}
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < NCB; ++j) {
+		if ((store >> j) & 1u) {
+			double result = bad_ret;
+			if (!(tws[j] < 1e-10)) {
+				const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2v[j] * s3[j]));
+				result = (v < max_color_diff) ? v : max_color_diff;
+			}
+			dst[(ptrdiff_t)j*ST_TP] = result;
+		}
+	}
+}
+
+// NWV waves: 4 (block lanes per pixel G = 8, NBUF = 1) or 8 (G = 16, NBUF = 2)
+template <int R, int NWV, int NBUF, bool FMA>
+__global__ __launch_bounds__(NWV*64, 2)
+void twoview_strip_cost_kernel(const StripArgs A)
+{
+	typedef StripSmem<R, NBUF> Smem;
+	constexpr int WS = Smem::WS, WP = Smem::WP, WPIX = Smem::WPIX, RW = Smem::RW, LW = Smem::LW, NS = Smem::NS;
+	constexpr int NCB = ST_NCB, CHUNK = ST_CHUNK;
+	constexpr int NR = NCB + 2*R;              // right-row values a block needs (even)
+	constexpr int G = 2*NWV;                   // block lanes per pixel
+	constexpr int NT = NWV*64;
+	static_assert(NR % 2 == 0, "16-byte rows");
+	static_assert((NWV == 4 && NBUF == 1) || (NWV == 8 && NBUF == 2), "two forms");
+	extern __shared__ __align__(16) unsigned char smem_raw[];
+	Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+	const Smem &CS = S;
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int pg = wv & 3;                       // pixel group of the wave: pixels 8*pg .. 8*pg + 7 of the tile
+	const int i = pg*8 + (lane & 7);             // pixel within the tile (pixel-fastest inside a wave)
+	const int g = (lane >> 3) + 8*(wv >> 2);     // block lane of the pixel
+	const int W = A.W;
+	const int tiles_per_row = (W + ST_TP - 1)/ST_TP;
+	const int SP = padded_stride(W);
+	unsigned n_dev = 0;
+	// 8-wave form: the two waves of a SIMD share its FP64 pipe, and the arbiter serves the older one first -- left alone,
+	// the older wave finishes every tile early and waits at the tile barrier while the younger runs on by itself at the
+	// lower single-wave issue rate (measured: a third of a wave's time at the barrier).  Each wave publishes how far it
+	// is in the tile and yields (s_setprio 0) while it is ahead of its SIMD partner, so both reach the barrier together.
+	int partner = wv;
+	if (NWV == 8) {
+		// HW_REG_HW_ID (id 4), SIMD_ID = bits [5:4]
+		const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+		if (lane == 0) S.simd[wv] = simd;
+		S.prog[wv][lane] = 0;
+		__syncthreads();
+		for (int j = 0; j < NWV; ++j) if (j != wv && CS.simd[j] == simd) { partner = j; break; }
+		partner = __builtin_amdgcn_readfirstlane(partner);
+	}
+	int prog = 0;
+	// publish own progress, look at the partner's (value used by prog_yield at the end of the window row)
+	auto prog_step = [&](int units, int &seen) {
+		if (NWV == 8) {
+			prog += units;
+			*(st_lds_vint *)&S.prog[wv][lane] = prog;
+			seen = *(st_lds_vint *)&S.prog[partner][lane];
+		}
+	};
+	// s_setprio 0 while ahead of the partner, 1 otherwise.  One asm statement with its own branch: the row loops stay
+	// single basic blocks for the compiler's scheduler and register allocator.
+	auto prog_yield = [&](int seen) {
+		if (NWV == 8) {
+			const int ps = __builtin_amdgcn_readfirstlane(seen), pm = __builtin_amdgcn_readfirstlane(prog);
+			asm volatile("s_nop 0\n\ts_cmp_gt_i32 %0, %1\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n\ts_branch 2f\n1:\n\ts_setprio 0\n2:"
+			             :: "s"(pm), "s"(ps) : "scc");
+		}
+	};
+	// per-wave phase clocks exist only in the -DSRH_PROFILE_PHASES diagnostic build: a handful of s_memtime per tile,
+	// none inside the block loops
+#ifdef SRH_PROFILE_PHASES
+	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long tp = __builtin_readcyclecounter();
+	const unsigned long long t_begin = tp;
+	unsigned long long n_tiles = 0, n_gen = 0;
+#define ST_STAMP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define ST_STAMP(k) do { } while (0)
+#endif
+
+	for (;;) {
+		// ---- next work item: (row segment, tile column); tall segments first, so the tail of the launch is short
+		if (tid == 0) S.item = (int)atomicAdd(&A.cnt->strip_ticket, 1u);
+		__syncthreads();                           // also: every wave has left the previous item's last tile
+		const int item = __builtin_amdgcn_readfirstlane(S.item);
+		ST_STAMP(0);                                  // ticket + waiting for the workgroup's other waves
+		if (item >= A.nitems) break;
+		const int seg = item / tiles_per_row, tx = item - seg*tiles_per_row;
+		int ya, nh;
+		{
+			const int s16 = A.n1 >> 4, s8 = (A.n2 - A.n1) >> 3;
+			if (seg < s16) { ya = seg*16; nh = 16; }
+			else if (seg < s16 + s8) { ya = A.n1 + (seg - s16)*8; nh = 8; }
+			else { ya = A.n2 + (seg - s16 - s8)*4; nh = 4; }
+			if (ya + nh > A.nrows) nh = A.nrows - ya;
+		}
+		const int x0 = tx*ST_TP;
+		const int x = x0 + i;
+		int cs = 0, rowbase = 0;                   // staging origin (column, even) and the image row held by slot 0
+
+		// one tile's own inputs (nothing here depends on the staging origin): constants, ranges, [windows]
+		auto issue_tile_inputs = [&](int r, int buf, int wb, bool consts, bool windows) {
+			const size_t px0 = (size_t)r*W + x0;
+			if (consts && wv == 0) st_dma16(A.pconst + px0*4, &S.pc[buf][0][0], ST_TP*32, lane);
+			if (consts && wv == 1) st_dma4(A.prange + px0, &S.pr[buf][0], ST_TP*8, lane);
+			if (windows) {
+				const double *wt = A.wimg + ((size_t)r*tiles_per_row + tx)*(size_t)(ST_TP*WPIX);
+				if (NBUF == 1) {
+					// each wave its own pixels' windows (8 pixels x WP taps of every window row): nobody else reads
+					// them in the block loops
+					for (int a = 0; a < WS; ++a)
+						st_dma16(wt + (size_t)a*(ST_TP*WP) + pg*8*WP, &S.w[wb][a][pg*8][0], 8*WP*8, lane);
+				} else {
+					constexpr int NBYTES = ST_TP*WPIX*8;
+					for (int off = wv*1024; off < NBYTES; off += NWV*1024)
+						if (off + lane*16 < NBYTES)
+							__builtin_amdgcn_global_load_lds((st_gbl_void *)((const char *)wt + off + lane*16),
+							                                 (st_lds_void *)((char *)&S.w[wb][0][0][0] + off), 16, 0, 0);
+				}
+			}
+		};
+		// image row `yy` of both views into ring slot `sl`, "full" bytes of row `fy` into full[fb]
+		auto issue_row = [&](int yy, int sl) {
+			const double *src = A.oth_tvp + (size_t)(yy + SRH_PADY)*SP + (cs - R + SRH_PADL);
+			if (wv < 3) { if (wv*1024 + lane*16 < RW*8) __builtin_amdgcn_global_load_lds((st_gbl_void *)((const char *)src + wv*1024 + lane*16),
+			                                                                              (st_lds_void *)((char *)&S.rt[sl][0] + wv*1024), 16, 0, 0); }
+			else if (wv == 3) st_dma16(A.ref_tvp + (size_t)(yy + SRH_PADY)*SP + (x0 - R + SRH_PADL), &S.lt[sl][0], LW*8, lane);
+		};
+		static_assert(RW*8 <= 3*1024, "three pieces per row of the other view");
+		auto issue_full = [&](int fy, int fb) {
+			// bytes [cs, cs + RW) of row fy, from the 4-byte granule that holds the first one
+			const size_t a0 = (size_t)(fy + SRH_PADY)*SP + (size_t)(cs + SRH_PADL);
+			if (wv == NWV - 1) st_dma4(A.oth_fullp + (a0 & ~(size_t)3), &S.full[fb][0], (RW + 4 + 3) & ~3, lane);
+		};
+
+		bool first = true;
+		for (int r = ya; r < ya + nh; ++r) {
+			const int y = A.y0 + r;
+			const int cur = (r - ya) & 1, nxt = cur ^ 1;
+			const int wcur = NBUF == 2 ? cur : 0, wnxt = NBUF == 2 ? nxt : 0;
+			const bool has_next = r + 1 < ya + nh;
+			if (first) issue_tile_inputs(r, cur, wcur, true, true);
+			// ---- A: everything requested for this tile has landed and every wave has left the previous tile
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			ST_STAMP(1);                               // own requests (and cost stores) outstanding
+			__builtin_amdgcn_s_barrier();
+			ST_STAMP(2);                               // waiting for the other waves
+
+			// ---- B: the tile's candidate ranges (every wave works out the union for itself: 32 values)
+			int cmin, cmax, cmin_raw;
+			{
+				const int pi = lane & 31;
+				const PixRange q = CS.pr[cur][pi];
+				int lo = q.lo, hi = q.hi;
+				if (x0 + pi >= W) { lo = 0; hi = -1; }
+				if (hi >= lo) hi = dense_cover_hi(lo, hi, NCB, G);
+				int mn = hi >= lo ? lo : 2147483647, mx = hi >= lo ? hi : -2147483647;
+#pragma unroll
+				for (int d = 1; d < 32; d <<= 1) {
+					const int on = __shfl_xor(mn, d), ox = __shfl_xor(mx, d);
+					mn = on < mn ? on : mn; mx = ox > mx ? ox : mx;
+				}
+				cmin_raw = __builtin_amdgcn_readfirstlane(mn);
+				cmax = __builtin_amdgcn_readfirstlane(mx);
+				cmin = cmin_raw & ~1;
+			}
+			const bool any = cmin_raw <= cmax;
+			// (re)stage the rings when the strip starts or the ranges have moved outside the staged columns
+			if (first || (any && (cmin < cs || cmax > cs + CHUNK - 1))) {
+				if (!first) __builtin_amdgcn_s_barrier();          // (a restage in mid-strip: nobody reads the rings any more)
+				cs = any ? cmin : 0;
+				rowbase = y - R;
+				for (int rr = 0; rr < WS; ++rr) issue_row(y - R + rr, rr);
+				issue_full(y, cur);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__builtin_amdgcn_s_barrier();
+			}
+			if (any && cmax > cs + CHUNK - 1) {
+				// a candidate range wider than the chunk: not this kernel's case (the host falls back)
+				if (tid == 0) atomicAdd(&A.cnt->strip_overflow, 1ull);
+				cmax = cs + CHUNK - 1;
+			}
+			first = false;
+			const int s0 = (y - R - rowbase) % NS;                   // ring slot of the window's first row
+			// ---- request the next tile's row, constants, ranges [and windows] now: they travel under the block loops
+			if (has_next) {
+				issue_row(y + R + 1, (y + R + 1 - rowbase) % NS);
+				issue_full(y + 1, nxt);
+				issue_tile_inputs(r + 1, nxt, wnxt, true, NBUF == 2);
+			}
+			const int foff = (int)(((size_t)(y + SRH_PADY)*SP + (size_t)(cs + SRH_PADL)) & 3);   // first byte inside its granule
+			const unsigned char *rfull = &CS.full[cur][foff];
+
+			// ---- which form do the tile's candidates need?  (uniform: every wave looks at the whole tile)
+			bool need_general = false;
+			{
+				const int pi = lane & 31;
+				const PixRange q = CS.pr[cur][pi];
+				const bool live = x0 + pi < W && q.hi >= q.lo;
+				bool bad = live && !(CS.pc[cur][pi][3] != 0.0);
+				for (int k = lane; k < CHUNK; k += 64) {
+					const int c = cs + k;
+					if (c >= cmin_raw && c <= cmax && rfull[k] == 0) bad = true;
+				}
+				need_general = __any(bad) != 0;
+			}
+
+			if (NWV == 8) { prog = 0; *(st_lds_vint *)&S.prog[wv][lane] = 0; __builtin_amdgcn_s_setprio(1); }
+			// ---- this lane's pixel
+			int e_min, e_max;
+			{
+				const PixRange q = CS.pr[cur][i];
+				e_min = q.lo; e_max = q.hi;
+				if (x >= W) { e_min = 0; e_max = -1; }
+				if (e_max >= e_min) e_max = dense_cover_hi(e_min, e_max, NCB, G);
+			}
+			const bool lall = CS.pc[cur][i][3] != 0.0;
+			const size_t tile = (size_t)r*tiles_per_row + tx;
+			ST_STAMP(3);                               // ranges, (re)staging, requests for the next tile, form of the tile
+			if (e_max >= e_min) {
+				const int lo = e_min > cs ? e_min : cs;
+				const int hi = e_max < cs + CHUNK - 1 ? e_max : cs + CHUNK - 1;
+				const int lo_e = lo & ~1;                               // blocks start on even columns (>= cs)
+				const int nblocks = hi >= lo ? (hi - lo_e + NCB)/NCB : 0;
+				double *crow = A.cost + tile*(size_t)A.cstride*ST_TP + i;
+				// phase 1: blocks of NCB candidates in the fast form (all taps usable on both sides): meanL, totalWeight,
+				// sum2 and a_t = w_t*gl_t - meanL do not depend on the candidate (twoviewstereo.cpp:917-976, same order)
+#ifdef SRH_EXPERIMENT
+				const int exp_rep = g_strip_exp_repeat;
+				for (int rep = 0; rep < exp_rep; ++rep)
+#endif
+				for (int b = g; b < (lall ? nblocks : 0); b += G) {
+					const int c0 = lo_e + b*NCB;
+					const int rc = c0 - cs;                 // tile column of the window's left edge (even)
+					bool fast = false;
+#pragma unroll
+					for (int j = 0; j < NCB; ++j) {
+						const int c = c0 + j;
+						if (c >= lo && c <= hi && rfull[rc + j] != 0) { fast = true; ++n_dev; }
+					}
+					if (fast) {
+						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
+						// Both passes are modulo-scheduled by hand (see twoview_dense_cost_kernel): a register is refilled
+						// with the next row's value right after its last use, so the LDS latency is always a row ahead.
+						double r_[NR], wv_[WS], acc[NCB];
+						{
+							const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[s0][rc]);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][0][i][0]);
+#pragma unroll
+							for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+#pragma unroll
+							for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv_[2*m] = v.x; wv_[2*m + 1] = v.y; }
+							wv_[WS - 1] = CS.w[wcur][0][i][WS - 1];
+						}
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) acc[j] = 0.0;
+						__builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the pre-header's reads have landed
+#pragma unroll 1
+						for (int row = 0; row < WS; ++row) {
+							int seen = 0;
+							prog_step(1, seen);
+							const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for pass 2
+							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
+							const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nsl][rc]);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								if (FMA) {
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) acc[j] = __builtin_fma(wv_[col], r_[col + j], acc[j]);
+								} else {
+									double pr[NCB];
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) pr[j] = wv_[col]*r_[col + j];
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) acc[j] += pr[j];        // meanR += weight*gray
+								}
+								__builtin_amdgcn_sched_barrier(0);
+								if (col & 1) {
+									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
+									const double2 u = wp[col >> 1]; wv_[col - 1] = u.x; wv_[col] = u.y;
+									__builtin_amdgcn_sched_barrier(0);
+								}
+							}
+#pragma unroll
+							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+							wv_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
+							prog_yield(seen);
+						}
+						double mR[NCB], s1[NCB], s3[NCB], av[WS];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) av[col] = CS.lt[s0][i + col];
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) { mR[j] = acc[j]/tw; s1[j] = 0.0; s3[j] = 0.0; }
+						__builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll 1
+						for (int row = 0; row < WS; ++row) {
+							int seen = 0;
+							prog_step(3, seen);
+							const int nrow = row + 1 < WS ? row + 1 : 0;
+							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
+							const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nsl][rc]);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
+							const double *lp = &CS.lt[nsl][i];
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								const double wt = wv_[col];
+								if (FMA) {
+									const double a = __builtin_fma(wt, av[col], -mL);
+									double bb[NCB];
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) bb[j] = __builtin_fma(wt, r_[col + j], -mR[j]);
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) { s1[j] = __builtin_fma(a, bb[j], s1[j]); s3[j] = __builtin_fma(bb[j], bb[j], s3[j]); }
+								} else {
+									double bb[NCB], u1[NCB], u3[NCB];
+									const double pa = wt*av[col];
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) bb[j] = wt*r_[col + j];
+									__builtin_amdgcn_sched_barrier(0);
+									const double a = pa - mL;                         // pixel_gray_l - meanL
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+								}
+								__builtin_amdgcn_sched_barrier(0);
+								av[col] = lp[col];
+								if (col & 1) {
+									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
+									const double2 u = wp[col >> 1]; wv_[col - 1] = u.x; wv_[col] = u.y;
+								}
+								__builtin_amdgcn_sched_barrier(0);
+							}
+#pragma unroll
+							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+							wv_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
+							prog_yield(seen);
+						}
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) {
+							const int c = c0 + j;
+							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
+								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
+								crow[(size_t)(c - e_min)*ST_TP] = (v < A.max_color_diff) ? v : A.max_color_diff;
+							}
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					}
+				}
+			}
+			if (NWV == 8) __builtin_amdgcn_s_setprio(2);
+			ST_STAMP(4);                               // block loops
+			// phase 2: the remaining candidates in the general form (any validity pattern), compacted into an LDS work
+			// list and spread over all lanes of the workgroup (image borders, masks): border tiles only
+			if (need_general) {
+				if (tid == 0) { S.glist_n = 0; S.gsingle_n = 0; }
+				__syncthreads();
+				for (int p = tid; p < ST_TP*Smem::NBMAX; p += NT) {
+					const int pi = p / Smem::NBMAX, b = p % Smem::NBMAX;
+					const PixRange q = CS.pr[cur][pi];
+					int qlo = q.lo, qhi = q.hi;
+					if (x0 + pi >= W) { qlo = 0; qhi = -1; }
+					if (qhi >= qlo) qhi = dense_cover_hi(qlo, qhi, NCB, G);
+					if (qhi > cs + CHUNK - 1) qhi = cs + CHUNK - 1;
+					if (qhi < qlo) continue;
+					const int c0 = (qlo & ~1) + b*NCB;
+					if (c0 > qhi) continue;
+					const bool pall = CS.pc[cur][pi][3] != 0.0;
+					unsigned need = 0;
+#pragma unroll
+					for (int j = 0; j < NCB; ++j) {
+						const int c = c0 + j;
+						if (c >= qlo && c <= qhi && !(pall && rfull[c - cs])) need |= 1u << j;     // not done in phase 1
+					}
+					if (!need) continue;
+					// Only a block whose 8 candidates all need it takes the blocked form (~2.4 fast blocks of one lane whatever it
+					// stores; rows next to the top / bottom border, pixels with unusable taps of their own).  The handful of
+					// columns next to the left / right border go candidate by candidate: 32 pixels x 5..6 of them fill three
+					// waves for one candidate's time, where 32 blocked tasks would hold half a wave for four times as long
+					// while the other waves wait at the tile barrier.
+					bool as_block = __builtin_popcount(need) == NCB;
+					if (!as_block) {
+						const int at = atomicAdd(&S.gsingle_n, __builtin_popcount(need));
+						if (at + __builtin_popcount(need) <= Smem::GL_SINGLES) {
+							int k = 0;
+#pragma unroll
+							for (int j = 0; j < NCB; ++j)
+								if ((need >> j) & 1u) { S.glist[Smem::GL_CAP - 1 - (at + k)] = (unsigned short)(pi*512 + (c0 + j - cs)); ++k; }
+						} else {
+							// no room: the reserved entries (if any lie inside the list) are marked void, the block goes to the block list
+							for (int k = at; k < at + __builtin_popcount(need) && k < Smem::GL_SINGLES; ++k) S.glist[Smem::GL_CAP - 1 - k] = 0xffffu;
+							as_block = true;
+						}
+					}
+					if (as_block) S.glist[atomicAdd(&S.glist_n, 1)] = (unsigned short)(pi*64 + b);
+				}
+				__syncthreads();
+				ST_STAMP(5);                           // phase 2: work lists
+#ifdef SRH_PROFILE_PHASES
+				++n_gen;
+#endif
+				const int nblk = S.glist_n;
+				const int nsingle = S.gsingle_n < Smem::GL_SINGLES ? S.gsingle_n : Smem::GL_SINGLES;
+				for (int q = tid; q < nblk; q += NT) {
+					const int pi = S.glist[q] >> 6, b = S.glist[q] & 63;
+					const PixRange pq = CS.pr[cur][pi];
+					int qhi = dense_cover_hi(pq.lo, pq.hi, NCB, G);
+					if (qhi > cs + CHUNK - 1) qhi = cs + CHUNK - 1;
+					const int c0 = (pq.lo & ~1) + b*NCB;
+					const bool pall = CS.pc[cur][pi][3] != 0.0;
+					unsigned store = 0;
+#pragma unroll
+					for (int j = 0; j < NCB; ++j) {
+						const int c = c0 + j;
+						if (c >= pq.lo && c <= qhi && !(pall && rfull[c - cs])) { store |= 1u << j; ++n_dev; }
+					}
+					strip_select_block<R, NBUF>(CS, wcur, s0, pi, c0 - cs, store,
+					                            A.cost + (tile*(size_t)A.cstride)*ST_TP + (ptrdiff_t)(c0 - pq.lo)*ST_TP + pi,
+					                            A.weight_cutoff, A.bad_ret, A.max_color_diff);
+				}
+				ST_STAMP(6);                           // phase 2: blocked select form
+				for (int q = tid; q < nsingle; q += NT) {
+					const unsigned short e = S.glist[Smem::GL_CAP - 1 - q];
+					if (e == 0xffffu) continue;
+					const int pi = e >> 9, k = e & 511;
+					++n_dev;
+					A.cost[(tile*(size_t)A.cstride + (size_t)(cs + k - CS.pr[cur][pi].lo))*ST_TP + pi] =
+						strip_cost_general<R, NBUF>(CS, wcur, s0, pi, k, A.weight_cutoff, A.bad_ret, A.max_color_diff);
+				}
+				ST_STAMP(7);                           // phase 2: single candidates
+				__syncthreads();     // the select forms read any pixel's window: all of it done before a window is replaced
+			}
+			// ---- one window buffer: the wave replaces its own pixels' windows as soon as it has left them
+			if (NBUF == 1 && has_next) issue_tile_inputs(r + 1, nxt, 0, false, true);
+			ST_STAMP(2);                               // (barrier after phase 2, window requests: with the barrier time)
+#ifdef SRH_PROFILE_PHASES
+			++n_tiles;
+#endif
+		}
+	}
+	block_count_add(&A.cnt->n_eval_device, n_dev);
+#ifdef SRH_PROFILE_PHASES
+	if (lane == 0) {
+		for (int k = 0; k < 8; ++k) atomicAdd(&A.cnt->dbg_phase[k], ph[k]);
+		atomicAdd(&A.cnt->dbg_blocks, n_tiles);
+		atomicAdd(&A.cnt->dbg_cycles, n_gen);
+		for (int k = 0; k < 8; ++k) atomicAdd(&A.cnt->dbg_wave[8*k + (wv & 7)], ph[k]);
+		atomicAdd(&A.cnt->dbg_total_cycles, (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+		atomicAdd(&A.cnt->dbg_waves, 1ull);
+	}
+#endif
+#undef ST_STAMP
+}
+
+template <int R, int NWV, int NBUF, bool FMA>
+static void launch_strip_variant(hipStream_t st, const StripArgs &a, int num_cus)
+{
+	typedef StripSmem<R, NBUF> Smem;
+	size_t lds = sizeof(Smem);
+	(void)hipFuncSetAttribute((const void *)twoview_strip_cost_kernel<R, NWV, NBUF, FMA>,
+	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	int grid = num_cus*(NBUF == 2 ? 1 : 2);
+	if (grid > a.nitems) grid = a.nitems;
+	if (grid < 1) grid = 1;
+	hipLaunchKernelGGL((twoview_strip_cost_kernel<R, NWV, NBUF, FMA>), dim3((unsigned)grid), dim3(NWV*64), lds, st, a);
+}
+
+// form: 0 = by the candidate range (16 block lanes only pay when a pixel has at least 17 blocks), 4 / 8 = forced
+int strip_block_lanes(int cstride, int form) {
+	if (form == 4) return 8;
+	if (form == 8) return 16;
+	return cstride > 16*ST_NCB ? 16 : 8;
+}
+
+bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, int height,
+                               const srh_params &P, int y0, int nrows, const double *wimg, const double *pconst,
+                               const PixRange *prange, const double *ref_tvp, const double *oth_tvp,
+                               const uint8_t *oth_fullp, double *cost, int cstride, Counters *cnt, int arith, int num_cus,
+                               int lanes)
+{
+	(void)views; (void)ref; (void)oth;
+	StripArgs a;
+	a.W = width; a.H = height; a.y0 = y0; a.nrows = nrows;
+	a.wimg = wimg; a.pconst = pconst; a.prange = prange;
+	a.ref_tvp = ref_tvp; a.oth_tvp = oth_tvp; a.oth_fullp = oth_fullp;
+	a.cost = cost; a.cstride = cstride; a.cnt = cnt;
+	// tall items first: 3/4 of the rows in 16-row items, 2/3 of the rest in 8-row items, the remainder in 4-row items
+	a.n1 = ((nrows*3/4)/16)*16;
+	a.n2 = a.n1 + (((nrows - a.n1)*2/3)/8)*8;
+	const int nseg = a.n1/16 + (a.n2 - a.n1)/8 + (nrows - a.n2 + 3)/4;
+	a.nitems = nseg*((width + ST_TP - 1)/ST_TP);
+	a.weight_cutoff = P.weight_cutoff; a.bad_ret = P.bad_ret; a.max_color_diff = P.max_color_diff;
+	const bool fma = arith == 1;
+	const bool wide = lanes == 16;
+	switch (P.window_radius) {
+	case 5:
+		if (wide) { if (fma) launch_strip_variant<5, 8, 2, true>(st, a, num_cus); else launch_strip_variant<5, 8, 2, false>(st, a, num_cus); }
+		else      { if (fma) launch_strip_variant<5, 4, 1, true>(st, a, num_cus); else launch_strip_variant<5, 4, 1, false>(st, a, num_cus); }
+		return true;
+	case 2:
+		if (wide) { if (fma) launch_strip_variant<2, 8, 2, true>(st, a, num_cus); else launch_strip_variant<2, 8, 2, false>(st, a, num_cus); }
+		else      { if (fma) launch_strip_variant<2, 4, 1, true>(st, a, num_cus); else launch_strip_variant<2, 4, 1, false>(st, a, num_cus); }
+		return true;
+	default: return false;
+	}
+}
+
+} // namespace srh

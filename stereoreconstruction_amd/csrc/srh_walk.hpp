@@ -189,16 +189,19 @@ __device__ __forceinline__ double tv_tap(const ViewDev &V, int x, int y) {
 	return V.gray_tv[(size_t)y*V.w + x];
 }
 
+// tap (row, col) of the window at wq[row*wrow + col*wstride]; wrow = 0 means the tile-major layout (row*WS + col)*wstride
 __device__ __forceinline__ double tv_cost(const ViewDev &L, const ViewDev &Rv, const double *__restrict__ wq,
-                                          size_t wstride, const srh_params &P, int x1, int y1, int x2, int y2)
+                                          size_t wstride, const srh_params &P, int x1, int y1, int x2, int y2,
+                                          size_t wrow = 0)
 {
 	const int R = P.window_radius, WS = 2*R + 1;
+	if (wrow == 0) wrow = (size_t)WS*wstride;
 	double meanL = 0, meanR = 0, totalWeight = 0.0;
 	for (int row = -R; row <= R; ++row) {
 		for (int col = -R; col <= R; ++col) {
 			const double gl = tv_tap(L, x1 + col, y1 + row);
 			const double gr = tv_tap(Rv, x2 + col, y2 + row);
-			const double weight = wq[(size_t)((row + R)*WS + (col + R))*wstride];
+			const double weight = wq[(size_t)(row + R)*wrow + (size_t)(col + R)*wstride];
 			if (gl == gl && gr == gr && weight > P.weight_cutoff) {
 				meanL += weight*gl;
 				meanR += weight*gr;
@@ -214,7 +217,7 @@ __device__ __forceinline__ double tv_cost(const ViewDev &L, const ViewDev &Rv, c
 		for (int col = -R; col <= R; ++col) {
 			const double gl = tv_tap(L, x1 + col, y1 + row);
 			const double gr = tv_tap(Rv, x2 + col, y2 + row);
-			const double weight = wq[(size_t)((row + R)*WS + (col + R))*wstride];
+			const double weight = wq[(size_t)(row + R)*wrow + (size_t)(col + R)*wstride];
 			if (gl == gl && gr == gr && weight > P.weight_cutoff) {
 				const double pgl = weight*gl;
 				const double pgr = weight*gr;
