@@ -492,6 +492,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 #ifdef SRH_EXPERIMENT
 	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
+	if (!strcmp(name, "exp_scan_mode")) { exp_set_scan((int)value); return SRH_OK; }
 #endif
 	return fail(SRH_E_INVALID, "unknown option '%s'", name);
 }
@@ -883,8 +884,8 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		// (+ one tile of slack: the strip kernel copies whole 32-pixel pieces of these rows)
 		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*4))) return rc;
 		int lanes = 8;
+		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
 		if (strip) {
-			if ((rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
 			lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);
 			// NaN-bordered gray_tv planes of both views, zero-bordered "window fully usable" plane of the other view
 			for (int k = 0; k < 2; ++k) {
@@ -909,17 +910,21 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 			const int nr = std::min((int)rows, y1 - by);
 			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr, strip);
+			if (dense) {
+				Scope s(c, "pixel_range_kernel");
+				launch_pixel_range(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, cstride, c->prange);
+			}
 			if (dense && strip) {
-				{ Scope s(c, "pixel_range_kernel");
-				  launch_pixel_range(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, cstride, c->prange); }
 				HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));
 				{ Scope s(c, "twoview_strip_cost_kernel");
 				  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
 				                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
 				                            c->d_cnt, c->arith, c->num_cus, lanes); }
+				{ Scope s(c, "twoview_lazy_fill_kernel");
+				  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
+				                           c->views[ref].tvp, c->views[oth].tvp, lanes, c->cost, cstride, c->d_cnt); }
 				{ Scope s(c, "twoview_scan_kernel");
-				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
-				                      c->wbuf, wstride, c->d_cnt, c->prange, lanes, true); }
+				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange); }
 			} else if (dense) {
 				{ Scope s(c, "twoview_dense_cost_kernel");
 				  if (c->arith == 2)
@@ -928,9 +933,11 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				  else
 					launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
 					                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith); }
+				{ Scope s(c, "twoview_lazy_fill_kernel");
+				  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
+				                           nullptr, nullptr, 8, c->cost, cstride, c->d_cnt); }
 				{ Scope s(c, "twoview_scan_kernel");
-				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride,
-				                      c->wbuf, wstride, c->d_cnt); }
+				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange); }
 			} else {
 				Scope s(c, "twoview_generic_kernel");
 				launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt);

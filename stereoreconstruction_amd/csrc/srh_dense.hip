@@ -396,7 +396,9 @@ __device__ __noinline__ double dense_cost_general(const DenseSmem<R, DC_NCB, DC_
 // timing experiments only (make exp): repeat the block loops of every tile `g_exp_repeat` times (the marginal
 // time of a repetition is the pure loop time), pad the dynamic LDS so that fewer workgroups fit a CU
 __device__ int g_exp_repeat = 1;
+__device__ int g_exp_scan_mode = 0;    // 1: the scan reads no cost (timing of the walk alone), 2: no walk (one label)
 int g_exp_lds_pad = 0;
+void exp_set_scan(int mode) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_scan_mode), &mode, sizeof(int)); }
 void strip_exp_set(int repeat);
 void exp_set(int repeat, int lds_pad) {
 	if (repeat >= 0) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_repeat), &repeat, sizeof(int)); strip_exp_set(repeat); }
@@ -829,17 +831,151 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 #define SC_QN 16
 #define SC_MW 1024
 
+// The columns the cost kernel leaves out (dense_cover_hi: a last block that would cost its lanes a whole extra round
+// for one or two columns) are evaluated here, one thread per pixel, with the general cost -- so that the scan kernel
+// only ever looks costs up.  (Inlined at every slot of the scan's flushes, that general cost made the scan kernel
+// 27 000 instructions long, far beyond the instruction cache.)
+__global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0, int nrows,
+                                         const PixRange *__restrict__ prange, const double *__restrict__ wbuf, size_t wstride,
+                                         int ncb, int lanes, double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	unsigned n_lazy = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
+		const PixRange pr = prange[q];
+		if (pr.hi >= pr.lo) {
+			const int cover = dense_cover_hi(pr.lo, pr.hi, ncb, lanes);
+			if (cover < pr.hi) {
+				const int R = P.window_radius, T = (2*R + 1)*(2*R + 1);
+				const double *wq = wbuf + wbuf_offset(W, T, trow, x);
+				double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+				for (int c = cover + 1; c <= pr.hi; ++c) {
+					crow[(size_t)(c - pr.lo)*DC_TP] = tv_cost(L, Rv, wq, wstride, P, x, y, c, y);
+					++n_lazy;
+				}
+			}
+		}
+	}
+	block_count_add(&cnt->n_eval_device, n_lazy);
+}
+
+// The same for the strip path: windows in the LDS-image layout (a window row = 11 contiguous doubles), image rows from
+// the NaN-bordered planes (no bound tests), loops unrolled by window row so that a row's 33 loads travel together.
+// Same sums, same order as tv_cost (twoviewstereo.cpp:909-977): a skipped tap adds +0.0.
+template <int R>
+__global__ __launch_bounds__(256)
+void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const PixRange *__restrict__ prange,
+                                   const double *__restrict__ wimg, const double *__restrict__ ref_tvp,
+                                   const double *__restrict__ oth_tvp, int ncb, int lanes,
+                                   double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
+{
+	constexpr int WS = 2*R + 1;
+	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	unsigned n_lazy = 0;
+	if (q < (size_t)nrows*W) {
+		const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
+		const PixRange pr = prange[q];
+		const int cover = pr.hi >= pr.lo ? dense_cover_hi(pr.lo, pr.hi, ncb, lanes) : pr.hi;
+		if (cover < pr.hi) {
+			const int SP = padded_stride(W);
+			const double *wq = wimg + wimg_offset(W, R, trow, x);
+			const int wrow = wimg_row_stride(R);
+			const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SP + (x + SRH_PADL - R);
+			double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+			for (int c = cover + 1; c <= pr.hi; ++c) {
+				const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
+				double meanL = 0, meanR = 0, totalWeight = 0.0;
+#pragma unroll 1
+				for (int row = 0; row < WS; ++row) {
+					double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+					for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
+#pragma unroll
+					for (int col = 0; col < WS; ++col) {
+						const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
+						const double pl = wt[col]*gl[col], prr = wt[col]*gr[col];
+						meanL += ok ? pl : 0.0;
+						meanR += ok ? prr : 0.0;
+						totalWeight += ok ? wt[col] : 0.0;
+					}
+				}
+				double result = P.bad_ret;
+				if (!(totalWeight < 1e-10)) {
+					meanL /= totalWeight;
+					meanR /= totalWeight;
+					double sum1 = 0, sum2 = 0, sum3 = 0;
+#pragma unroll 1
+					for (int row = 0; row < WS; ++row) {
+						double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
+#pragma unroll
+						for (int col = 0; col < WS; ++col) {
+							const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
+							const double a = wt[col]*gl[col] - meanL, b = wt[col]*gr[col] - meanR;
+							const double ab = a*b, aa = a*a, bb = b*b;
+							sum1 += ok ? ab : 0.0;
+							sum2 += ok ? aa : 0.0;
+							sum3 += ok ? bb : 0.0;
+						}
+					}
+					const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
+					result = (v < P.max_color_diff) ? v : P.max_color_diff;
+				}
+				crow[(size_t)(c - pr.lo)*DC_TP] = result;
+				++n_lazy;
+			}
+		}
+	}
+	block_count_add(&cnt->n_eval_device, n_lazy);
+}
+
+void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,
+                              const double *ref_tvp, const double *oth_tvp,
+                              int lanes, double *cost, int cstride, Counters *cnt)
+{
+	const size_t n = (size_t)nrows*width;
+	const dim3 grid((unsigned)((n + 255)/256)), block(256);
+	if (ref_tvp && P.window_radius == 5)
+		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<5>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, cost, cstride, cnt);
+	else if (ref_tvp && P.window_radius == 2)
+		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<2>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, cost, cstride, cnt);
+	else
+		hipLaunchKernelGGL(twoview_lazy_fill_kernel, grid, block, 0, st, views, ref, oth, P, y0, nrows, prange, wbuf, wstride, 8, lanes, cost, cstride, cnt);
+}
+
+// sums / minima over the 64 lanes of the scan kernel's one-wave workgroup (no LDS, no barrier)
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) v += (unsigned)__shfl_xor((int)v, d);
+	return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+	return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+	return v;
+}
+
 struct TwoViewScanState {
 	double minCost, secondBest;
 	int wcol;                 // winning column relative to lo, -1 = none
 };
 
-__global__ __launch_bounds__(SC_TW)
+__global__ __launch_bounds__(SC_TW, 4)
 void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                          int y0, int nrows, const double *__restrict__ tnum,
                          const double *__restrict__ cost, int cstride,
-                         const double *__restrict__ wbuf, size_t wstride, int ncb, int lanes,
-                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange, int wimg)
+                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
@@ -852,28 +988,40 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	const int x = x0 + tid;
 
 	__shared__ unsigned short queue[SC_QN][SC_TW];
-	__shared__ unsigned char mrow[SC_MW];
-	__shared__ int s_umin;
+	__shared__ __align__(16) unsigned char mrow_raw[SC_MW + 16];
 
-	unsigned n_eval = 0, n_pix = 0, bad = 0, n_lazy = 0;
+	unsigned n_eval = 0, n_pix = 0, bad = 0;
 	const bool active = x < W && L.mask[(size_t)y*W + x] == 1;
 	Ray ray;
-	int lo = 0, hi = -1, cover_hi = -1;
+	int lo = 0, hi = -1;
 	if (active) {
 		ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-		if (prange) { const PixRange pr = prange[(size_t)trow*W + x]; lo = pr.lo; hi = pr.hi; }   // pixel_range_kernel: the same function
-		else pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
-		if (hi >= lo) cover_hi = dense_cover_hi(lo, hi, ncb, lanes);
+		const PixRange pr = prange[(size_t)trow*W + x];      // pixel_range_kernel (pinhole_column_range)
+		lo = pr.lo; hi = pr.hi;
 	}
-	if (tid == 0) s_umin = 2147483647;
-	__syncthreads();
-	if (hi >= lo) atomicMin(&s_umin, lo);
-	__syncthreads();
-	const int umin = s_umin;
-	// mask bytes of row y of the other view, columns [umin, umin + SC_MW)
-	for (int k = tid; k < SC_MW; k += SC_TW) {
-		const int cx = umin + k;
-		mrow[k] = (umin != 2147483647 && y >= 0 && y < OH && cx >= 0 && cx < OW) ? Rv.mask[(size_t)y*OW + cx] : 0;
+	const int umin = wave_min_i32(hi >= lo ? lo : 2147483647);       // the workgroup is one wave
+	// mask bytes of row y of the other view, columns [umin, umin + SC_MW): 16 bytes per lane from the 4-byte granule
+	// that holds the first one (bytes past the row's end belong to the next row and are never looked at: every
+	// candidate column lies inside [lo, hi], inside the image)
+	const unsigned char *mrow = mrow_raw;
+	if (umin != 2147483647 && y >= 0 && y < OH) {
+		const size_t first = (size_t)y*OW + (size_t)umin, a0 = first & ~(size_t)3, total = (size_t)OW*OH;
+		mrow = mrow_raw + (first - a0);
+		const size_t at = a0 + (size_t)tid*16;
+		uint32_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			v[k] = (at + 4*k + 4 <= total) ? *reinterpret_cast<const uint32_t *>(Rv.mask + at + 4*k) : 0u;   // (the plane's size is not a multiple of 4: its last bytes ...)
+		if (at + 16 > total) {                                                                                   // ... one by one)
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				uint32_t w = 0;
+				for (int b2 = 0; b2 < 4; ++b2) if (at + 4*k + b2 < total) w |= (uint32_t)Rv.mask[at + 4*k + b2] << (8*b2);
+				v[k] = w;
+			}
+		}
+		uint4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+		*reinterpret_cast<uint4 *>(mrow_raw + tid*16) = q;
 	}
 	__syncthreads();
 
@@ -881,9 +1029,6 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	if (active) {
 		n_pix = 1;
 		const double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
-		const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
-		const double *wq = wbuf + (wimg ? wimg_offset(W, P.window_radius, trow, x) : wbuf_offset(W, T, trow, x));
-		const size_t wq_col = wimg ? 1 : wstride, wq_row = wimg ? (size_t)wimg_row_stride(P.window_radius) : 0;
 		TwoViewScanState st = { __builtin_inf(), __builtin_inf(), -1 };
 		int qn = 0;
 
@@ -895,15 +1040,15 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 			for (int k = 0; k < SC_QN; ++k) col[k] = queue[k][tid];
 #pragma unroll
 			for (int k = 0; k < SC_QN; ++k)
-				c[k] = (k < count && lo + col[k] <= cover_hi) ? crow[(size_t)col[k]*DC_TP] : __builtin_inf();
+#ifdef SRH_EXPERIMENT
+				c[k] = (k < count && g_exp_scan_mode != 1) ? crow[(size_t)col[k]*DC_TP] : (double)col[k];
+#else
+				c[k] = (k < count) ? crow[(size_t)col[k]*DC_TP] : __builtin_inf();
+#endif
 #pragma unroll
 			for (int k = 0; k < SC_QN; ++k) {
 				if (k < count) {
-					double cv = c[k];
-					if (lo + col[k] > cover_hi) {                   // column left out by the dense kernel
-						cv = tv_cost(L, Rv, wq, wq_col, P, x, y, lo + col[k], y, wq_row);
-						++n_lazy;
-					}
+					const double cv = c[k];
 					if (cv + P.wta_margin < st.minCost) {           // twoviewstereo.cpp:293-301
 						st.secondBest = st.minCost;
 						st.minCost = cv;
@@ -918,9 +1063,15 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 		const double nd = dot(nrm, ray.dir);
 		if (!(fabs(nd) < 1e-10)) {
 			double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+			const SharedDivisor nd_sd = shared_divisor(nd);           // 256 labels are divided by this one n.dir
+#ifdef SRH_EXPERIMENT
+			const int exp_nd = g_exp_scan_mode == 2 ? 2 : P.num_depth_levels;
+			for (int d = 0; d < exp_nd; ++d) {
+#else
 			for (int d = 0; d < P.num_depth_levels; ++d) {
+#endif
 				double x2, y2;
-				if (!pinhole_project_label(ray, nd, tnum[d], Rv.cam, P.image_scale, x2, y2)) continue;
+				if (!pinhole_project_label_sd(ray, nd_sd, tnum[d], Rv.cam, P.image_scale, x2, y2)) continue;
 				if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
 				const double dx = x2 - x1, dy = y2 - y1;
 				if (!(dx*dx + dy*dy >= 1)) continue;
@@ -931,7 +1082,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 					// ascending x whatever the direction of the segment (lineiter.hpp:96-111)
 					for (int tx = a; tx <= b; ++tx) {
 						const int k = tx - umin;
-						const bool white = (k >= 0 && k < SC_MW) ? (mrow[k] == 1) : (Rv.mask[(size_t)y*OW + tx] == 1);
+						const bool white = (k >= 0 && k < SC_MW - 4) ? (mrow[k] == 1) : (Rv.mask[(size_t)y*OW + tx] == 1);
 						if (white) {
 							++n_eval;
 							queue[qn][tid] = (unsigned short)(tx - lo);
@@ -969,22 +1120,22 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 			depth = __builtin_inf();
 	}
 	if (x < W) L.depth[(size_t)y*W + x] = depth;
-	block_count_add(&cnt->n_eval, n_eval);
-	block_count_add(&cnt->n_eval_device, n_lazy);
-	block_count_add(&cnt->n_pixels, n_pix);
-	block_count_add(&cnt->not_row_aligned, bad);
+	// the workgroup is one wave: its counts are summed by lane shuffles, one atomic each
+	n_eval = wave_sum_u32(n_eval); n_pix = wave_sum_u32(n_pix); bad = wave_sum_u32(bad);
+	if (tid == 0) {
+		if (n_eval) atomicAdd(&cnt->n_eval, (unsigned long long)n_eval);
+		if (n_pix) atomicAdd(&cnt->n_pixels, (unsigned long long)n_pix);
+		if (bad) atomicAdd(&cnt->not_row_aligned, (unsigned long long)bad);
+	}
 }
 
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         const double *wbuf, size_t wstride, Counters *cnt, const PixRange *prange, int lanes, bool wimg)
+                         Counters *cnt, const PixRange *prange)
 {
-	// block geometry of the cost kernel (dense_cover_hi must agree on both sides): 8 columns per block,
-	// `lanes` lanes per pixel (8: twoview_dense_cost_kernel and the 256-thread strip kernel; 16: the 512-thread one)
-	const int ncb = 8;
 	const int tiles = (width + SC_TW - 1)/SC_TW;
 	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, wbuf, wstride, ncb, lanes, cnt, prange, wimg ? 1 : 0);
+	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange);
 }
 
 } // namespace srh

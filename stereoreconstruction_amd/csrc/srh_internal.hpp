@@ -125,8 +125,12 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         const double *wbuf, size_t wstride, Counters *cnt,
-                         const PixRange *prange = nullptr, int lanes = 8, bool wimg = false);
+                         Counters *cnt, const PixRange *prange);
+// columns the cost kernel leaves out (dense_cover_hi with `lanes` block lanes per pixel), filled in before the scan
+void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
+                              int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,
+                              const double *ref_tvp, const double *oth_tvp,      // strip path: LDS-image windows + padded planes; else null
+                              int lanes, double *cost, int cstride, Counters *cnt);
 
 // Persistent strip form of the dense cost kernel, srh_strip.hip
 void launch_padded_plane(hipStream_t st, const double *gray_tv, int w, int h, double *out);
@@ -143,6 +147,7 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
 
 #ifdef SRH_EXPERIMENT
 void exp_set(int repeat, int lds_pad);
+void exp_set_scan(int mode);
 #endif
 
 // Fused row-aligned TwoView kernel (geometry + cost + WTA per 16-pixel tile), srh_fused.hip.

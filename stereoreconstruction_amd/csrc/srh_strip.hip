@@ -150,6 +150,7 @@ struct StripSmem {
 	unsigned short glist[GL_CAP];
 	int glist_n, gsingle_n;
 	int item;
+	unsigned long long badcols[ST_CHUNK/64 + 2];   // bit k: the window of candidate column cs + k is not fully usable
 	int simd[8];                  // SIMD of each wave of the workgroup (8-wave form: which two waves share one)
 	int prog[NBUF == 2 ? 8 : 1][64];   // progress of each wave inside the current tile, in window rows (pass 2 rows count 3); one copy per lane: no lane masking in the hot loops
 	static_assert(ST_CHUNK <= 512 && ST_TP <= 64, "work-list entry = pixel*512 + column in 16 bits");
@@ -492,9 +493,13 @@ void twoview_strip_cost_kernel(const StripArgs A)
 				const PixRange q = CS.pr[cur][pi];
 				const bool live = x0 + pi < W && q.hi >= q.lo;
 				bool bad = live && !(CS.pc[cur][pi][3] != 0.0);
-				for (int k = lane; k < CHUNK; k += 64) {
-					const int c = cs + k;
-					if (c >= cmin_raw && c <= cmax && rfull[k] == 0) bad = true;
+#pragma unroll
+				for (int it = 0; it < (CHUNK + 63)/64 + 1; ++it) {
+					const int k = it*64 + lane, c = cs + k;
+					const bool colbad = k < CHUNK + NCB && rfull[k] == 0;
+					if (colbad && c >= cmin_raw && c <= cmax) bad = true;
+					const unsigned long long m = __ballot(colbad);
+					if (wv == 0 && lane == 0) S.badcols[it] = m;         // for phase 2 (read behind its first barrier)
 				}
 				need_general = __any(bad) != 0;
 			}
@@ -667,11 +672,17 @@ void twoview_strip_cost_kernel(const StripArgs A)
 					const int c0 = (qlo & ~1) + b*NCB;
 					if (c0 > qhi) continue;
 					const bool pall = CS.pc[cur][pi][3] != 0.0;
-					unsigned need = 0;
-#pragma unroll
-					for (int j = 0; j < NCB; ++j) {
-						const int c = c0 + j;
-						if (c >= qlo && c <= qhi && !(pall && rfull[c - cs])) need |= 1u << j;     // not done in phase 1
+					// candidates of the block inside the pixel's range ...
+					unsigned need = 0xffu;
+					if (qlo > c0) need &= 0xffu << (qlo - c0);
+					if (c0 + NCB - 1 > qhi) need &= 0xffu >> (c0 + NCB - 1 - qhi);
+					// ... that phase 1 has not done: all of them when the pixel has unusable taps of its own, else those
+					// whose own window is not fully usable
+					if (pall) {
+						const int rc = c0 - cs, wd = rc >> 6, sh = rc & 63;
+						unsigned long long bits = CS.badcols[wd] >> sh;
+						if (sh) bits |= CS.badcols[wd + 1] << (64 - sh);
+						need &= (unsigned)bits;
 					}
 					if (!need) continue;
 					// Only a block whose 8 candidates all need it takes the blocked form (~2.4 fast blocks of one lane whatever it

@@ -121,6 +121,52 @@ __device__ __forceinline__ bool pinhole_project_label(const Ray &ray, double nd,
 	return true;
 }
 
+// ---- one denominator, many numerators ------------------------------------------------------------------
+// The compiler expands a double division into v_div_scale x2, v_rcp_f64, four Newton fmas on the reciprocal of
+// the (scaled) denominator, a multiply, a remainder fma, v_div_fmas and v_div_fixup.  Six of those eleven
+// instructions depend on the denominator alone.  When both operands are far from the exponent limits,
+// v_div_scale scales nothing, v_div_fmas is a plain fma and v_div_fixup returns its first operand (CDNA4 ISA,
+// V_DIV_SCALE_F64 / V_DIV_FIXUP_F64), so hoisting the denominator half changes no bit of the quotient; any
+// other operand takes the ordinary division.  The scan kernel divides 256 label numerators by one n.dir per
+// pixel and two image coordinates by one z per label.
+struct SharedDivisor { double b, r; bool ok; };
+__device__ __forceinline__ SharedDivisor shared_divisor(double b) {
+	SharedDivisor q;
+	q.b = b;
+	const double ab = fabs(b);
+	q.ok = ab > 0x1p-300 && ab < 0x1p300;
+	double r = __builtin_amdgcn_rcp(b);
+	double e = __builtin_fma(-b, r, 1.0);
+	r = __builtin_fma(r, e, r);
+	e = __builtin_fma(-b, r, 1.0);
+	q.r = __builtin_fma(r, e, r);
+	return q;
+}
+__device__ __forceinline__ double div_by(double a, const SharedDivisor &q) {
+	const double aa = fabs(a);
+	if (q.ok && aa > 0x1p-300 && aa < 0x1p300) {
+		const double m = a*q.r;
+		const double rem = __builtin_fma(-q.b, m, a);
+		return __builtin_fma(rem, q.r, m);
+	}
+	return a / q.b;
+}
+
+// pinhole_project_label with the pixel's n.dir prepared as a shared divisor: the same quotients, fewer instructions
+__device__ __forceinline__ bool pinhole_project_label_sd(const Ray &ray, const SharedDivisor &nd, double tnum,
+                                                         const srh_camera &oth, double scale, double &x2, double &y2)
+{
+	const double t = div_by(tnum, nd);
+	if (t < 1e-10) return false;
+	const Vec3 point = ray.src + t*ray.dir;
+	const Vec3 pl = matvec(oth.R, point) + load3(oth.t);
+	const Vec3 pk = matvec(oth.K, pl);
+	const SharedDivisor z = shared_divisor(pk.z);
+	x2 = div_by(pk.x, z)*scale;
+	y2 = div_by(pk.y, z)*scale;
+	return true;
+}
+
 template <class Visitor>
 __device__ __forceinline__ void walk_curve_pinhole(const Ray &ray, const srh_camera &refcam, const ViewDev &oth,
                                                    const srh_params &P, const double *__restrict__ tnum, Visitor &vis)
