@@ -215,7 +215,8 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     return result
 
 
-def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, plane=None, scale=1.0, dists=(None, None)):
+def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, plane=None, scale=1.0, dists=(None, None),
+                 all_cores=True):
     """Time the oracle (CPU restatement, one thread) on a centre row band of the same pair."""
     import oracle_ffi as O
     (Kl, Rl, tl), (Kr, Rr, tr) = cam_triples
@@ -238,7 +239,7 @@ def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, pl
     # the single-thread figure the metric names ("tbb/openmp off")
     from concurrent.futures import ThreadPoolExecutor
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    if cores > 1:
+    if cores > 1 and all_cores:
         ys = [max(0, min(h - rows, y0 + (i - cores // 2) * rows)) for i in range(cores)]
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
@@ -249,68 +250,27 @@ def cpu_baseline(L, R, ml, mr, cam_triples, zmin, zmax, D, weight_kind, rows, pl
     return base, depth, y0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the CPU-baseline band (0 = skip)")
-    ap.add_argument("--arith", default="exact", choices=["exact", "fma", "f32"],
-                    help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
-                         "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
-    ap.add_argument("--no-configs", action="store_true",
-                    help="headline line only: skip the short driver-timed legs of the other BASELINE configurations")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
-
+def run_twoview(args, workload, rank, world, dev, dev_index, backend):
+    """One TwoView workload (c1, c2, c3, c5, small); returns the JSON dict on rank 0."""
     import torch
     import torch.distributed as dist
-    # SRH_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the
-    # visible GPUs and the gather goes through host memory.  The measured configuration is "nccl" (RCCL).
-    backend = os.environ.get("SRH_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    if args.workload == "c4":
-        result = run_c4(args, rank, world, dev, dev_index, backend)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        if rank == 0:
-            print(json.dumps(result))
-        return
-
-    W, H, D, wkind, seed, desc = WORKLOADS[args.workload]
+    W, H, D, wkind, seed, desc = WORKLOADS[workload]
     # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair
     (unit,) = list(shard_units(world, world, rank))
     # C5: the 8 pairs of SURVEY 8(d) are seeds ...50-...57; other workloads: one independent pair per rank
     scale, dist_l, dist_r = 1.0, None, None
-    if args.workload == "c1":
+    if workload == "c1":
         g = np.load(os.path.join(ROOT, "tests", "golden", "bunny_pair.npz"))
         L, R, ml, mr = g["left_rgba"], g["right_rgba"], g["left_mask"], g["right_mask"]
         cams3 = ((g["left_K"], g["left_R"], g["left_t"]), (g["right_K"], g["right_R"], g["right_t"]))
         zmin, zmax, scale = 30.0, 80.0, float(g["scale"][0])
         dist_l, dist_r = g["left_dist"], g["right_dist"]
     else:
-        L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + (unit if args.workload == "c5" else 0x10000 * unit))
+        L, R, ml, mr, disp = synthetic.rectified_pair(W, H, D, seed + (unit if workload == "c5" else 0x10000 * unit))
         cams3 = synthetic.rectified_cameras(W, H)
         zmin, zmax = synthetic.rectified_depth_range(W, D)
     (Kl, Rl, tl), (Kr, Rr, tr) = cams3
-    if args.workload == "c5":
+    if workload == "c5":
         plane = (np.array([0.0, 0.0, 1.0]), 0.1, 1.333)
         cl = capi.camera_from_krt(Kl, Rl, tl, None, *plane)
         cr = capi.camera_from_krt(Kr, Rr, tr, None, *plane)
@@ -327,7 +287,7 @@ def main():
     ctx.upload_view(1, R, mr, cr)
     mismatch = None
     if args.arith in ("fma", "f32"):
-        if args.workload in ("c1", "c4", "c5"):
+        if workload in ("c1", "c4", "c5"):
             sys.exit("--arith fma applies to the dense row-aligned TwoView path (c2, c3, small)")
         ctx.twoview_wta(0, 1, p)
         exact_l = ctx.download_depth(0)
@@ -413,14 +373,14 @@ def main():
         flops_per_step = hyp_per_step_per_gpu * (15.0 * T + 8)
         valu_achieved = flops_per_step * args.steps / (ms * 1e-3) / 1e12
         # the PMC files were collected on the exact mode: no traffic / instruction figures are claimed for the opt-in modes
-        traffic = pmc_traffic(args.workload, name) if args.arith == "exact" else None
+        traffic = pmc_traffic(workload, name) if args.arith == "exact" else None
         VALU_PEAK = 157.3 if args.arith == "f32" else FP64_VALU_PEAK_TFLOPS
         result = {
             "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(value, 3), "unit": "Mhyp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if args.arith == "f32" else "f64"), "data": "synthetic" if args.workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
+            "dtype": ("f32" if args.arith == "f32" else "f64"), "data": "synthetic" if workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
             "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
                        "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
@@ -441,11 +401,13 @@ def main():
             "roofline": {"bound": "valu_fp32" if args.arith == "f32" else "valu_fp64", "kernel": name,
                          "achieved": round(valu_achieved, 3), "peak": VALU_PEAK, "unit": "TFLOP/s",
                          "frac": round(valu_achieved / VALU_PEAK, 5), "traffic": traffic,
-                         "executed": pmc_executed(args.workload, name, avg_ms) if args.arith == "exact" else None,
+                         "executed": pmc_executed(workload, name, avg_ms) if args.arith == "exact" else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                          "alg_flops_per_launch": round(flops_per_step * args.steps / launches),
                          "flops_per_hyp": 15 * T + 8,
-                         "note": "nominal flops against the FMA datasheet peak; see 'executed' for the instruction-level view",
+                         "note": "nominal flops against the FMA datasheet peak over the launch time measured in THIS run (HIP events); 'traffic' and "
+                                 "'executed' take their per-launch counts from the committed rocprofv3 --pmc passes (profiles/pmc_*.json), "
+                                 "only the time they are divided by is live",
                          "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved / HBM_PEAK_GBS, 6),
                                  "alg_bytes_per_launch": round(bytes_per_launch),
@@ -454,10 +416,10 @@ def main():
         }
         if world == 1 and args.cpu_rows > 0:
             base, cpu_depth, y0 = cpu_baseline(L, R, ml, mr, cams3, zmin, zmax, D, wkind,
-                                                args.cpu_rows if args.workload != "c1" else max(args.cpu_rows, 24),
-                                                (np.array([0.0, 0.0, 1.0]), 0.1, 1.333) if args.workload == "c5" else None,
-                                                scale, (dist_l, dist_r))
-            if args.workload == "c1":
+                                                args.cpu_rows if workload != "c1" else max(args.cpu_rows, 24),
+                                                (np.array([0.0, 0.0, 1.0]), 0.1, 1.333) if workload == "c5" else None,
+                                                scale, (dist_l, dist_r), getattr(args, "cpu_all_cores", True))
+            if workload == "c1":
                 args.cpu_rows = max(args.cpu_rows, 24)
             # the timed CPU band doubles as a full-size parity spot check of the WTA pass
             ctx.twoview_wta(0, 1, p, y0, y0 + args.cpu_rows)
@@ -472,6 +434,83 @@ def main():
         else:
             result["cpu_baseline"] = None
     ctx.close()
+    return result
+
+
+def other_configs(args, rank, world, dev, dev_index, backend):
+    """Short legs (3 timed steps after 1 warm-up) of the other BASELINE configurations, run after the headline so that
+    every config's number is timed by the same driver run: C5 (refractive pair), C4 (8-view MultiViewStereo), C2, C1.
+    Each leg carries its own CPU-oracle band (parity spot check at full size + baseline rate)."""
+    import copy
+    out = {}
+    for w, rows in (("c5", 2), ("c4", 8), ("c2", 4), ("c1", 24)):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.cpu_rows, a.workload, a.cpu_all_cores = 3, 1, rows, w, False
+        t0 = time.perf_counter()
+        try:
+            r = run_c4(a, rank, world, dev, dev_index, backend) if w == "c4" else run_twoview(a, w, rank, world, dev, dev_index, backend)
+        except Exception as e:                                   # a leg must never take the headline line down with it
+            out[w] = {"error": "%s: %s" % (type(e).__name__, e)}
+            continue
+        cb = r.get("cpu_baseline") or {}
+        out[w] = {"workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"],
+                  "steps": a.steps, "warmup": a.warmup, "scaling": r["scaling"],
+                  "roofline": {k: r["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
+                  "n_eval_reference": r["config"].get("n_eval_reference_last_pass", r["config"].get("n_eval_reference_rank0_per_step")),
+                  "kernels_ms": r["kernels_ms"], "parity_band": cb.get("parity_band"),
+                  "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
+                  "leg_seconds": round(time.perf_counter() - t0, 2)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the CPU-baseline band (0 = skip)")
+    ap.add_argument("--arith", default="exact", choices=["exact", "fma", "f32"],
+                    help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
+                         "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline line only: skip the short driver-timed legs of the other BASELINE configurations")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    # SRH_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the
+    # visible GPUs and the gather goes through host memory.  The measured configuration is "nccl" (RCCL).
+    backend = os.environ.get("SRH_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    if args.workload == "c4":
+        result = run_c4(args, rank, world, dev, dev_index, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result))
+        return
+
+    result = run_twoview(args, args.workload, rank, world, dev, dev_index, backend)
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_configs and args.arith == "exact":
+        result["configs"] = other_configs(args, rank, world, dev, dev_index, backend)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -758,6 +758,8 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 
 	// the persistent strip form of the cost kernel (srh_strip.hip): exact / fma arithmetic, candidate ranges of a
 	// 32-pixel tile inside one LDS chunk; anything else, or a range that turns out wider, takes the per-tile kernel
+	// (and enough tiles to keep every persistent workgroup busy for dozens of tiles: a small image is better served by
+	// one workgroup per tile; option strip = 4 / 8 forces the strip kernel for tests)
 	bool strip = dense && c->strip != 0 && c->arith != 2 && cstride + SRH_WTILE <= strip_chunk_columns();
 	for (int attempt = 0; attempt < 3; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
@@ -873,11 +875,17 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 			Scope s(c, "pinhole_label_table_kernel");
 			launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum);
 		}
-		const int wdoubles = strip ? (2*R + 1)*wimg_wp(R) : T;         // doubles per pixel window in the band buffer
-		size_t per_pixel = (size_t)wdoubles*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
-		size_t rows = c->wbuf_budget / (per_pixel*(size_t)W);
-		if (rows < 1) rows = 1;
-		if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
+		size_t rows = 0;
+		for (int pass = 0; pass < 2; ++pass) {
+			const int wdoubles = strip ? (2*R + 1)*wimg_wp(R) : T;     // doubles per pixel window in the band buffer
+			const size_t per_pixel = (size_t)wdoubles*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
+			rows = c->wbuf_budget / (per_pixel*(size_t)W);
+			if (rows < 1) rows = 1;
+			if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
+			// the strip kernel wants dozens of tiles per persistent workgroup and launch; thin bands take the per-tile kernel
+			if (strip && c->strip == 1 && (size_t)((W + SRH_WTILE - 1)/SRH_WTILE)*rows < (size_t)48*2*c->num_cus) strip = false;
+			else break;
+		}
 		const size_t wstride = SRH_WTILE;
 		if ((rc = ensure(c->wbuf, c->wbuf_cap, strip ? wimg_doubles(W, (int)rows, R) : wbuf_doubles(W, (int)rows, T)))) return rc;
 		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*(size_t)((W + 31)/32)*32*(size_t)cstride))) return rc;   // 32-pixel tiles

@@ -96,18 +96,33 @@ def test_c3_full_size_band_invariance(hip_ctx):
     """C3: 1920x1080, 256 levels, GeodesicWeight r=5: the depth map must not depend on the band
     split (one band at the default 8 GB budget vs ~50 bands at 128 MB), left->right pass."""
     W, H, D = 1920, 1080, 256
-    _, _, p, _ = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
+    (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
     hip_ctx.set_option("band_budget_mb", 8192)
     hip_ctx.twoview_wta(0, 1, p)
     a = hip_ctx.download_depth(0)
     st_a = hip_ctx.stats()
+    assert st_a["used_strip_kernel"]                      # one band: the persistent strip kernel ...
     hip_ctx.set_option("band_budget_mb", 128)
     hip_ctx.twoview_wta(0, 1, p)
     b = hip_ctx.download_depth(0)
     st_b = hip_ctx.stats()
+    assert not st_b["used_strip_kernel"]                  # ... ~50 thin bands: one workgroup per tile
     hip_ctx.set_option("band_budget_mb", 8192)
     assert st_a["used_dense_path"] and st_b["used_dense_path"]
     assert _same_bits(a, b)
+    # one full-width row per direction against the oracle (the right -> left pass at full size is compared nowhere else)
+    hip_ctx.twoview_wta(1, 0, p)
+    ar = hip_ctx.download_depth(1)
+    (Kl, Rl, tl), (Kr, Rr, tr) = cams3
+    li, ri, cl, cr = O.OImage(L, ml), O.OImage(R, mr), O.camera_set(Kl, Rl, tl), O.camera_set(Kr, Rr, tr)
+    y = H // 2 + 7
+    want_l = O.twoview_wta(li, ri, cl, cr, op, y, y + 1)
+    want_r = O.twoview_wta(ri, li, cr, cl, op, y, y + 1)
+    for got, want, tag in ((a, want_l, "left->right"), (ar, want_r, "right->left")):
+        same_cls = (np.isnan(got[y]) == np.isnan(want[y])) & (np.isinf(got[y]) == np.isinf(want[y]))
+        fin = np.isfinite(got[y]) & np.isfinite(want[y])
+        assert same_cls.all(), tag
+        assert np.all(np.abs(got[y][fin] - want[y][fin]) <= 1e-9*np.maximum(1.0, np.abs(want[y][fin]))), tag
     assert st_a["n_eval"] == st_b["n_eval"] and st_a["n_pixels"] == W * H
     # every reference pixel got a verdict: finite depth or +INF (ratio test); NaN only without candidates
     assert np.isnan(a).mean() < 0.01
@@ -246,4 +261,37 @@ def test_c5_full_size(hip_ctx, seed):
     for ref, oth, y in ((0, 1, H // 2), (1, 0, H // 3)):
         want = O.twoview_wta(oi[ref], oi[oth], oc[ref], oc[oth], op, y, y + 1)
         ok, msg, _ = _cmp(res["rows"][ref][0][y], want[y])
+        assert ok, (ref, y, msg)
+
+
+def test_c5_full_size_tilted_interface(hip_ctx):
+    """C5 geometry at BASELINE size with the refractive interface TILTED against the optical axis (normal not (0,0,1):
+    the axis on which the reference's y-only side test of projectRefraction, camera.cpp:119-135, is harmless): one
+    full-width row per direction against the oracle, row-run evaluation == list-order evaluation for the left view."""
+    W, H, D = 1920, 1080, 256
+    L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, 0x5EED0053)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    n = np.array([0.12, -0.07, 1.0]); n /= np.linalg.norm(n)
+    plane = (n, 0.1, 1.333)
+    hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl, None, *plane))
+    hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr, None, *plane))
+    kw = dict(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
+    p = capi.params_twoview(**kw)
+    maps = []
+    for ref, oth in ((0, 1), (1, 0)):
+        hip_ctx.twoview_wta(ref, oth, p)
+        assert not hip_ctx.stats()["used_dense_path"]
+        maps.append(hip_ctx.download_depth(ref))
+        assert np.isfinite(maps[-1]).mean() > 0.2
+    hip_ctx.set_option("list_rows", 0)
+    hip_ctx.twoview_wta(0, 1, p)
+    hip_ctx.set_option("list_rows", 1)
+    assert _same_bits(maps[0], hip_ctx.download_depth(0))
+    op = O.params_twoview(**kw)
+    oc = [O.camera_set(Kl, Rl, tl, None, *plane), O.camera_set(Kr, Rr, tr, None, *plane)]
+    oi = [O.OImage(L, ml), O.OImage(R, mr)]
+    for ref, oth, y in ((0, 1, 2 * H // 3), (1, 0, H // 4)):
+        want = O.twoview_wta(oi[ref], oi[oth], oc[ref], oc[oth], op, y, y + 1)
+        ok, msg, _ = _cmp(maps[ref][y], want[y])
         assert ok, (ref, y, msg)

@@ -47,7 +47,7 @@ def test_strip_forms_match_the_per_tile_kernel_and_the_oracle(hip_ctx, name, ove
     cases.upload_case(hip_ctx, case, cams)
     ref = _run(hip_ctx, p, 0)
     assert not ref[0][1]["used_strip_kernel"] and ref[0][1]["used_dense_path"]
-    for strip in (1, 4, 8):
+    for strip in (4, 8):          # (strip = 1, the default, takes the strip kernel only for images of thousands of tiles)
         got = _run(hip_ctx, p, strip)
         for d in range(2):
             assert got[d][1]["used_strip_kernel"], "strip=%d: the strip kernel did not run" % strip
@@ -57,7 +57,7 @@ def test_strip_forms_match_the_per_tile_kernel_and_the_oracle(hip_ctx, name, ove
             if strip == 4:      # same block geometry as the per-tile kernel (16 block lanes leave other columns to the scan)
                 assert got[d][1]["n_eval_device"] == ref[d][1]["n_eval_device"]
     want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
-    ok, msg, _ = cases.compare_depth(_run(hip_ctx, p, 1)[0][0], want, RTOL)
+    ok, msg, _ = cases.compare_depth(_run(hip_ctx, p, 8)[0][0], want, RTOL)
     assert ok, msg
 
 
@@ -66,19 +66,23 @@ def test_strip_row_bands_and_small_budget(hip_ctx):
     case = cases.get_twoview("geodesic_masks", w=96, h=64, D=20)
     cams, p = cases.hip_inputs(case)
     cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.set_option("strip", 0)
     hip_ctx.twoview_wta(0, 1, p)
     full = hip_ctx.download_depth(0)
-    hip_ctx.upload_depth(0, np.full(full.shape, np.nan))
-    for y0, y1 in ((0, 7), (7, 30), (30, 64)):
-        hip_ctx.twoview_wta(0, 1, p, y0, y1)
-        assert hip_ctx.stats()["used_strip_kernel"]
-    assert np.array_equal(hip_ctx.download_depth(0).view(np.uint64), full.view(np.uint64))
-    hip_ctx.set_option("band_budget_mb", 1)
+    hip_ctx.set_option("strip", 4)
     try:
+        hip_ctx.upload_depth(0, np.full(full.shape, np.nan))
+        for y0, y1 in ((0, 7), (7, 30), (30, 64)):
+            hip_ctx.twoview_wta(0, 1, p, y0, y1)
+            assert hip_ctx.stats()["used_strip_kernel"]
+        assert np.array_equal(hip_ctx.download_depth(0).view(np.uint64), full.view(np.uint64))
+        hip_ctx.set_option("band_budget_mb", 1)
         hip_ctx.twoview_wta(0, 1, p)
+        assert hip_ctx.stats()["used_strip_kernel"]
         assert np.array_equal(hip_ctx.download_depth(0).view(np.uint64), full.view(np.uint64))
     finally:
         hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.set_option("strip", 1)
 
 
 def test_strip_falls_back_when_a_range_is_wider_than_a_chunk(hip_ctx):
@@ -86,7 +90,11 @@ def test_strip_falls_back_when_a_range_is_wider_than_a_chunk(hip_ctx):
     case = cases.get_twoview("adaptive_rect", w=400, h=24, D=330)
     cams, p = cases.hip_inputs(case)
     cases.upload_case(hip_ctx, case, cams)
-    hip_ctx.twoview_wta(0, 1, p)
+    hip_ctx.set_option("strip", 8)
+    try:
+        hip_ctx.twoview_wta(0, 1, p)
+    finally:
+        hip_ctx.set_option("strip", 1)
     st = hip_ctx.stats()
     got = hip_ctx.download_depth(0)
     assert st["used_dense_path"] and not st["used_strip_kernel"]
