@@ -29,7 +29,8 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 from stereoreconstruction_amd import capi, synthetic  # noqa: E402
-from stereoreconstruction_amd.distributed import HipMultiViewEngine, multiview_sharded, shard_units  # noqa: E402
+from stereoreconstruction_amd.distributed import (HipMultiViewEngine, HipTwoViewBandEngine, multiview_sharded,  # noqa: E402
+                                                  shard_units, twoview_rowbands_sharded)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (datasheet)
@@ -256,7 +257,9 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
     import torch.distributed as dist
     W, H, D, wkind, seed, desc = WORKLOADS[workload]
     # weak scaling: `world` pairs in the job, pairs sharded over ranks -> every rank owns one pair
-    (unit,) = list(shard_units(world, world, rank))
+    # (--shard rows: every rank holds the SAME pair and computes its band of rows)
+    rows_shard = world > 1 and getattr(args, "shard", "pairs") == "rows"
+    (unit,) = [0] if rows_shard else list(shard_units(world, world, rank))
     # C5: the 8 pairs of SURVEY 8(d) are seeds ...50-...57; other workloads: one independent pair per rank
     scale, dist_l, dist_r = 1.0, None, None
     if workload == "c1":
@@ -309,7 +312,12 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
     host_src = [None] * NBUF
     state = {"n": 0}
 
+    band_engine = HipTwoViewBandEngine(ctx, p, dev if on_dev else "cpu") if rows_shard else None
+
     def step():
+        if rows_shard:
+            twoview_rowbands_sharded(band_engine, H)
+            return
         b = state["n"] % NBUF
         state["n"] += 1
         if pending[b] is not None:                     # the gather that last used this staging buffer
@@ -356,7 +364,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
     prof = ctx.profile()
     stats = ctx.stats()
     hyp_per_step_per_gpu = 2 * W * H * D
-    value = world * hyp_per_step_per_gpu * args.steps / dt / 1e6
+    value = (1 if rows_shard else world) * hyp_per_step_per_gpu * args.steps / dt / 1e6
 
     result = None
     if rank == 0:
@@ -365,12 +373,13 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         # algorithmic HBM bytes: 14 B per reference pixel per direction
         # (u8 RGB+mask of the reference view, u8 gray+mask of the other view, f64 depth out);
         # one step covers 2*W*H reference pixels, spread over `launches/steps` launches.
-        alg_bytes_total = 14.0 * 2 * W * H * args.steps
+        share = (len(shard_units(H, world, 0)) / H) if rows_shard else 1.0   # what rank 0's profile covers of the pair
+        alg_bytes_total = 14.0 * 2 * W * H * args.steps * share
         bytes_per_launch = alg_bytes_total / launches
         avg_ms = ms / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         T = (2 * p.window_radius + 1) ** 2
-        flops_per_step = hyp_per_step_per_gpu * (15.0 * T + 8)
+        flops_per_step = hyp_per_step_per_gpu * (15.0 * T + 8) * share
         valu_achieved = flops_per_step * args.steps / (ms * 1e-3) / 1e12
         # the PMC files were collected on the exact mode: no traffic / instruction figures are claimed for the opt-in modes
         traffic = pmc_traffic(workload, name) if args.arith == "exact" else None
@@ -379,12 +388,13 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
             "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(value, 3), "unit": "Mhyp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if rows_shard else "weak", "vs_baseline": None,
             "dtype": ("f32" if args.arith == "f32" else "f64"), "data": "synthetic" if workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
             "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
                        "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
-                       "pairs_per_gpu": 1, "parallelism": ("pairs sharded, %s gather" % ("RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
+                       "pairs_per_gpu": 1, "parallelism": (("ONE pair in %d row bands, %s gather to rank 0, cross-check there" if rows_shard else "%.0s pairs sharded, %s gather")
+                                                           % (world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                        "dense_path": bool(stats["used_dense_path"]),
                        "arithmetic": ("exact: the reference's operation order, no contraction (bit parity)" if args.arith == "exact"
                                       else "fma: multiply-adds of the cost loops fused (opt-in, NOT the parity mode)" if args.arith == "fma"
@@ -473,6 +483,9 @@ def main():
     ap.add_argument("--arith", default="exact", choices=["exact", "fma", "f32"],
                     help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
                          "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
+    ap.add_argument("--shard", default="pairs", choices=["pairs", "rows"],
+                    help="N > 1, TwoView workloads: 'pairs' (default) = one pair per GPU, weak scaling; 'rows' = ONE pair cut "
+                         "into N row bands, bands gathered on rank 0, cross-check there: strong scaling")
     ap.add_argument("--no-configs", action="store_true",
                     help="headline line only: skip the short driver-timed legs of the other BASELINE configurations")
     args = ap.parse_args()

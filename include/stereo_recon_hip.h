@@ -248,8 +248,11 @@ int  srh_mvs_initial_estimate_peaks(srh_context *ctx, int view_slot, const int32
 int  srh_mvs_mrf_estimate_views(srh_context *ctx, const int32_t *view_slots, int nviews, const srh_mrf_params *m, srh_mrf_info *infos);
 /* State of the last srh_mvs_mrf_estimate on this context, to HOST buffers (each may be NULL): labels (w*h, what
  * getLabel(p) returns), data_costs (w*h*(top_k+1)), messages (w*h*2*(top_k+1): [pixel][towards x+1, towards y+1][label],
- * the message currently stored on that edge). */
-int  srh_mvs_mrf_state(srh_context *ctx, int32_t *labels, double *data_costs, double *messages);
+ * the message currently stored on that edge).  w, h, top_k say what the caller sized its buffers for: the call fails
+ * with SRH_E_INVALID unless they are the dimensions of that run (srh_mvs_mrf_dims reports them).  There is no such
+ * state after srh_mvs_mrf_estimate_views (every view has scratch of its own) or after the view was uploaded again. */
+int  srh_mvs_mrf_dims(srh_context *ctx, int *w, int *h, int *top_k);
+int  srh_mvs_mrf_state(srh_context *ctx, int w, int h, int top_k, int32_t *labels, double *data_costs, double *messages);
 
 /* ---- depth map -> point cloud ----
  * The output side of the path (the reference keeps only the PLY writer, multiviewstereo.cpp:291-315,
@@ -307,6 +310,11 @@ int  srh_comm_allgather_depth(srh_context *ctx, int slot, void *recv_dev);
  * order); staged through device memory of the context, RCCL in between.  For callers above the C-ABI that hold
  * several maps per rank in host memory (host/sharded.hpp). */
 int  srh_comm_allgather_host(srh_context *ctx, const double *send_host, size_t count, double *recv_host);
+/* The one exchange of a sharded MultiViewStereo::runTask, device to device: the nviews views are dealt to the ranks in
+ * contiguous balanced shards (view v belongs to the rank r with lo(r) <= v < hi(r), lo(r) = r*(n/world) + min(r, n%world));
+ * every rank contributes the depth maps of ITS views, and on return (stream-ordered, nothing is staged through host
+ * memory) the depth map of every slot on every rank is its owner's.  Views may differ in size (maps travel padded). */
+int  srh_comm_allgather_views(srh_context *ctx, const int32_t *view_slots, int nviews);
 int  srh_comm_destroy(srh_context *ctx);
 
 /* ---- measurement ---- */

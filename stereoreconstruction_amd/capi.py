@@ -82,9 +82,10 @@ EXPORTS = [
     "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
     "srh_epipolar_preview", "srh_refraction_error",
-    "srh_mrf_params_defaults", "srh_mvs_mrf_estimate", "srh_mvs_mrf_state", "srh_mvs_initial_estimate_mrf",
+    "srh_mrf_params_defaults", "srh_mvs_mrf_estimate", "srh_mvs_mrf_state", "srh_mvs_mrf_dims", "srh_mvs_initial_estimate_mrf",
     "srh_mvs_initial_estimate_peaks", "srh_mvs_mrf_estimate_views",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
+    "srh_comm_allgather_views",
     "srh_comm_destroy",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
 ]
@@ -138,7 +139,10 @@ def lib():
     L.srh_mvs_initial_estimate_mrf.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
     L.srh_mvs_initial_estimate_peaks.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params)]
     L.srh_mvs_mrf_estimate_views.argtypes = [vp, c_int32_p, C.c_int, C.POINTER(SrhMrfParams), C.POINTER(SrhMrfInfo)]
-    L.srh_mvs_mrf_state.argtypes = [vp, c_int32_p, c_double_p, c_double_p]
+    L.srh_mvs_mrf_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int32_p, c_double_p, c_double_p]
+    L.srh_mvs_mrf_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.srh_comm_allgather_views.argtypes = [vp, c_int32_p, C.c_int]
+    L.srh_hw_queues_requested.restype = C.c_int
     L.srh_epipolar_preview.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p, c_int32_p]
     L.srh_refraction_error.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.srh_view_point_cloud.argtypes = [vp, C.c_int, C.POINTER(Params), c_double_p, c_uint8_p, c_uint8_p, vp, vp, vp]
@@ -237,6 +241,11 @@ def mvs_neighbours(cams, p):
     _check(lib().srh_mvs_neighbours(n, arr, C.byref(p), neigh.ctypes.data_as(c_int32_p),
                                     cnt.ctypes.data_as(c_int32_p)))
     return [[int(v) for v in neigh[i, :cnt[i]]] for i in range(n)]
+
+
+def hw_queues_requested():
+    """Hardware queues the HIP runtime was asked for (GPU_MAX_HW_QUEUES, else the runtime's default 4): srh_hw_queues_requested."""
+    return int(lib().srh_hw_queues_requested())
 
 
 def device_count():
@@ -412,8 +421,14 @@ class Context:
         labels = np.zeros((h, w), dtype=np.int32)
         D = np.zeros((h, w, top_k + 1), dtype=np.float64)
         M = np.zeros((h, w, 2, top_k + 1), dtype=np.float64)
-        _check(lib().srh_mvs_mrf_state(self._h, labels.ctypes.data_as(c_int32_p), _dptr(D), _dptr(M)))
+        _check(lib().srh_mvs_mrf_state(self._h, w, h, top_k, labels.ctypes.data_as(c_int32_p), _dptr(D), _dptr(M)))
         return labels, D, M
+
+    def mvs_mrf_dims(self):
+        """(w, h, top_k) of the single-view MRF run whose state mvs_mrf_state reports."""
+        w, h, k = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().srh_mvs_mrf_dims(self._h, C.byref(w), C.byref(h), C.byref(k)))
+        return w.value, h.value, k.value
 
     def epipolar_preview(self, ref_slot, oth_slot, min_depth, max_depth, num_depths, xy):
         """The GUI's curve preview (StereoWidget::epipolarLineItem) for the pixels `xy` (n,2) -> list of (k,2) float64."""
@@ -465,6 +480,11 @@ class Context:
 
     def comm_allgather_depth(self, slot, recv_dev_ptr):
         _check(lib().srh_comm_allgather_depth(self._h, slot, C.c_void_p(recv_dev_ptr)))
+
+    def comm_allgather_views(self, view_slots):
+        """Sharded MultiViewStereo: every rank contributes the depth maps of its shard of `view_slots`, device to device."""
+        sl = np.ascontiguousarray(view_slots, dtype=np.int32)
+        _check(lib().srh_comm_allgather_views(self._h, sl.ctypes.data_as(c_int32_p), len(sl)))
 
     def comm_destroy(self):
         _check(lib().srh_comm_destroy(self._h))

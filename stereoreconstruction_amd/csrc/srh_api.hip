@@ -1276,6 +1276,7 @@ extern "C" int srh_mvs_mrf_estimate_views(srh_context *c, const int32_t *slots, 
 		for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) return fail(SRH_E_INVALID, "view slot %d listed twice", slots[i]);
 	}
 	HIP_TRY(hipSetDevice(c->device));
+	c->mrf_w = c->mrf_h = c->mrf_k = 0;                       // the per-view runs leave no state srh_mvs_mrf_state could report
 	struct HostState { double energy, pad; unsigned status[4]; };
 	if (!c->mrf_host) HIP_TRY(hipHostMalloc(&c->mrf_host, sizeof(HostState)*SRH_MAX_VIEWS, hipHostMallocDefault));
 	HostState *hs = static_cast<HostState *>(c->mrf_host);
@@ -1337,10 +1338,22 @@ extern "C" int srh_mvs_mrf_estimate_views(srh_context *c, const int32_t *slots, 
 	return SRH_OK;
 }
 
-extern "C" int srh_mvs_mrf_state(srh_context *c, int32_t *labels, double *data_costs, double *messages)
+extern "C" int srh_mvs_mrf_dims(srh_context *c, int *w, int *h, int *top_k)
 {
 	if (!c) return fail(SRH_E_INVALID, "null context");
-	if (!c->mrf_w) return fail(SRH_E_INVALID, "no finished MRF run on this context");
+	if (!c->mrf_w) return fail(SRH_E_INVALID, "no finished single-view MRF run on this context");
+	if (w) *w = c->mrf_w;
+	if (h) *h = c->mrf_h;
+	if (top_k) *top_k = c->mrf_k;
+	return SRH_OK;
+}
+
+extern "C" int srh_mvs_mrf_state(srh_context *c, int bw, int bh, int bk, int32_t *labels, double *data_costs, double *messages)
+{
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (!c->mrf_w) return fail(SRH_E_INVALID, "no finished single-view MRF run on this context");
+	if (bw != c->mrf_w || bh != c->mrf_h || bk != c->mrf_k)
+		return fail(SRH_E_INVALID, "buffers sized for %dx%d, K = %d, the last MRF run was %dx%d, K = %d", bw, bh, bk, c->mrf_w, c->mrf_h, c->mrf_k);
 	HIP_TRY(hipSetDevice(c->device));
 	const int w = c->mrf_w, h = c->mrf_h, K = c->mrf_k, L = K + 1;
 	const size_t n = (size_t)w*h;
@@ -1461,6 +1474,45 @@ extern "C" int srh_comm_allgather_host(srh_context *c, const double *send_host, 
 		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
 	HIP_TRY(hipMemcpyAsync(recv_host, c->wbuf + count, count*(size_t)c->comm_ranks*sizeof(double), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return SRH_OK;
+}
+
+extern "C" int srh_comm_allgather_views(srh_context *c, const int32_t *slots, int nviews) {
+	int rc;
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (!c->comm) return fail(SRH_E_INVALID, "srh_comm_init has not been called");
+	if (!slots || nviews < 1 || nviews > SRH_MAX_VIEWS) return fail(SRH_E_INVALID, "bad view list");
+	size_t npix = 0;
+	for (int v = 0; v < nviews; ++v) {
+		if ((rc = check_slot(c, slots[v], true))) return rc;
+		npix = std::max(npix, (size_t)c->views[slots[v]].w*c->views[slots[v]].h);
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	const int world = c->comm_ranks, rank = c->comm_rank;
+	const int per = (nviews + world - 1)/world;                   // equal contributions: short ranks pad with NaN maps
+	auto shard = [&](int r, int &lo, int &hi) { const int base = nviews/world, extra = nviews % world;
+	                                            lo = r*base + std::min(r, extra); hi = lo + base + (r < extra ? 1 : 0); };
+	// [send | recv] in the band scratch (free between runs); everything below is ordered on the context's stream
+	if ((rc = ensure(c->wbuf, c->wbuf_cap, (size_t)(world + 1)*per*npix))) return rc;
+	double *send = c->wbuf, *recv = c->wbuf + (size_t)per*npix;
+	launch_fill(c->stream, send, (size_t)per*npix, __builtin_nan(""));
+	int lo, hi;
+	shard(rank, lo, hi);
+	for (int v = lo; v < hi; ++v) {
+		const ViewHost &vh = c->views[slots[v]];
+		HIP_TRY(hipMemcpyAsync(send + (size_t)(v - lo)*npix, vh.depth, (size_t)vh.w*vh.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+	}
+	if (const char *e = rccl_allgather_f64(c->comm, send, recv, (size_t)per*npix, c->stream))
+		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
+	for (int r = 0; r < world; ++r) {
+		if (r == rank) continue;
+		int rlo, rhi;
+		shard(r, rlo, rhi);
+		for (int v = rlo; v < rhi; ++v) {
+			const ViewHost &vh = c->views[slots[v]];
+			HIP_TRY(hipMemcpyAsync(vh.depth, recv + ((size_t)r*per + (v - rlo))*npix, (size_t)vh.w*vh.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+		}
+	}
 	return SRH_OK;
 }
 

@@ -101,6 +101,9 @@ def multiview_sharded(engine, n_views):
         engine.fence()
         local = torch.stack(maps)
         everyone = all_gather_depth_maps(local)
+        # RCCL only makes torch's current stream wait for the collective; the copies below run on the library's own
+        # stream: order the two before the first map is read (`everyone` stays alive until the final fence)
+        engine.fence()
         for r in range(world):
             if r == rank:
                 continue
@@ -111,3 +114,94 @@ def multiview_sharded(engine, n_views):
         engine.cross_check(v)
     engine.fence()
     return mine
+
+
+def twoview_rowbands_sharded(engine, height):
+    """ONE TwoViewStereo pair over the ranks of the default process group by row bands (BASELINE.md's
+    C3 row "+ row-band split for 2/4/8"): computeCostVolumes is independent per reference row
+    (twoviewstereo.cpp:265-332, 436-500 -- the row loops the reference itself hands to OpenMP), so rank r computes
+    rows shard_units(height, world, r) of BOTH maps; the bands are gathered on rank 0 (padded to the tallest band),
+    stitched, and the order-dependent cross-check (twoviewstereo.cpp:596-672: left pass, then right pass on the
+    filtered left map) runs there on the whole maps.  Returns (y0, y1) of this rank's band.
+    `engine`: wta_rows(y0, y1) -- both directions for rows [y0, y1); band_tensor(view, y0, y1, rows) -> (rows, W)
+    float64 tensor padded with NaN; set_band(view, y0, y1, tensor); cross_check(); fence(); device."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = shard_units(height, world, rank)
+    y0, y1 = mine.start, mine.stop
+    if y1 > y0:
+        engine.wta_rows(y0, y1)
+    if world > 1:
+        tallest = -(-height // world)
+        local = torch.stack([engine.band_tensor(view, y0, y1, tallest) for view in (0, 1)])
+        engine.fence()
+        bands = gather_depth_maps(local, dst=0)
+        engine.fence()
+        if rank == 0:
+            for r in range(1, world):
+                rr = shard_units(height, world, r)
+                if rr.stop > rr.start:
+                    for view in (0, 1):
+                        engine.set_band(view, rr.start, rr.stop, bands[r][view])
+            engine.fence()
+    if rank == 0:
+        engine.cross_check()
+    engine.fence()
+    return y0, y1
+
+
+class HipTwoViewBandEngine:
+    """The per-rank side of twoview_rowbands_sharded() on a GPU: one srh_context holding both views (slots 0, 1).
+    Bands travel as device tensors (RCCL; the maps never leave the device: srh_view_depth_copy_to/from_device) or,
+    device "cpu", through host memory (the gloo rehearsal)."""
+
+    def __init__(self, ctx, params, device):
+        self.ctx, self.p, self.device = ctx, params, device
+        self.w, self.h = ctx.view_size(0)
+        self.on_dev = torch.device(device).type != "cpu"
+        self.full = [None, None]            # this rank's maps as tensors, bands of other ranks written into them
+        self.dirty = [False, False]
+
+    def wta_rows(self, y0, y1):
+        self.ctx.twoview_wta(0, 1, self.p, y0, y1)
+        self.ctx.twoview_wta(1, 0, self.p, y0, y1)
+
+    def _map(self, view):
+        if self.full[view] is None:
+            if self.on_dev:
+                t = torch.empty((self.h, self.w), dtype=torch.float64, device=self.device)
+                self.fence()                                     # the allocation is torch's, the copy the library's stream
+                self.ctx.copy_depth_to_device(view, t.data_ptr(), t.numel() * 8)
+                self.ctx.synchronize()
+            else:
+                t = torch.from_numpy(self.ctx.download_depth(view))
+            self.full[view] = t
+        return self.full[view]
+
+    def band_tensor(self, view, y0, y1, rows):
+        self.full[view] = None                                   # a fresh pass: re-read the map
+        t = torch.full((rows, self.w), float("nan"), dtype=torch.float64, device=self.device if self.on_dev else "cpu")
+        if y1 > y0:
+            t[:y1 - y0] = self._map(view)[y0:y1]
+        return t
+
+    def set_band(self, view, y0, y1, t):
+        self._map(view)[y0:y1] = t[:y1 - y0]
+        self.dirty[view] = True
+
+    def cross_check(self):
+        for view in (0, 1):
+            if self.dirty[view]:
+                m = self.full[view]
+                if self.on_dev:
+                    torch.cuda.synchronize(self.device)
+                    self.ctx.copy_depth_from_device(view, m.data_ptr(), m.numel() * 8)
+                else:
+                    self.ctx.upload_depth(view, m.numpy())
+                self.dirty[view] = False
+        self.ctx.twoview_cross_check(0, 1, self.p)
+
+    def fence(self):
+        self.ctx.synchronize()
+        if self.on_dev:
+            torch.cuda.synchronize(self.device)

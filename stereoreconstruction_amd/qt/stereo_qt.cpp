@@ -101,6 +101,35 @@ QImage TwoViewStereo::colorize(const DepthMap &d, int w, int h) const {
 	return out;
 }
 
+bool TwoViewStereo::uploadViews() const {
+	if (uploaded_) return true;
+	if (srh_view_upload(ctx_, 0, left.w, left.h, left.rgba.data(), leftMask.data(), &leftView) != SRH_OK ||
+	    srh_view_upload(ctx_, 1, right.w, right.h, right.rgba.data(), rightMask.data(), &rightView) != SRH_OK) {
+		error_ = srh_last_error(); return false;
+	}
+	uploaded_ = true;
+	return true;
+}
+
+std::vector<std::array<double, 3> > TwoViewStereo::epipolarCurve(int x, int y, bool fromLeft) const {
+	std::vector<std::array<double, 3> > curve;
+	if (!ctx_ || left.w <= 0 || right.w <= 0 || !uploadViews()) return curve;
+	srh_params p = params_;
+	p.min_depth = minDepth; p.max_depth = maxDepth; p.num_depth_levels = numDepthLevels; p.image_scale = imageScale;
+	const int32_t xy[2] = { x, y };
+	int32_t count = 0;
+	std::vector<int32_t> pts(2*256);
+	for (int pass = 0; pass < 2; ++pass) {                  // the curve's length is only known afterwards
+		if (srh_epipolar_curves(ctx_, fromLeft ? 0 : 1, fromLeft ? 1 : 0, &p, 0, 1, xy, pts.data(),
+		                        static_cast<int>(pts.size()/2), &count) != SRH_OK) { error_ = srh_last_error(); return curve; }
+		if (static_cast<size_t>(count) <= pts.size()/2) break;
+		pts.resize(2*static_cast<size_t>(count));
+	}
+	curve.resize(static_cast<size_t>(count));
+	for (int k = 0; k < count; ++k) curve[k] = { static_cast<double>(pts[2*k]), static_cast<double>(pts[2*k + 1]), 1.0 };
+	return curve;
+}
+
 void TwoViewStereo::computeDepthMaps() {
 	// twoviewstereo.cpp:150-227: cost volumes (steps 1, 3), cross-check (5), colourise, finished (8).
 	// Errors are silent, as in the reference; lastError() keeps the library's message.
@@ -108,10 +137,7 @@ void TwoViewStereo::computeDepthMaps() {
 	if (left.w != right.w || left.h != right.h) { error_ = "views differ in size"; return; }
 	params_.min_depth = minDepth; params_.max_depth = maxDepth;
 	params_.num_depth_levels = numDepthLevels; params_.image_scale = imageScale;
-	if (srh_view_upload(ctx_, 0, left.w, left.h, left.rgba.data(), leftMask.data(), &leftView) != SRH_OK ||
-	    srh_view_upload(ctx_, 1, right.w, right.h, right.rgba.data(), rightMask.data(), &rightView) != SRH_OK) {
-		error_ = srh_last_error(); return;
-	}
+	if (!uploadViews()) return;
 	emit progressUpdate(1);
 	emit stageUpdate("Computing cost volume for left image...");
 	if (srh_twoview_wta(ctx_, 0, 1, &params_, 0, 0) != SRH_OK) { error_ = srh_last_error(); return; }

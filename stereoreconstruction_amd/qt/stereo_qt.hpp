@@ -12,6 +12,7 @@
 #include <QtCore/QString>
 #include <QtGui/QImage>
 
+#include <array>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,13 @@ public:
 	int numSteps() const { return 8; }
 
 	void computeDepthMaps();
+	// TwoViewStereo::epipolarCurve (public member of the reference, stereo/twoviewstereo.hpp:66-70, .cpp:999-1054; the
+	// GUI's curve preview is its user): the candidate pixels (tx, ty, 1) of reference pixel (x, y), in the order the
+	// reference visits them, joint duplicates included.  The reference takes (ray, cameraOffset, depthPlaneNormal,
+	// mask, view) -- Ray3d / Eigen types this image lacks -- and every caller builds them from a pixel the same way
+	// (twoviewstereo.cpp:275-283, 445-453: ray = unproject((x + 0.5)/scale, (y + 0.5)/scale), offset and normal from the
+	// same camera, mask and view of the other one), so the pixel and the direction are the arguments here.
+	std::vector<std::array<double, 3> > epipolarCurve(int x, int y, bool fromLeft = true) const;
 	QImage leftDepthMap() const { return resultLeft; }
 	QImage rightDepthMap() const { return resultRight; }
 	const DepthMap &leftDepths() const { return computedDepthLeft; }
@@ -69,7 +77,9 @@ private:
 	DepthMap computedDepthLeft, computedDepthRight;
 	srh_params params_;
 	srh_context *ctx_;
-	QString error_;
+	mutable bool uploaded_ = false;                        // views resident on the device (epipolarCurve before computeDepthMaps)
+	bool uploadViews() const;
+	mutable QString error_;
 };
 
 class MultiViewStereo : public Task {

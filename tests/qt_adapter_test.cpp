@@ -96,6 +96,13 @@ int main(int argc, char **argv) {
 		if (lm != "-") { if (!readRaw(lm, ML, static_cast<size_t>(w)*h*4)) return 1; qml = imageFromRaw(ML, w, h); }
 		if (rm != "-") { if (!readRaw(rm, MR, static_cast<size_t>(w)*h*4)) return 1; qmr = imageFromRaw(MR, w, h); }
 		TwoViewStereo *tv = new TwoViewStereo(cl, imageFromRaw(L, w, h), qml, cr, imageFromRaw(R, w, h), qmr, zmin, zmax, levels, scale);
+		// the public epipolarCurve member (twoviewstereo.hpp:66-70), before and independent of computeDepthMaps
+		for (int dir = 0; dir < 2; ++dir) {
+			const auto curve = tv->epipolarCurve(w/2, h/2, dir == 0);
+			printf("curve%d", dir);
+			for (const auto &pt : curve) printf(" %d,%d", static_cast<int>(pt[0]), static_cast<int>(pt[1]));
+			printf("\n");
+		}
 		std::vector<std::string> stages;
 		const std::vector<int> steps = runOnThread(app, tv, stages);
 		printf("title %s\nnumSteps %d\nsteps", tv->title().toStdString().c_str(), tv->numSteps());

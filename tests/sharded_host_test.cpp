@@ -20,17 +20,43 @@
 struct FakeEngine {
 	std::vector<std::vector<double> > maps;
 	std::vector<std::pair<char, int> > log;
+	bool fail_estimate = false;
 	explicit FakeEngine(int nviews) {
 		for (int v = 0; v < nviews; ++v) maps.push_back(std::vector<double>(5 + 3*(v % 3), std::nan("")));   // views differ in size
 	}
 	size_t viewSize(int v) const { return maps[v].size(); }
-	bool initialEstimate(int v) { log.push_back({'e', v}); for (size_t i = 0; i < maps[v].size(); ++i) maps[v][i] = 10.0*v + 0.25*i; return true; }
+	bool initialEstimate(int v) { if (fail_estimate) return false; log.push_back({'e', v}); for (size_t i = 0; i < maps[v].size(); ++i) maps[v][i] = 10.0*v + 0.25*i; return true; }
 	bool getDepth(int v, double *out) { std::memcpy(out, maps[v].data(), maps[v].size()*sizeof(double)); return true; }
 	bool setDepth(int v, const double *in) { std::memcpy(maps[v].data(), in, maps[v].size()*sizeof(double)); return true; }
 	bool crossCheck(int v) {
 		log.push_back({'c', v});
 		for (size_t u = 0; u < maps.size(); ++u) if ((int)u != v)
 			for (size_t i = 0; i < maps[v].size(); ++i) maps[v][i] = 0.5*maps[v][i] + 0.125*maps[u][i % maps[u].size()];
+		return true;
+	}
+};
+
+// a stand-in pair: row y of map `view` is a function of (view, y, x); the "cross-check" folds the OTHER map into each
+// map, left first, then right reading the already-filtered left map (twoviewstereo.cpp:596-672's order dependence)
+struct FakePair {
+	size_t w; int h;
+	std::vector<double> maps[2];
+	bool checked = false;
+	FakePair(size_t w_, int h_) : w(w_), h(h_) { for (auto &m : maps) m.assign(w*h, std::nan("")); }
+	size_t width() const { return w; }
+	bool wtaRows(int y0, int y1) {
+		for (int view = 0; view < 2; ++view) for (int y = y0; y < y1; ++y) for (size_t x = 0; x < w; ++x)
+			maps[view][y*w + x] = (x + y) % 7 == 3 ? std::nan("") : 100.0*view + y + 0.125*x;
+		return true;
+	}
+	bool getRows(int view, int y0, int y1, double *out) { std::memcpy(out, &maps[view][y0*w], (y1 - y0)*w*sizeof(double)); return true; }
+	bool setRows(int view, int y0, int y1, const double *in) { std::memcpy(&maps[view][y0*w], in, (y1 - y0)*w*sizeof(double)); return true; }
+	bool crossCheck() {
+		checked = true;
+		for (int view = 0; view < 2; ++view) for (int y = 0; y < h; ++y) for (size_t x = 0; x < w; ++x) {
+			const double o = maps[1 - view][((y*5 + 3) % h)*w + x];                   // reads a row of (usually) another band
+			if (o == o) maps[view][y*w + x] = 0.5*maps[view][y*w + x] + 0.25*o;
+		}
 		return true;
 	}
 };
@@ -69,6 +95,35 @@ static int cpuTest() {
 	int lo, hi;
 	sharded::shardUnits(8, 3, 0, lo, hi); if (lo != 0 || hi != 3) return 8;
 	sharded::shardUnits(8, 3, 2, lo, hi); if (lo != 6 || hi != 8) return 8;
+	// ---- a shard whose estimate fails: every shard returns false, none is left waiting in the exchange
+	for (int bad = 0; bad < 3; ++bad) {
+		const int world = 3, nviews = 7;
+		sharded::LoopbackTransport t(world);
+		std::vector<FakeEngine> eng(world, FakeEngine(nviews));
+		eng[bad].fail_estimate = true;
+		std::vector<int> ok(world, 1);
+		std::vector<std::thread> th;
+		for (int r = 0; r < world; ++r) th.emplace_back([&, r] { ok[r] = sharded::runMultiView(eng[r], nviews, &t, r) ? 1 : 0; });
+		for (auto &x : th) x.join();
+		for (int r = 0; r < world; ++r) if (ok[r]) { fprintf(stderr, "failing shard %d: shard %d reported success\n", bad, r); return 9; }
+	}
+	// ---- one pair by row bands: 2, 3 and 5 shards (uneven bands, one of them empty when rows < shards) == 1 shard
+	for (int height : {3, 16, 37}) {
+		FakePair ref(11, height);
+		if (!sharded::runTwoViewRowBands(ref, height, nullptr, 0)) return 10;
+		for (int world : {2, 3, 5}) {
+			sharded::LoopbackTransport t(world);
+			std::vector<FakePair> eng(world, FakePair(11, height));
+			std::vector<int> ok(world, 0);
+			std::vector<std::thread> th;
+			for (int r = 0; r < world; ++r) th.emplace_back([&, r] { ok[r] = sharded::runTwoViewRowBands(eng[r], height, &t, r) ? 1 : 0; });
+			for (auto &x : th) x.join();
+			for (int r = 0; r < world; ++r) if (!ok[r]) { fprintf(stderr, "row bands: rank %d of %d failed\n", r, world); return 11; }
+			for (int view = 0; view < 2; ++view)
+				if (!sameBits(eng[0].maps[view], ref.maps[view])) { fprintf(stderr, "row bands: height %d world %d view %d differs\n", height, world, view); return 12; }
+			for (int r = 1; r < world; ++r) if (eng[r].checked) return 13;            // the cross-check runs on shard 0 only
+		}
+	}
 	printf("cpu ok\n");
 	return 0;
 }

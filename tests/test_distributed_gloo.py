@@ -171,3 +171,90 @@ def test_two_rank_multiview_run_matches_single_process():
         assert same(got[0][1][v], eng.maps[v]) and same(got[1][1][v], eng.maps[v])
         changed |= bool(np.isnan(eng.maps[v]).any())
     assert changed, "cross-check rejected nothing: the chain is not exercised"
+
+
+class _OraclePairBandEngine:
+    """CPU stand-in for HipTwoViewBandEngine (checker role: the row split, the stitching and the place of the
+    order-dependent cross-check in twoview_rowbands_sharded are what is under test)."""
+
+    def __init__(self, case):
+        import cases
+        import oracle_ffi as O
+        self.O = O
+        self.imgs, self.cams, self.p = cases.oracle_inputs(case)
+        self.h, self.w = case["views"][0][0].shape[:2]
+        self.device = "cpu"
+        self.maps = [np.full((self.h, self.w), np.nan), np.full((self.h, self.w), np.nan)]
+        self.log = []
+
+    def wta_rows(self, y0, y1):
+        self.log.append(("wta", y0, y1))
+        O, i, c = self.O, self.imgs, self.cams
+        self.maps[0][y0:y1] = O.twoview_wta(i[0], i[1], c[0], c[1], self.p, y0, y1)[y0:y1]
+        self.maps[1][y0:y1] = O.twoview_wta(i[1], i[0], c[1], c[0], self.p, y0, y1)[y0:y1]
+
+    def band_tensor(self, view, y0, y1, rows):
+        t = torch.full((rows, self.w), float("nan"), dtype=torch.float64)
+        t[:y1 - y0] = torch.from_numpy(self.maps[view][y0:y1].copy())
+        return t
+
+    def set_band(self, view, y0, y1, t):
+        self.maps[view][y0:y1] = t[:y1 - y0].numpy()
+
+    def cross_check(self):
+        self.log.append(("cc",))
+        self.maps = list(self.O.twoview_cross_check(self.cams[0], self.cams[1], self.p, self.maps[0], self.maps[1]))
+
+    def fence(self):
+        pass
+
+
+def _band_worker(rank, world, port, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cases
+    from stereoreconstruction_amd.distributed import twoview_rowbands_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = cases.get_twoview("geodesic_masks", w=48, h=27, D=10)       # 27 rows over 2 ranks: 14 + 13, padded gather
+        eng = _OraclePairBandEngine(case)
+        band = twoview_rowbands_sharded(eng, 27)
+        q.put((rank, band, [m.copy() for m in eng.maps], eng.log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_row_band_split_of_one_pair_matches_single_process():
+    """One TwoViewStereo pair cut into two row bands (BASELINE.md's C3 row "+ row-band split for 2/4/8"): rank 0 ends
+    with the maps of a single-process run, bit for bit, cross-check (which reads rows of the other band) included."""
+    import cases
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, band, maps, log = q.get(timeout=300)
+        got[rank] = (band, maps, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == (0, 14) and got[1][0] == (14, 27)
+    assert got[0][2] == [("wta", 0, 14), ("cc",)] and got[1][2] == [("wta", 14, 27)]
+    case = cases.get_twoview("geodesic_masks", w=48, h=27, D=10)
+    eng = _OraclePairBandEngine(case)
+    from stereoreconstruction_amd.distributed import twoview_rowbands_sharded
+    assert twoview_rowbands_sharded(eng, 27) == (0, 27)
+    same = lambda a, b: np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    for view in range(2):
+        assert same(got[0][1][view], eng.maps[view])
+    assert np.isinf(eng.maps[0]).any() and np.isfinite(eng.maps[0]).any()

@@ -107,6 +107,11 @@ def test_twoview_through_the_qt_binding(hip_ctx):
         assert np.array_equal(got_l.view(np.uint64), want_l.view(np.uint64))
         assert np.array_equal(got_r.view(np.uint64), want_r.view(np.uint64))
         assert os.path.getsize(os.path.join(td, "out_left.png")) > 100
+        # the public epipolarCurve member equals the C-ABI's curve query (TwoViewStereo::epipolarCurve, twoviewstereo.hpp:66-70)
+        for d, (a, b) in enumerate(((0, 1), (1, 0))):
+            want = hip_ctx.epipolar_curves(a, b, p, [(w // 2, h // 2)])[0]
+            got = [tuple(int(v) for v in tok.split(",")) for tok in out["curve%d" % d].split()]
+            assert got == [tuple(int(v) for v in q) for q in want] and len(got) > 4
 
 
 @needs_bin
