@@ -870,7 +870,7 @@ template <int R>
 __global__ __launch_bounds__(256)
 void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const PixRange *__restrict__ prange,
                                    const double *__restrict__ wimg, const double *__restrict__ ref_tvp,
-                                   const double *__restrict__ oth_tvp, int ncb, int lanes,
+                                   const double *__restrict__ oth_tvp, int ncb, int lanes, int pad,
                                    double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
 {
 	constexpr int WS = 2*R + 1;
@@ -879,7 +879,7 @@ void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const
 	if (q < (size_t)nrows*W) {
 		const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
 		const PixRange pr = prange[q];
-		const int cover = pr.hi >= pr.lo ? dense_cover_hi(pr.lo, pr.hi, ncb, lanes) : pr.hi;
+		const int cover = pr.hi >= pr.lo ? dense_cover_hi(pr.lo, pr.hi, ncb, lanes, pad != 0) : pr.hi;
 		if (cover < pr.hi) {
 			const int SP = padded_stride(W);
 			const double *wq = wimg + wimg_offset(W, R, trow, x);
@@ -942,9 +942,9 @@ void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + 255)/256)), block(256);
 	if (ref_tvp && P.window_radius == 5)
-		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<5>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<5>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, lanes == 8 ? 1 : 0, cost, cstride, cnt);
 	else if (ref_tvp && P.window_radius == 2)
-		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<2>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<2>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, lanes == 8 ? 1 : 0, cost, cstride, cnt);
 	else
 		hipLaunchKernelGGL(twoview_lazy_fill_kernel, grid, block, 0, st, views, ref, oth, P, y0, nrows, prange, wbuf, wstride, 8, lanes, cost, cstride, cnt);
 }

@@ -232,10 +232,18 @@ SRH_HD double depth_from_label(const srh_params &P, bool mvs, int label) {
 // double -> int as at the LineIterator call sites.  NaN / out of range is UB in
 // the reference; saturate at +-2^29 (NaN -> 0) so deltas cannot overflow.
 SRH_HD int trunc_sat(double v) {
+#ifdef __HIP_DEVICE_COMPILE__
+	// branch-free: clamp (a NaN comes out of the clamp as a bound), truncate, then NaN -> 0.  Four of these per kept label
+	// were a quarter of the scan kernel's instructions as compare-and-branch chains.
+	const double c = __builtin_fmin(__builtin_fmax(v, -536870912.0), 536870912.0);
+	const int i = (int)c;
+	return v == v ? i : 0;
+#else
 	if (isnan_d(v)) return 0;
 	if (v >= 536870912.0) return 536870912;
 	if (v <= -536870912.0) return -536870912;
 	return (int)v;
+#endif
 }
 
 SRH_HD int out_code(int x, int y, int w, int h) {             // lineiter.cpp:35-42

@@ -143,6 +143,10 @@ struct StripSmem {
 	static constexpr int GL_SINGLES = GL_CAP - ST_TP*NBMAX;
 	alignas(16) double w[NBUF][WS][ST_TP][WP];         // LDS image of the windows: [row][pixel][tap], as in the band buffer
 	alignas(16) double rt[NS][RW];
+	// 8-wave form: the same rows once more, shifted by one column (rto[s][k] = rt[s][k + 1]): a block that starts on
+	// an odd column still reads 16 aligned bytes at a time, so blocks start at the pixel's first column (no alignment
+	// pad) and a range of 8*16*k columns needs exactly k rounds -- on C3 no column is left to the fill kernel
+	alignas(16) double rto[NBUF == 2 ? NS : 1][RW];
 	alignas(16) double lt[NS][LW];
 	alignas(16) double pc[2][ST_TP][4];
 	alignas(16) PixRange pr[2][ST_TP];
@@ -241,7 +245,7 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 	for (int row = 0; row < WS; ++row) {
 		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
 		double rr[NR];
-		const double2 *rp = reinterpret_cast<const double2 *>(&S.rt[sl][rc]);
+		const double2 *rp = reinterpret_cast<const double2 *>((NBUF == 2 && (rc & 1)) ? &S.rto[sl][rc - 1] : &S.rt[sl][rc]);
 #pragma unroll
 		for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; rr[2*m] = v.x; rr[2*m + 1] = v.y; }
 #pragma unroll
@@ -269,7 +273,7 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 	for (int row = 0; row < WS; ++row) {
 		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
 		double rr[NR];
-		const double2 *rp = reinterpret_cast<const double2 *>(&S.rt[sl][rc]);
+		const double2 *rp = reinterpret_cast<const double2 *>((NBUF == 2 && (rc & 1)) ? &S.rto[sl][rc - 1] : &S.rt[sl][rc]);
 #pragma unroll
 		for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; rr[2*m] = v.x; rr[2*m + 1] = v.y; }
 #pragma unroll
@@ -313,6 +317,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 	constexpr int NR = NCB + 2*R;              // right-row values a block needs (even)
 	constexpr int G = 2*NWV;                   // block lanes per pixel
 	constexpr int NT = NWV*64;
+	constexpr bool PAD = NBUF == 1;            // blocks start on even columns (one copy of the rows); 8-wave form: at the pixel's first column
 	static_assert(NR % 2 == 0, "16-byte rows");
 	static_assert((NWV == 4 && NBUF == 1) || (NWV == 8 && NBUF == 2), "two forms");
 	extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -420,6 +425,11 @@ void twoview_strip_cost_kernel(const StripArgs A)
 			if (wv < 3) { if (wv*1024 + lane*16 < RW*8) __builtin_amdgcn_global_load_lds((st_gbl_void *)((const char *)src + wv*1024 + lane*16),
 			                                                                              (st_lds_void *)((char *)&S.rt[sl][0] + wv*1024), 16, 0, 0); }
 			else if (wv == 3) st_dma16(A.ref_tvp + (size_t)(yy + SRH_PADY)*SP + (x0 - R + SRH_PADL), &S.lt[sl][0], LW*8, lane);
+			else if (NBUF == 2 && wv < 7) {
+				const int pc = wv - 4;                            // the copy shifted by one column
+				if (pc*1024 + lane*16 < RW*8) __builtin_amdgcn_global_load_lds((st_gbl_void *)((const char *)(src + 1) + pc*1024 + lane*16),
+				                                                                (st_lds_void *)((char *)&S.rto[sl][0] + pc*1024), 16, 0, 0);
+			}
 		};
 		static_assert(RW*8 <= 3*1024, "three pieces per row of the other view");
 		auto issue_full = [&](int fy, int fb) {
@@ -448,7 +458,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 				const PixRange q = CS.pr[cur][pi];
 				int lo = q.lo, hi = q.hi;
 				if (x0 + pi >= W) { lo = 0; hi = -1; }
-				if (hi >= lo) hi = dense_cover_hi(lo, hi, NCB, G);
+				if (hi >= lo) hi = dense_cover_hi(lo, hi, NCB, G, PAD);
 				int mn = hi >= lo ? lo : 2147483647, mx = hi >= lo ? hi : -2147483647;
 #pragma unroll
 				for (int d = 1; d < 32; d <<= 1) {
@@ -511,7 +521,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 				const PixRange q = CS.pr[cur][i];
 				e_min = q.lo; e_max = q.hi;
 				if (x >= W) { e_min = 0; e_max = -1; }
-				if (e_max >= e_min) e_max = dense_cover_hi(e_min, e_max, NCB, G);
+				if (e_max >= e_min) e_max = dense_cover_hi(e_min, e_max, NCB, G, PAD);
 			}
 			const bool lall = CS.pc[cur][i][3] != 0.0;
 			const size_t tile = (size_t)r*tiles_per_row + tx;
@@ -519,7 +529,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 			if (e_max >= e_min) {
 				const int lo = e_min > cs ? e_min : cs;
 				const int hi = e_max < cs + CHUNK - 1 ? e_max : cs + CHUNK - 1;
-				const int lo_e = lo & ~1;                               // blocks start on even columns (>= cs)
+				const int lo_e = PAD ? (lo & ~1) : lo;                  // blocks start on even columns (>= cs) / at the first column
 				const int nblocks = hi >= lo ? (hi - lo_e + NCB)/NCB : 0;
 				double *crow = A.cost + tile*(size_t)A.cstride*ST_TP + i;
 				// phase 1: blocks of NCB candidates in the fast form (all taps usable on both sides): meanL, totalWeight,
@@ -530,7 +540,9 @@ void twoview_strip_cost_kernel(const StripArgs A)
 #endif
 				for (int b = g; b < (lall ? nblocks : 0); b += G) {
 					const int c0 = lo_e + b*NCB;
-					const int rc = c0 - cs;                 // tile column of the window's left edge (even)
+					const int rc = c0 - cs;                 // tile column of the window's left edge
+					// 16-byte reads need an even index: an odd edge reads the copy shifted by one column
+					const double *rbase = (!PAD && (rc & 1)) ? &CS.rto[0][0] - 1 : &CS.rt[0][0];
 					bool fast = false;
 #pragma unroll
 					for (int j = 0; j < NCB; ++j) {
@@ -543,7 +555,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 						// with the next row's value right after its last use, so the LDS latency is always a row ahead.
 						double r_[NR], wv_[WS], acc[NCB];
 						{
-							const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[s0][rc]);
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + s0*RW + rc);
 							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][0][i][0]);
 #pragma unroll
 							for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
@@ -560,7 +572,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 							prog_step(1, seen);
 							const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for pass 2
 							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
-							const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nsl][rc]);
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
 							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
 #pragma unroll
 							for (int col = 0; col < WS; ++col) {
@@ -599,7 +611,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 							prog_step(3, seen);
 							const int nrow = row + 1 < WS ? row + 1 : 0;
 							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
-							const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nsl][rc]);
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
 							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
 							const double *lp = &CS.lt[nsl][i];
 #pragma unroll
@@ -666,10 +678,10 @@ void twoview_strip_cost_kernel(const StripArgs A)
 					const PixRange q = CS.pr[cur][pi];
 					int qlo = q.lo, qhi = q.hi;
 					if (x0 + pi >= W) { qlo = 0; qhi = -1; }
-					if (qhi >= qlo) qhi = dense_cover_hi(qlo, qhi, NCB, G);
+					if (qhi >= qlo) qhi = dense_cover_hi(qlo, qhi, NCB, G, PAD);
 					if (qhi > cs + CHUNK - 1) qhi = cs + CHUNK - 1;
 					if (qhi < qlo) continue;
-					const int c0 = (qlo & ~1) + b*NCB;
+					const int c0 = (PAD ? (qlo & ~1) : qlo) + b*NCB;
 					if (c0 > qhi) continue;
 					const bool pall = CS.pc[cur][pi][3] != 0.0;
 					// candidates of the block inside the pixel's range ...
@@ -716,9 +728,9 @@ void twoview_strip_cost_kernel(const StripArgs A)
 				for (int q = tid; q < nblk; q += NT) {
 					const int pi = S.glist[q] >> 6, b = S.glist[q] & 63;
 					const PixRange pq = CS.pr[cur][pi];
-					int qhi = dense_cover_hi(pq.lo, pq.hi, NCB, G);
+					int qhi = dense_cover_hi(pq.lo, pq.hi, NCB, G, PAD);
 					if (qhi > cs + CHUNK - 1) qhi = cs + CHUNK - 1;
-					const int c0 = (pq.lo & ~1) + b*NCB;
+					const int c0 = (PAD ? (pq.lo & ~1) : pq.lo) + b*NCB;
 					const bool pall = CS.pc[cur][pi][3] != 0.0;
 					unsigned store = 0;
 #pragma unroll

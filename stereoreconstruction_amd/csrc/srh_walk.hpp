@@ -221,8 +221,10 @@ __device__ __forceinline__ void pinhole_column_range(const Ray &ray, const srh_c
 // shared by `lanes` lanes.  When the last block would cost a whole extra round of the lanes for
 // at most two columns (typically the never-visited column of the last label plus the alignment
 // pad), it is left out: the scan evaluates such a column on demand with the general cost.
-__device__ __forceinline__ int dense_cover_hi(int lo, int hi, int ncb, int lanes) {
-	const int lo_e = lo & ~1;
+// (pad: blocks start on even columns -- the kernels that keep ONE copy of the other view's rows in LDS and read it 16
+// bytes at a time; the 8-wave strip kernel keeps a second copy shifted by one column and starts its blocks at lo)
+__device__ __forceinline__ int dense_cover_hi(int lo, int hi, int ncb, int lanes, bool pad = true) {
+	const int lo_e = pad ? (lo & ~1) : lo;
 	const int nblocks = (hi - lo_e + ncb)/ncb;
 	const int last_cols = (hi - lo_e + 1) - (nblocks - 1)*ncb;
 	if (nblocks > lanes && nblocks % lanes == 1 && last_cols <= 2) return lo_e + (nblocks - 1)*ncb - 1;
