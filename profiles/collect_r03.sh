@@ -45,7 +45,7 @@ for w in c4 c5; do
 	pmc ${w}_tcp $w TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
 	pmc ${w}_tcc $w TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 done
-for w in c3 c4 c5; do python3 profiles/pmc_table.py "$OUT"/pmc_${w}_mix*.csv "$OUT"/pmc_${w}_tc*.csv > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
+for w in c3 c4 c5; do python3 profiles/pmc_table.py $(ls "$OUT"/pmc_${w}_mix*.csv "$OUT"/pmc_${w}_tc*.csv 2>/dev/null) > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
 # per-phase stamps of the strip kernel (diagnostic build: never the shipped library), both forms
 for strip in 8 4; do
 	SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so SRH_BENCH_STRIP=$strip timeout -k 10 200 $B --workload c3 --steps 2 --warmup 1 --cpu-rows 0 --no-configs > /dev/null 2> "$OUT/phases_strip$strip.err"
