@@ -61,7 +61,6 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
                          srh_params P, int y0, int nrows, double *__restrict__ wbuf, size_t wstride,
                          double *__restrict__ pconst)
 {
-	constexpr bool wimg = WIMG;
 	constexpr int WS = 2*R + 1;
 	constexpr int TWD = GW_TW + 2*R;            // tile width
 	const ViewDev &V = views[ref];

@@ -186,7 +186,7 @@ __device__ __noinline__ double strip_cost_general(const StripSmem<R, NBUF> &S, i
                                                   double weight_cutoff, double bad_ret, double max_color_diff)
 {
 	typedef StripSmem<R, NBUF> Smem;
-	constexpr int WS = Smem::WS, WP = Smem::WP, NS = Smem::NS;
+	constexpr int WS = Smem::WS, NS = Smem::NS;
 	double meanL = 0, meanR = 0, totalWeight = 0.0;
 #pragma unroll 1
 	for (int row = 0; row < WS; ++row) {
