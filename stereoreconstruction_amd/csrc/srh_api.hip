@@ -87,6 +87,9 @@ struct srh_context {
 	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
 	int list_smax_hint = 0;                             // most cost slots a pixel needed so far (run-blocked lists)
 	int mvs_cmax_hint = 0;                              // longest MultiViewStereo candidate list seen so far
+	int mvs_staged = 1;                                 // option "mvs_staged": the list cost kernel takes its windows from LDS copies of the other view where they fit (default), 0 = gathers only
+	uint32_t *mvs_wdesc = nullptr; size_t mvs_wdesc_cap = 0;   // window descriptors of the walk kernel's waves
+	int32_t *mvs_nwin = nullptr; size_t mvs_nwin_cap = 0;
 	bool list_rows = true;                              // option "list_rows": evaluate lists in row runs (srh_rows.hip)
 	uint32_t *lrowinfo = nullptr; size_t lrowinfo_cap = 0;
 	int32_t *lmeta = nullptr; size_t lmeta_cap = 0;
@@ -393,6 +396,7 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
 	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
 	if (const char *s = getenv("SRH_STRIP")) c->strip = atoi(s);
+	if (const char *s = getenv("SRH_MVS_STAGED")) c->mvs_staged = atoi(s) != 0;
 	{ int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
 	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
 	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
@@ -453,6 +457,8 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->lcand) hipFree(c->lcand);
 	if (c->lrowinfo) hipFree(c->lrowinfo);
 	if (c->lmeta) hipFree(c->lmeta);
+	if (c->mvs_wdesc) hipFree(c->mvs_wdesc);
+	if (c->mvs_nwin) hipFree(c->mvs_nwin);
 	if (c->comm) rccl_comm_destroy(c->comm);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
@@ -484,6 +490,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		if (value != 0 && value != 1 && value != 4 && value != 8) return fail(SRH_E_INVALID, "strip must be 0, 1, 4 or 8");
 		c->strip = (int)value; return SRH_OK;
 	}
+	if (!strcmp(name, "mvs_staged")) { c->mvs_staged = value != 0; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
@@ -1056,21 +1063,41 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 			if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K
 			if ((rc = ensure(c->lcand, c->lcand_cap, ((units + 63) & ~(size_t)63)*(size_t)cmax))) return rc;   // wave-tiled lists
 			if ((rc = ensure(c->lcount, c->lcount_cap, units))) return rc;
+			const bool staged = c->mvs_staged && !peaks_dev;
+			if (staged) {
+				int maxw; size_t words;
+				mvs_staging_shape(&maxw, &words);
+				const size_t waves = ((lrows*W + 127)/128)*2*(size_t)nneigh;
+				if ((rc = ensure(c->mvs_wdesc, c->mvs_wdesc_cap, waves*words))) return rc;
+				if ((rc = ensure(c->mvs_nwin, c->mvs_nwin_cap, waves))) return rc;
+			}
 			for (int by = y0; by < y1; by += (int)lrows) {
 				if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 				const int nr = std::min((int)lrows, y1 - by);
 				run_weights(c, view, W, *p, by, nr, wstride);
 				{ Scope s(c, "mvs_walk_kernel");
 				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
-				                  c->d_cnt, c->d_span); }
+				                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr); }
 				{ Scope s(c, "mvs_list_cost_kernel");
 				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
 				                       c->lcand, cmax, c->lcount, c->cost, peaks_dev ? c->cost + units*2 : nullptr,
-				                       (double *)peaks_dev); }
+				                       (double *)peaks_dev, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, c->d_cnt); }
 			}
 			int maxc = 0;
 			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
 			HIP_TRY(hipStreamSynchronize(c->stream));
+#ifdef SRH_PROFILE_PHASES
+			{
+				Counters h;
+				HIP_TRY(hipMemcpy(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost));
+				if (h.dbg_waves)
+					fprintf(stderr, "[srh prof] staged MVS cost: %llu waves, %.1f windows and %.1f slots per wave; cycles per wave: life %.0f = "
+					        "set-up %.0f + copies %.0f + slots %.0f (%.0f per slot) + end %.0f\n", h.dbg_waves, (double)h.dbg_cycles/h.dbg_waves,
+					        (double)h.dbg_blocks/h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_phase[0]/h.dbg_waves,
+					        (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
+					        h.dbg_blocks ? (double)h.dbg_phase[2]/h.dbg_blocks : 0.0, (double)h.dbg_phase[3]/h.dbg_waves);
+			}
+#endif
 			if (maxc <= cmax) { if (cmax > c->mvs_cmax_hint) c->mvs_cmax_hint = cmax; break; }
 			cmax = (maxc + 7) & ~7;                                   // a list was cut: repeat with the true maximum
 		}

@@ -673,6 +673,19 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 //                     current one is reduced; keeps the largest (cost, depth) pair (:589-604, 654-660).
 // Lists are stored wave-tiled, entry k of unit u at ((u/64)*cmax + k)*64 + u%64: a wave reads and
 // writes its 64 lists coalesced, and they are contiguous in memory.
+// The lists of a wave's 64 units (64 neighbouring pixels of one row, one link) are kept ALIGNED: after every flush of
+// the raster queues the shorter lists are filled up with MQ_PAD entries to the wave's longest.  Entry k of every lane
+// then belongs to the same stretch of depth levels, so the 64 windows the cost kernel gathers for one k lie side by
+// side in the other view (a few cache lines per wave-load).  Without it the k-th candidates drift apart -- a curve
+// that enters the other view's mask fifteen pixels later than its neighbour's stays fifteen entries behind for the
+// rest of the list -- and the kernel is bound by the L1 address path (18 lines per wave-load).
+// A pad is never evaluated; count[] holds the list length in slots, the work counters count candidates.
+// Every flush also closes a WINDOW of list slots [kb, ke) shared by the wave's 64 lists, and the walk kernel records
+// the bounding box of the candidates in it: mvs_staged_cost_kernel copies that box of the other view (plus the
+// window radius) into LDS once and takes the 64 x (ke - kb) x 25 taps from there.  A wave with a window that does not
+// fit (box over an image border, larger than the LDS share, more than `maxw` windows) is left to
+// mvs_list_cost_kernel, which gathers from memory: nwin[wave] = -1.
+#define MQ_PAD 0xffffffffu
 #define MQ_T 128
 #define MQ_QN 32
 #define MQ_FLUSH 24
@@ -682,10 +695,15 @@ __global__ __launch_bounds__(MQ_T)
 void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                      int y0, int nrows, const double *__restrict__ tnum, uint32_t *__restrict__ cand, int cmax,
                      int32_t *__restrict__ count,
-                     Counters *__restrict__ cnt, int *__restrict__ max_count)
+                     Counters *__restrict__ cnt, int *__restrict__ max_count,
+                     uint4 *__restrict__ wdesc, int32_t *__restrict__ nwin, int maxw, int lds_cap)
 {
 	__shared__ uint32_t s_q[MQ_QN][MQ_T];
 	__shared__ int s_max;
+	const size_t waveid = ((size_t)blockIdx.y*gridDim.x + blockIdx.x)*(MQ_T/64) + (threadIdx.x >> 6);
+	int nw = 0, wbase = 0;                                          // windows closed so far, first slot of the open one
+	bool wstaged = wdesc != nullptr;
+	int fx0 = 65535, fx1 = -1, fy0 = 65535, fy1 = -1;               // box of the candidates this lane kept in the open window
 	const ViewDev &A = views[ref];
 	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w, OH = B.h;
@@ -695,7 +713,8 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 	const size_t unit = (size_t)blockIdx.y*npix + q;
 	const int x = (int)(q % W), y = y0 + (int)(q / W);
 	const bool active = q < npix && A.mask[(size_t)y*W + x] == 1;
-	int nk = 0;                                                     // candidates kept so far
+	int nk = 0;                                                     // list slots written so far (candidates and pads)
+	int nreal = 0;                                                  // candidates kept so far
 	if (tid == 0) s_max = 0;
 
 	if (__any(active)) {
@@ -720,10 +739,38 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 					if (m[j] == 1 && e[j] != last) {                // mask == WHITE, then std::unique (:786-807)
 						last = e[j];
 						if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = e[j];
-						++nk;
+						++nk; ++nreal;
+						const int ex = (int)(e[j] & 0xffffu), ey = (int)(e[j] >> 16);
+						fx0 = ex < fx0 ? ex : fx0; fx1 = ex > fx1 ? ex : fx1;
+						fy0 = ey < fy0 ? ey : fy0; fy1 = ey > fy1 ? ey : fy1;
 					}
 			}
 			qn = 0;
+			// align the wave's lists (flush() is called by all lanes together)
+			int top = nk;
+#pragma unroll
+			for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_xor(top, dd); top = o > top ? o : top; }
+			if (active)
+				for (; nk < top; ++nk)
+					if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = MQ_PAD;
+			if (wdesc && top > wbase) {
+				int X0 = fx0, X1 = fx1, Y0 = fy0, Y1 = fy1;
+#pragma unroll
+				for (int dd = 1; dd < 64; dd <<= 1) {
+					const int a0 = __shfl_xor(X0, dd), a1 = __shfl_xor(X1, dd), b0 = __shfl_xor(Y0, dd), b1 = __shfl_xor(Y1, dd);
+					X0 = a0 < X0 ? a0 : X0; X1 = a1 > X1 ? a1 : X1; Y0 = b0 < Y0 ? b0 : Y0; Y1 = b1 > Y1 ? b1 : Y1;
+				}
+				const int Rw = P.window_radius;
+				const int cols = X1 - X0 + 1 + 2*Rw, rows = Y1 - Y0 + 1 + 2*Rw;
+				const bool fits = X0 - Rw >= 0 && Y0 - Rw >= 0 && X1 + Rw < OW && Y1 + Rw < OH && rows*(cols | 1) <= lds_cap;
+				if (!fits || nw >= maxw) wstaged = false;
+				else if ((tid & 63) == 0)
+					wdesc[waveid*(size_t)maxw + nw] = make_uint4((unsigned)wbase, (unsigned)top, (unsigned)X0 | ((unsigned)Y0 << 16),
+					                                            (unsigned)X1 | ((unsigned)Y1 << 16));
+				++nw;
+				wbase = top;
+				fx0 = 65535; fx1 = -1; fy0 = 65535; fy1 = -1;
+			}
 		};
 
 		const Vec3 camC = load3(A.cam.C);
@@ -776,12 +823,13 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		flush();
 	}
 	if (q < npix) count[unit] = nk;
+	if (nwin && (tid & 63) == 0) nwin[waveid] = wstaged ? nw : -1;
 	__syncthreads();
 	if (nk) atomicMax(&s_max, nk);
 	__syncthreads();
 	if (tid == 0 && s_max) atomicMax(max_count, s_max);
-	block_count_add(&cnt->n_eval, (unsigned)nk);
-	block_count_add(&cnt->n_eval_device, (unsigned)nk);
+	block_count_add(&cnt->n_eval, (unsigned)nreal);
+	block_count_add(&cnt->n_eval_device, (unsigned)nreal);
 	block_count_add(&cnt->n_pixels, (active && blockIdx.y == 0) ? 1u : 0u);
 }
 
@@ -849,6 +897,7 @@ __device__ __noinline__ void mvs_unit_general(const ViewDev &A, const ViewDev &B
 	if (pk) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }
 	for (int k = 0; k < n; ++k) {
 		const uint32_t e = cl[(size_t)k*64];
+		if (e == MQ_PAD) continue;                                   // alignment filler of the wave-aligned lists
 		const int cx = (int)(e & 0xffffu), cy = (int)(e >> 16);
 		const double c = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, cx, cy);
 		if (c > P.peak_threshold && (pk || c >= bestCost)) {         // multiviewstereo.cpp:589-594, 654-660
@@ -867,9 +916,11 @@ __global__ __launch_bounds__(MQ_T, SRH_MVS_WAVES)
 void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                           int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                           const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
-                          double *__restrict__ best, double *__restrict__ upk)
+                          double *__restrict__ best, double *__restrict__ upk, const int32_t *__restrict__ nwin)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
+	// waves whose windows all fit the LDS are mvs_staged_cost_kernel's
+	if (nwin && nwin[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*(MQ_T/64) + (threadIdx.x >> 6)] >= 0) return;
 	__shared__ double s_w[T][MQ_T];                                 // per-thread columns: conflict-free
 	double a[T];
 	const ViewDev &A = views[ref];
@@ -927,9 +978,12 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 	bool inn;
 	auto request = [&](uint32_t ee) {
 		const int cx = (int)(ee & 0xffffu), cy = (int)(ee >> 16);
-		inn = all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH;
+		inn = ee == MQ_PAD || (all && cx - R >= 0 && cy - R >= 0 && cx + R < OW && cy + R < OH);   // a pad: nothing to redo
+		if (ee == MQ_PAD) ee = (uint32_t)R | ((uint32_t)R << 16);      // (any readable window)
 		typedef const __attribute__((address_space(1))) double *gptr;     // global_load, not flat_load
-		gptr bp = (gptr)(B.gray + (size_t)((inn ? cy : R) - R)*OW + ((inn ? cx : R) - R));   // not usable: any valid address
+		const int ux = (int)(ee & 0xffffu), uy = (int)(ee >> 16);
+		const bool rd = ux - R >= 0 && uy - R >= 0 && ux + R < OW && uy + R < OH;
+		gptr bp = (gptr)(B.gray + (size_t)((rd ? uy : R) - R)*OW + ((rd ? ux : R) - R));   // not usable: any valid address
 #pragma unroll
 		for (int row = 0; row < WS; ++row)
 #pragma unroll
@@ -964,7 +1018,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 			if (k + 2 < n) e2 = cl[(size_t)(k + 2)*64];
 			request(en);
 		}
-		if (c > P.peak_threshold) {                                  // multiviewstereo.cpp:589-594, 654-660
+		if (e != MQ_PAD && c > P.peak_threshold) {                   // multiviewstereo.cpp:589-594, 654-660
 			if (PEAKS) {
 				if (fast) {
 					const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
@@ -984,30 +1038,224 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 	bout[0] = bestCost; bout[1] = bestDepth;
 }
 
+// ---- the staged form of the list cost kernel ------------------------------------------------------------------
+// Same units, same lanes, same per-lane bookkeeping as mvs_list_cost_kernel; the 25-tap windows come from the wave's
+// LDS copy of the current window's box of the other view instead of 15 gathers per candidate (which kept that
+// kernel on the L1 address path at a quarter of the FP64 rate).  Weights and a_t live in registers.
+#define MS_CAP 2432                   // doubles of LDS per wave: 4 workgroups of 2 waves fill a compute unit's 160 KB
+#define MS_MAXW 96                    // windows per wave
+#ifndef MS_AHEAD
+#define MS_AHEAD 4                    // list entries in flight per lane
+#endif
+#ifndef MS_NC
+#define MS_NC 1                       // slots evaluated side by side
+#endif
+
+template <int R>
+__global__ __launch_bounds__(MQ_T, 2)
+void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
+                            int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
+                            const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
+                            double *__restrict__ best, const uint4 *__restrict__ wdesc, const int32_t *__restrict__ nwin,
+                            Counters *__restrict__ cnt)
+{
+	constexpr int WS = 2*R + 1, T = WS*WS;
+#ifdef SRH_PROFILE_PHASES
+	// diagnostic build: wave clocks of the phases, summed in cnt->dbg_phase (0 set-up, 1 copies, 2 slots, 3 end; dbg_blocks = slots)
+	unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph[4] = {0, 0, 0, 0}, ph_slots = 0;
+	const unsigned long long ph_t0 = ph_t;
+#define MS_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define MS_STAMP(i)
+#endif
+	__shared__ double s_box[MQ_T/64][MS_CAP];
+	const ViewDev &A = views[ref];
+	const ViewDev &B = views[nl.n[blockIdx.y]];
+	const int W = A.w, OW = B.w;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const size_t waveid = ((size_t)blockIdx.y*gridDim.x + blockIdx.x)*(MQ_T/64) + (tid >> 6);
+	const int nw = nwin[waveid];
+	if (nw < 0) return;                                             // mvs_list_cost_kernel's wave
+	double *const sb = s_box[tid >> 6];
+	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
+	const size_t npix = (size_t)nrows*W;
+	const size_t unit = (size_t)blockIdx.y*npix + q;
+	const int x = (int)(q % W), y = y0 + (int)(q / W);
+	const bool active = q < npix && A.mask[(size_t)y*W + x] == 1;    // (the other lanes help with the copies)
+	double *bout = best + unit*2;
+	if (nw == 0) {                                                  // no candidate anywhere in the wave
+		if (active) { bout[0] = 0.0; bout[1] = -1.0; }
+		return;
+	}
+	const int n = active ? (count[unit] < cmax ? count[unit] : cmax) : 0;
+
+	// ---- per-pixel constants: weights and a_t = w_t*gl_t - meanL
+	const double *wq = wbuf + wbuf_offset(W, T, active ? (int)(q / W) : 0, active ? x : 0);
+	double w[T], a[T];
+	bool all = active;
+	double tw = 0, s2 = 0;
+	if (active) {
+		double mL = 0;
+#pragma unroll
+		for (int row = 0; row < WS; ++row)
+#pragma unroll
+			for (int col = 0; col < WS; ++col) {
+				const int t = row*WS + col;
+				w[t] = wq[(size_t)t*wstride];
+				a[t] = mvs_tap(A, x - R + col, y - R + row);
+				all = all && a[t] == a[t] && w[t] > P.weight_cutoff;
+				mL += w[t]*a[t];
+				tw += w[t];
+			}
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+#pragma unroll
+			for (int t = 0; t < T; ++t) { a[t] = w[t]*a[t] - mL; s2 += a[t]*a[t]; }
+		} else all = false;
+	} else {
+#pragma unroll
+		for (int t = 0; t < T; ++t) { w[t] = 0.0; a[t] = 0.0; }
+	}
+
+	double bestCost = 0.0;
+	uint32_t be = 0xffffffffu;
+	bool redo = active && !all;                                     // this unit needs mvs_unit_general
+	const uint32_t *cl = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);
+	const uint4 *wd = wdesc + waveid*(size_t)MS_MAXW;
+	typedef const __attribute__((address_space(1))) double *gptr;
+
+	// list entries travel MS_AHEAD slots ahead of their use (the windows are consecutive slot ranges: one running index)
+	const int nslots = __builtin_amdgcn_readfirstlane((int)wd[nw - 1].y) < cmax ? __builtin_amdgcn_readfirstlane((int)wd[nw - 1].y) : cmax;
+	uint32_t ering[MS_AHEAD];
+#pragma unroll
+	for (int j = 0; j < MS_AHEAD; ++j) ering[j] = j < nslots && j < n ? cl[(size_t)j*64] : MQ_PAD;
+	uint4 dnext = wd[0];
+	MS_STAMP(0)
+	for (int wn = 0; wn < nw; ++wn) {
+		const uint4 d = dnext;
+		if (wn + 1 < nw) dnext = wd[wn + 1];
+		const int kb = (int)d.x, ke = (int)d.y < cmax ? (int)d.y : cmax;
+		const int X0 = (int)(d.z & 0xffffu), Y0 = (int)(d.z >> 16), X1 = (int)(d.w & 0xffffu), Y1 = (int)(d.w >> 16);
+		const int cols = X1 - X0 + 1 + 2*R, rows = Y1 - Y0 + 1 + 2*R, stride = cols | 1;
+		// ---- copy the box (with its margin of R) into the wave's LDS: element (r, c) at r*stride + c
+		{
+			const int total = rows*stride;
+			const int qs = 64 / stride, rs = 64 - qs*stride;
+			int r = lane / stride, c = lane - r*stride;
+			gptr src = (gptr)(B.gray + (size_t)(Y0 - R)*OW + (X0 - R));
+			for (int idx = lane; idx < total; idx += 64) {
+				sb[idx] = c < cols ? src[(size_t)r*OW + c] : 0.0;
+				r += qs; c += rs;
+				if (c >= stride) { c -= stride; ++r; }
+			}
+		}
+		// ---- the window's slots
+		MS_STAMP(1)
+#ifdef SRH_PROFILE_PHASES
+		ph_slots += (unsigned long long)(ke - kb);
+#endif
+		// two slots per trip: their sums are independent chains, which is what keeps the FP64 pipe busy at two waves per
+		// SIMD (a single dependent chain issues once in 12 cycles, profiles/microbench/fp64_chain_latency.hip)
+		for (int k = kb; k < ke; k += MS_NC) {
+			uint32_t e[MS_NC];
+			const double *gp[MS_NC];
+#pragma unroll
+			for (int u = 0; u < MS_NC; ++u) {
+				if (k + u < ke) {                                        // (uniform) -- the ring holds the slots in order
+					e[u] = ering[0];
+#pragma unroll
+					for (int j = 0; j + 1 < MS_AHEAD; ++j) ering[j] = ering[j + 1];
+					ering[MS_AHEAD - 1] = k + u + MS_AHEAD < nslots && k + u + MS_AHEAD < n ? cl[(size_t)(k + u + MS_AHEAD)*64] : MQ_PAD;
+				} else e[u] = MQ_PAD;
+				const int off = e[u] != MQ_PAD ? ((int)(e[u] >> 16) - Y0)*stride + ((int)(e[u] & 0xffffu) - X0) : 0;
+				gp[u] = sb + off;
+			}
+			// p_t = weight*gray of the other view (multiviewstereo.cpp:150-151, 171); meanR is their sum / totalWeight
+			double g[MS_NC][T], mR[MS_NC], s1[MS_NC], s3[MS_NC];
+#pragma unroll
+			for (int u = 0; u < MS_NC; ++u) mR[u] = 0;
+#pragma unroll
+			for (int row = 0; row < WS; ++row)
+#pragma unroll
+				for (int col = 0; col < WS; ++col)
+#pragma unroll
+					for (int u = 0; u < MS_NC; ++u) { const int t = row*WS + col; g[u][t] = w[t]*gp[u][row*stride + col]; mR[u] += g[u][t]; }
+#pragma unroll
+			for (int u = 0; u < MS_NC; ++u) { mR[u] /= tw; s1[u] = 0; s3[u] = 0; }
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int u = 0; u < MS_NC; ++u) {
+					const double b = g[u][t] - mR[u];
+					s1[u] += a[t]*b;
+					s3[u] += b*b;
+				}
+#pragma unroll
+			for (int u = 0; u < MS_NC; ++u) {
+				const double c = (s2 * s3[u] < 1e-10) ? 0.0 : s1[u] / sqrt(s2 * s3[u]);
+				if (e[u] != MQ_PAD && c > P.peak_threshold) {                // multiviewstereo.cpp:589-594, 654-660
+					if (c > bestCost) { bestCost = c; be = e[u]; }
+					else if (c == bestCost && e[u] != be) redo = true;       // exact tie of two candidates: depths decide
+				}
+			}
+		}
+		MS_STAMP(2)
+	}
+	if (active) {
+		if (redo) mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout, nullptr);
+		else {
+			double bestDepth = -1.0;                                    // no peak above the threshold
+			if (be != 0xffffffffu) {
+				const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+				bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16));
+			}
+			bout[0] = bestCost; bout[1] = bestDepth;
+		}
+	}
+#ifdef SRH_PROFILE_PHASES
+	MS_STAMP(3)
+	if (lane == 0) {
+		for (int i = 0; i < 4; ++i) atomicAdd(&cnt->dbg_phase[i], ph[i]);
+		atomicAdd(&cnt->dbg_total_cycles, ph_t - ph_t0);
+		atomicAdd(&cnt->dbg_blocks, ph_slots);
+		atomicAdd(&cnt->dbg_waves, 1ull);
+		atomicAdd(&cnt->dbg_cycles, (unsigned long long)nw);
+	}
+#endif
+}
+#undef MS_STAMP
+
+void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave) { *maxw = MS_MAXW; *desc_words_per_wave = (size_t)MS_MAXW*4; }
+
+// wdesc / nwin: window descriptors (MS_MAXW uint4 per wave) and window counts of the launch's waves, or null (no staging)
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
-                     Counters *cnt, int *max_count)
+                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
-	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count);
+	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW, MS_CAP);
 }
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                          double *unit_peaks, double *peaks)
+                          double *unit_peaks, double *peaks, const uint32_t *wdesc, const int32_t *nwin, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	const NeighList nl = make_neigh_list(neigh, nneigh);
 	if (peaks)
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, unit_peaks);
-	else
+		                   wbuf, wstride, cand, cmax, count, best, unit_peaks, (const int32_t *)nullptr);
+	else {
+		if (nwin)
+			hipLaunchKernelGGL(mvs_staged_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
+			                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt);
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr);
+		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr, nwin);
+	}
 	hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, ref, nneigh, y0, nrows, best,
 	                   unit_peaks, peaks, P.top_k);
 }
