@@ -1057,7 +1057,12 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 			                      + (peaks_dev ? (size_t)p->top_k*2*sizeof(double) : 0));
 			size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
 			if (lrows < 1) lrows = 1;
-			if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
+			{
+				// the budget is a target, not a limit: no sliver band for a few rows over it, and bands of equal height
+				const size_t rows = (size_t)(y1 - y0);
+				if (rows <= lrows + lrows/4) lrows = rows;
+				else { const size_t nb = (rows + lrows - 1)/lrows; lrows = (rows + nb - 1)/nb; }
+			}
 			const size_t units = lrows*W*(size_t)nneigh;
 			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
 			if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K

@@ -703,7 +703,8 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 	const size_t waveid = ((size_t)blockIdx.y*gridDim.x + blockIdx.x)*(MQ_T/64) + (threadIdx.x >> 6);
 	int nw = 0, wbase = 0;                                          // windows closed so far, first slot of the open one
 	bool wstaged = wdesc != nullptr;
-	int fx0 = 65535, fx1 = -1, fy0 = 65535, fy1 = -1;               // box of the candidates this lane kept in the open window
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	us2 flo = { 65535, 65535 }, fhi = { 0, 0 };                     // box of the candidates this lane kept in the open window, (x, y) packed like a list entry
 	const ViewDev &A = views[ref];
 	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w, OH = B.h;
@@ -740,9 +741,9 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 						last = e[j];
 						if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = e[j];
 						++nk; ++nreal;
-						const int ex = (int)(e[j] & 0xffffu), ey = (int)(e[j] >> 16);
-						fx0 = ex < fx0 ? ex : fx0; fx1 = ex > fx1 ? ex : fx1;
-						fy0 = ey < fy0 ? ey : fy0; fy1 = ey > fy1 ? ey : fy1;
+						const us2 ev = __builtin_bit_cast(us2, e[j]);               // v_pk_min_u16 / v_pk_max_u16: x and y at once
+						flo = __builtin_elementwise_min(flo, ev);
+						fhi = __builtin_elementwise_max(fhi, ev);
 					}
 			}
 			qn = 0;
@@ -754,12 +755,14 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 				for (; nk < top; ++nk)
 					if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = MQ_PAD;
 			if (wdesc && top > wbase) {
-				int X0 = fx0, X1 = fx1, Y0 = fy0, Y1 = fy1;
 #pragma unroll
 				for (int dd = 1; dd < 64; dd <<= 1) {
-					const int a0 = __shfl_xor(X0, dd), a1 = __shfl_xor(X1, dd), b0 = __shfl_xor(Y0, dd), b1 = __shfl_xor(Y1, dd);
-					X0 = a0 < X0 ? a0 : X0; X1 = a1 > X1 ? a1 : X1; Y0 = b0 < Y0 ? b0 : Y0; Y1 = b1 > Y1 ? b1 : Y1;
+					const us2 lo2 = __builtin_bit_cast(us2, __shfl_xor(__builtin_bit_cast(int, flo), dd));
+					const us2 hi2 = __builtin_bit_cast(us2, __shfl_xor(__builtin_bit_cast(int, fhi), dd));
+					flo = __builtin_elementwise_min(flo, lo2);
+					fhi = __builtin_elementwise_max(fhi, hi2);
 				}
+				const int X0 = flo.x, Y0 = flo.y, X1 = fhi.x, Y1 = fhi.y;
 				const int Rw = P.window_radius;
 				const int cols = X1 - X0 + 1 + 2*Rw, rows = Y1 - Y0 + 1 + 2*Rw;
 				const bool fits = X0 - Rw >= 0 && Y0 - Rw >= 0 && X1 + Rw < OW && Y1 + Rw < OH && rows*(cols | 1) <= lds_cap;
@@ -769,13 +772,15 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 					                                            (unsigned)X1 | ((unsigned)Y1 << 16));
 				++nw;
 				wbase = top;
-				fx0 = 65535; fx1 = -1; fy0 = 65535; fy1 = -1;
+				flo = us2{ 65535, 65535 }; fhi = us2{ 0, 0 };
 			}
 		};
 
 		const Vec3 camC = load3(A.cam.C);
 		const Vec3 normal = load3(A.cam.pdir);
 		const double nd = dot(normalized(normal), ray.dir);           // intersect(): n . dir, the same for every label
+		const SharedDivisor ndd = shared_divisor(nd);                 // tnum[d] / nd with the divisor's half of the division done once
+		const bool b_pinhole = !B.cam.is_refractive && !B.cam.is_distorted;
 		double x1 = __builtin_nan(""), y1 = __builtin_nan("");
 		for (int d = 0; d < P.num_depth_levels; ++d) {
 			bool seg = false;
@@ -786,13 +791,20 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 				bool hit;
 				if (tnum) {
 					// label table (pinhole_label_tnum): the operands and operations of pointFromDepth / intersect
-					const double t = tnum[d] / nd;
+					const double t = div_by(tnum[d], ndd);
 					hit = !(fabs(nd) < 1e-10) && !(t < 1e-10);
 					point = ray.src + t*ray.dir;
 				} else {
 					hit = point_from_depth(ray, normal, depth_from_label(P, true, d), point);
 				}
-				if (hit && cam_project(B.cam, point)) {
+				if (hit && b_pinhole) {
+					// cam_project of a plain pinhole camera (camera.cpp:380-419), the two quotients sharing their divisor
+					const Vec3 pl = matvec(B.cam.R, point) + load3(B.cam.t);
+					const Vec3 pk = matvec(B.cam.K, pl);
+					const SharedDivisor zd = shared_divisor(pk.z);
+					point.x = div_by(pk.x, zd); point.y = div_by(pk.y, zd);
+				} else if (hit) hit = cam_project(B.cam, point);
+				if (hit) {
 					const double x2 = point.x*P.image_scale, y2 = point.y*P.image_scale;
 					if (isnan_d(x1)) { x1 = x2; y1 = y2; }
 					else {
@@ -1120,6 +1132,8 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	double bestCost = 0.0;
 	uint32_t be = 0xffffffffu;
 	bool redo = active && !all;                                     // this unit needs mvs_unit_general
+	const SharedDivisor twd = shared_divisor(tw);
+	const double thr0 = P.peak_threshold > 0.0 ? P.peak_threshold : 0.0;
 	const uint32_t *cl = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);
 	const uint4 *wd = wdesc + waveid*(size_t)MS_MAXW;
 	typedef const __attribute__((address_space(1))) double *gptr;
@@ -1137,19 +1151,26 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 		const int kb = (int)d.x, ke = (int)d.y < cmax ? (int)d.y : cmax;
 		const int X0 = (int)(d.z & 0xffffu), Y0 = (int)(d.z >> 16), X1 = (int)(d.w & 0xffffu), Y1 = (int)(d.w >> 16);
 		const int cols = X1 - X0 + 1 + 2*R, rows = Y1 - Y0 + 1 + 2*R, stride = cols | 1;
-		// ---- copy the box (with its margin of R) into the wave's LDS: element (r, c) at r*stride + c
+		// ---- copy the box (with its margin of R) into the wave's LDS: element (r, c) at r*stride + c; four loads per
+		// lane in flight (the copy is a chain of memory round trips otherwise)
 		{
 			const int total = rows*stride;
 			const int qs = 64 / stride, rs = 64 - qs*stride;
 			int r = lane / stride, c = lane - r*stride;
 			gptr src = (gptr)(B.gray + (size_t)(Y0 - R)*OW + (X0 - R));
-			for (int idx = lane; idx < total; idx += 64) {
-				sb[idx] = c < cols ? src[(size_t)r*OW + c] : 0.0;
-				r += qs; c += rs;
-				if (c >= stride) { c -= stride; ++r; }
+			for (int idx = lane; idx < total; idx += 4*64) {
+				double v[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					v[j] = (idx + 64*j < total && c < cols) ? src[(size_t)r*OW + c] : 0.0;
+					r += qs; c += rs;
+					if (c >= stride) { c -= stride; ++r; }
+				}
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					if (idx + 64*j < total) sb[idx + 64*j] = v[j];
 			}
 		}
-		// ---- the window's slots
 		MS_STAMP(1)
 #ifdef SRH_PROFILE_PHASES
 		ph_slots += (unsigned long long)(ke - kb);
@@ -1181,7 +1202,7 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 #pragma unroll
 					for (int u = 0; u < MS_NC; ++u) { const int t = row*WS + col; g[u][t] = w[t]*gp[u][row*stride + col]; mR[u] += g[u][t]; }
 #pragma unroll
-			for (int u = 0; u < MS_NC; ++u) { mR[u] /= tw; s1[u] = 0; s3[u] = 0; }
+			for (int u = 0; u < MS_NC; ++u) { mR[u] = div_by(mR[u], twd); s1[u] = 0; s3[u] = 0; }   // mR / tw, the same bits (srh_walk.hpp)
 #pragma unroll
 			for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1192,7 +1213,20 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 				}
 #pragma unroll
 			for (int u = 0; u < MS_NC; ++u) {
-				const double c = (s2 * s3[u] < 1e-10) ? 0.0 : s1[u] / sqrt(s2 * s3[u]);
+				// A score has an effect only when it is > threshold and >= the best so far (>= 0), hence >= bound.  With
+				// sum1 >= 0:  sum1^2 < bound^2 * den * (1 - 1e-6)  puts the exact quotient below bound*(1 - 5e-7), out of reach
+				// of the roundings of the square root and the division (and of the three products here).  A negative sum1
+				// gives a negative score, without effect when the threshold is >= 0.  When no lane of the wave can be
+				// affected, the square root and the division are skipped.
+				const double den = s2 * s3[u];
+				const double bound = bestCost > thr0 ? bestCost : thr0;
+				bool hopeless;
+				if (e[u] == MQ_PAD) hopeless = true;
+				else if (!(den >= 1e-10)) hopeless = P.peak_threshold >= 0.0;        // score 0 (or NaN)
+				else if (s1[u] < 0.0) hopeless = P.peak_threshold >= 0.0;
+				else hopeless = s1[u]*s1[u] < bound*bound*den*0.999999;
+				if (__all(hopeless)) continue;
+				const double c = (den < 1e-10) ? 0.0 : s1[u] / sqrt(den);
 				if (e[u] != MQ_PAD && c > P.peak_threshold) {                // multiviewstereo.cpp:589-594, 654-660
 					if (c > bestCost) { bestCost = c; be = e[u]; }
 					else if (c == bestCost && e[u] != be) redo = true;       // exact tie of two candidates: depths decide

@@ -134,6 +134,12 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
     for bit, independently of the band split; one row of view 1 agrees with the oracle; cross-check chain runs."""
     W, H, D, NV = 640, 480, 64, 4
     cams3 = synthetic.semicircle_rig(NV, W, H, radius=10.0, step_deg=22.5, focal=float(W))
+    # view 2 rolled by 35 degrees about its optical axis: the curves of its links run obliquely through the other image,
+    # their window boxes do not fit the LDS share and those waves stay on the gathering cost kernel
+    roll = np.deg2rad(35.0)
+    Rz = np.array([[np.cos(roll), -np.sin(roll), 0.0], [np.sin(roll), np.cos(roll), 0.0], [0.0, 0.0, 1.0]])
+    K2, R2, t2 = cams3[2]
+    cams3[2] = (K2, Rz @ R2, Rz @ t2)
     rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, 0x5EED0004, sphere_radius=2.0, tex_size=512)
     cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
     kw = dict(min_depth=8.0, max_depth=12.0, num_depth_levels=D, cross_check_threshold=2 * 4.0 / (D - 1))
@@ -142,9 +148,11 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
     for v in range(NV):
         hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
     res = {}
-    for tag, generic, budget in (("two_stage", 0, 8192), ("two_stage_bands", 0, 64), ("inline", 1, 8192)):
+    for tag, generic, budget, staged in (("two_stage", 0, 8192, 1), ("two_stage_bands", 0, 64, 1), ("gathering", 0, 8192, 0),
+                                        ("inline", 1, 8192, 1)):
         hip_ctx.set_option("force_generic", generic)
         hip_ctx.set_option("band_budget_mb", budget)
+        hip_ctx.set_option("mvs_staged", staged)
         maps, evals = [], []
         for v in range(NV):
             hip_ctx.mvs_initial_estimate(v, neigh[v], p)
@@ -153,8 +161,9 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
         res[tag] = (maps, evals)
     hip_ctx.set_option("force_generic", 0)
     hip_ctx.set_option("band_budget_mb", 8192)
+    hip_ctx.set_option("mvs_staged", 1)
     for v in range(NV):
-        for tag in ("two_stage_bands", "inline"):
+        for tag in ("two_stage_bands", "gathering", "inline"):
             assert _same_bits(res["two_stage"][0][v], res[tag][0][v]), (tag, v)
             assert res["two_stage"][1][v] == res[tag][1][v], (tag, v)
         m = masks[v] == 1

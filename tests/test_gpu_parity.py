@@ -127,6 +127,12 @@ def test_mvs_initial_estimate_and_cross_check(hip_ctx, name):
         hip_ctx.set_option("force_generic", 0)
         assert np.array_equal(got.view(np.uint64), hip_ctx.download_depth(v).view(np.uint64)), "view %d: two-stage vs inline kernel" % v
         assert hip_ctx.stats()["n_eval"] == n_eval
+        # the gathering list cost kernel alone (no LDS copies of the other view's window boxes) gives the same bits
+        hip_ctx.set_option("mvs_staged", 0)
+        hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+        hip_ctx.set_option("mvs_staged", 1)
+        assert np.array_equal(got.view(np.uint64), hip_ctx.download_depth(v).view(np.uint64)), "view %d: staged vs gathering cost kernel" % v
+        assert hip_ctx.stats()["n_eval"] == n_eval
         some_peak |= bool((want[v][np.isfinite(want[v])] > 0).any())
     assert some_peak, "degenerate case: no NCC peak above threshold anywhere"
     # cross-check in view order, each view reading the already filtered earlier views
