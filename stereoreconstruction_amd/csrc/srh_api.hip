@@ -628,6 +628,13 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.used_dense_path = used_dense;
 	c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 #ifdef SRH_PROFILE_PHASES
+	{
+		unsigned long long g[5];
+		geodesic_phases_fetch(g);
+		if (g[4])
+			fprintf(stderr, "[srh prof] geodesic kernel: %llu waves, cycles per wave: staging %.0f  sweeps %.0f  exp + stores %.0f  pconst %.0f\n",
+			        g[4], (double)g[0]/g[4], (double)g[1]/g[4], (double)g[2]/g[4], (double)g[3]/g[4]);
+	}
 	if (h.dbg_waves && h.dbg_blocks && h.dbg_phase[3] && h.strip_ticket) {
 		const double nw = (double)h.dbg_waves, nt = (double)h.dbg_blocks/nw;
 		fprintf(stderr, "[srh dbg] strip: waves %llu, tiles/wave %.1f (%.1f with phase 2), cycles/wave %.0f | per tile: ticket %.0f  own requests %.0f  barriers %.0f  setup %.0f  "
@@ -1083,10 +1090,17 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 				{ Scope s(c, "mvs_walk_kernel");
 				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
 				                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr); }
+				double *const upk = peaks_dev ? c->cost + units*2 : nullptr;
+				if (staged) {
+					Scope s(c, "mvs_staged_cost_kernel");
+					launch_mvs_staged_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
+					                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt);
+				}
 				{ Scope s(c, "mvs_list_cost_kernel");
 				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-				                       c->lcand, cmax, c->lcount, c->cost, peaks_dev ? c->cost + units*2 : nullptr,
-				                       (double *)peaks_dev, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, c->d_cnt); }
+				                       c->lcand, cmax, c->lcount, c->cost, upk, peaks_dev != nullptr, staged ? c->mvs_nwin : nullptr); }
+				{ Scope s(c, "mvs_combine_kernel");
+				  launch_mvs_combine(c->stream, c->d_views, view, nneigh, W, *p, by, nr, c->cost, upk, (double *)peaks_dev); }
 			}
 			int maxc = 0;
 			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -54,9 +54,24 @@ void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, doub
 // (2R+1)^2 window lives in registers (fully unrolled sweeps).  Cells outside the
 // image keep geodesic_init because all their edges are +inf.
 #define GW_TW 64
+#define GW_ROWS 2                  // image rows per workgroup, one wave each: the waves share the staged tile (2R+GW_ROWS rows
+                                   // instead of 2R+1 per wave), which is what lets two waves per SIMD fit the LDS
+
+#ifdef SRH_PROFILE_PHASES
+// diagnostic build: wave clocks of the geodesic kernel's phases (0 staging, 1 sweeps, 2 exp + stores, 3 pconst), [4] = waves
+__device__ unsigned long long g_geo_phase[5];
+void geodesic_phases_fetch(unsigned long long out[5]) {
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_geo_phase), sizeof(unsigned long long)*5);
+	unsigned long long z[5] = {0, 0, 0, 0, 0};
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_geo_phase), z, sizeof(z));
+}
+#define GEO_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); gph[i] += now_ - gph_t; gph_t = now_; }
+#else
+#define GEO_STAMP(i)
+#endif
 
 template <int R, bool WIMG>
-__global__ __launch_bounds__(GW_TW)
+__global__ __launch_bounds__(GW_TW*GW_ROWS)
 void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const double *__restrict__ edges,
                          srh_params P, int y0, int nrows, double *__restrict__ wbuf, size_t wstride,
                          double *__restrict__ pconst)
@@ -66,58 +81,63 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 	const ViewDev &V = views[ref];
 	const int W = V.w, H = V.h;
 	const size_t n = (size_t)W*H;
+	constexpr int TH = WS + GW_ROWS - 1;       // tile height
+	constexpr int NT = GW_TW*GW_ROWS;          // threads
 	const int tiles_per_row = (W + GW_TW - 1)/GW_TW;
-	const int trow = blockIdx.x / tiles_per_row;
+	const int tgrp = blockIdx.x / tiles_per_row;                  // group of GW_ROWS rows of the band
 	const int x0 = (blockIdx.x % tiles_per_row)*GW_TW;
-	const int cy = y0 + trow;
-	if (trow >= nrows) return;
+	const int wv = threadIdx.x / GW_TW;                           // the wave = its row within the group
+	const int trow = tgrp*GW_ROWS + wv;
+	const int cy0 = y0 + tgrp*GW_ROWS;                            // first row of the group
+	const int cy = cy0 + wv;
+	const bool rowok = trow < nrows;
+#ifdef SRH_PROFILE_PHASES
+	unsigned long long gph_t = __builtin_amdgcn_s_memtime(), gph[4] = {0, 0, 0, 0};
+#endif
 
-	__shared__ double eE[WS][TWD], eS[WS][TWD], eSE[WS][TWD], eSW[WS][TWD];
-	__shared__ double gt[WS][TWD];                           // the view's TwoView tap values (NaN = unusable), for pconst
+	__shared__ double eE[TH][TWD], eS[TH][TWD], eSE[TH][TWD], eSW[TH][TWD];
+	__shared__ double gt[TH][TWD];                           // the view's TwoView tap values (NaN = unusable), for pconst
 	const double inf = __builtin_inf();
-	if (pconst) {
-		for (int idx = threadIdx.x; idx < WS*TWD; idx += GW_TW) {
-			const int ty = idx / TWD, tx = idx % TWD;
-			const int gx = x0 - R + tx, gy = cy - R + ty;
-			gt[ty][tx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? V.gray_tv[(size_t)gy*W + gx] : __builtin_nan("");
-		}
-	}
 	{
 		// all global loads of the thread first, LDS stores after: one memory latency per tile
-		constexpr int NB = (WS*TWD + GW_TW - 1)/GW_TW;
-		double t0[NB], t1[NB], t2[NB], t3[NB];
+		constexpr int NB = (TH*TWD + NT - 1)/NT;
+		double t0[NB], t1[NB], t2[NB], t3[NB], t4[NB];
 #pragma unroll
 		for (int k = 0; k < NB; ++k) {
-			const int idx = threadIdx.x + k*GW_TW;
+			const int idx = threadIdx.x + k*NT;
 			const int ty = idx / TWD, tx = idx % TWD;
-			const int gx = x0 - R + tx, gy = cy - R + ty;
-			const bool in = idx < WS*TWD && gx >= 0 && gy >= 0 && gx < W && gy < H;
+			const int gx = x0 - R + tx, gy = cy0 - R + ty;
+			const bool in = idx < TH*TWD && gx >= 0 && gy >= 0 && gx < W && gy < H;
 			const size_t gi = in ? (size_t)gy*W + gx : 0;
 			t0[k] = in ? edges[0*n + gi] : inf;
 			t1[k] = in ? edges[1*n + gi] : inf;
 			t2[k] = in ? edges[2*n + gi] : inf;
 			t3[k] = in ? edges[3*n + gi] : inf;
+			t4[k] = (pconst && in) ? V.gray_tv[gi] : __builtin_nan("");
 		}
 #pragma unroll
 		for (int k = 0; k < NB; ++k) {
-			const int idx = threadIdx.x + k*GW_TW;
-			if (idx < WS*TWD) {
+			const int idx = threadIdx.x + k*NT;
+			if (idx < TH*TWD) {
 				const int ty = idx / TWD, tx = idx % TWD;
 				eE[ty][tx] = t0[k]; eS[ty][tx] = t1[k]; eSE[ty][tx] = t2[k]; eSW[ty][tx] = t3[k];
+				gt[ty][tx] = t4[k];
 			}
 		}
 	}
 	__syncthreads();
 
-	const int i = threadIdx.x;
+	const int i = threadIdx.x % GW_TW;
 	const int cx = x0 + i;
 	// masked pixels never reach init_weights (twoviewstereo.cpp:268-272): their lanes sit out, their windows stay unwritten
-	const bool active = cx < W && V.mask[(size_t)cy*W + (cx < W ? cx : 0)] == 1;
+	// (a wave past the band's last row runs along for the barriers and stores nothing)
+	const bool active = rowok && cx < W && V.mask[(size_t)(rowok ? cy : y0)*W + (cx < W ? cx : 0)] == 1;
 	const unsigned long long amask = WIMG ? __ballot(active) : 0ull;
 	// (WIMG: every lane runs the sweeps -- the stores at the end are a joint effort of the wave -- on the staged edges,
 	// which are finite or +inf for any tile cell; only lanes of masked-in pixels store)
 	if (!WIMG && !active) return;
 
+	GEO_STAMP(0)
 	double w[WS][WS];
 #pragma unroll
 	for (int a = 0; a < WS; ++a)
@@ -140,10 +160,10 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 #pragma unroll
 			for (int xx = 0; xx < WS; ++xx) {
 				const int tx = i + xx;
-				se[xx] = (yy > 0 && xx > 0)      ? eSE[yy-1][tx-1] : inf;
-				s_[xx] = (yy > 0)                ? eS[yy-1][tx]    : inf;
-				sw[xx] = (yy > 0 && xx < WS - 1) ? eSW[yy-1][tx+1] : inf;
-				ee[xx] = (xx > 0)                ? eE[yy][tx-1]    : inf;
+				se[xx] = (yy > 0 && xx > 0)      ? eSE[wv+yy-1][tx-1] : inf;
+				s_[xx] = (yy > 0)                ? eS[wv+yy-1][tx]    : inf;
+				sw[xx] = (yy > 0 && xx < WS - 1) ? eSW[wv+yy-1][tx+1] : inf;
+				ee[xx] = (xx > 0)                ? eE[wv+yy][tx-1]    : inf;
 			}
 #pragma unroll
 			for (int xx = 0; xx < WS; ++xx) {
@@ -163,10 +183,10 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 #pragma unroll
 			for (int xx = 0; xx < WS; ++xx) {
 				const int tx = i + xx;
-				sw[xx] = (yy < WS - 1 && xx > 0)      ? eSW[yy][tx] : inf;
-				s_[xx] = (yy < WS - 1)                ? eS[yy][tx]  : inf;
-				se[xx] = (yy < WS - 1 && xx < WS - 1) ? eSE[yy][tx] : inf;
-				ee[xx] = (xx < WS - 1)                ? eE[yy][tx]  : inf;
+				sw[xx] = (yy < WS - 1 && xx > 0)      ? eSW[wv+yy][tx] : inf;
+				s_[xx] = (yy < WS - 1)                ? eS[wv+yy][tx]  : inf;
+				se[xx] = (yy < WS - 1 && xx < WS - 1) ? eSE[wv+yy][tx] : inf;
+				ee[xx] = (xx < WS - 1)                ? eE[wv+yy][tx]  : inf;
 			}
 #pragma unroll
 			for (int xx = WS - 1; xx >= 0; --xx) {
@@ -179,17 +199,18 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			}
 		}
 	}
+	GEO_STAMP(1)
 	// exponential weighting (geodesicweight.cpp:128-130)
 	if constexpr (WIMG) {
 		// the strip kernel's LDS-image layout [tile][row][pixel][WP]: the 32 pixels' taps of one window row are 3 KB of
 		// contiguous bytes.  Stored as they stand (a lane's 96 bytes, 16 at a time) every store instruction touches 64
 		// cache lines (measured: +25 % kernel time); so each window row goes through LDS -- a 6 KB staging row --
-		// and leaves as whole kilobytes.  The workgroup is one wave; the barriers only order its LDS traffic.
+		// and leaves as whole kilobytes.  Each wave has its own staging row; the barriers only order LDS traffic.
 		constexpr int WP = (WS + 1) & ~1;
-		static_assert(GW_TW == 2*SRH_WTILE, "a workgroup covers two window-buffer tiles");
-		__shared__ __align__(16) double stage_buf[GW_TW*WP];
-		double *stage = stage_buf;
-		double *wt = wbuf + wimg_offset(W, R, trow, x0);     // first of the two window-buffer tiles of this workgroup
+		static_assert(GW_TW == 2*SRH_WTILE, "a wave covers two window-buffer tiles");
+		__shared__ __align__(16) double stage_buf[GW_ROWS][GW_TW*WP];
+		double *stage = stage_buf[wv];
+		double *wt = wbuf + wimg_offset(W, R, rowok ? trow : 0, x0);   // first of the two window-buffer tiles of this wave's row
 		constexpr size_t TILE_D = (size_t)SRH_WTILE*WS*WP;   // doubles per tile
 #pragma unroll
 		for (int a = 0; a < WS; ++a) {
@@ -216,7 +237,7 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			}
 		}
 	} else {
-		double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
+		double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);         // (active lanes only: inside the band)
 #pragma unroll
 		for (int a = 0; a < WS; ++a) {
 #pragma unroll
@@ -227,6 +248,7 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			asm volatile("" ::: "memory");
 		}
 	}
+	GEO_STAMP(2)
 	if (pconst && active) {
 		// Per-pixel constants of the dense kernel's fast cost form, while the window is in registers: when every tap
 		// is usable (gray value valid, weight above the cut-off), meanL, totalWeight and sum2 of
@@ -237,7 +259,7 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		for (int a = 0; a < WS; ++a)
 #pragma unroll
 			for (int b = 0; b < WS; ++b) {
-				const double gl = gt[a][i + b];
+				const double gl = gt[wv + a][i + b];
 				if (!(gl == gl && w[a][b] > P.weight_cutoff)) all = false;
 				mL += w[a][b]*gl;
 				tw += w[a][b];
@@ -248,18 +270,26 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 #pragma unroll
 			for (int a = 0; a < WS; ++a)
 #pragma unroll
-				for (int b = 0; b < WS; ++b) { const double t = w[a][b]*gt[a][i + b] - mL; s2 += t*t; }
+				for (int b = 0; b < WS; ++b) { const double t = w[a][b]*gt[wv + a][i + b] - mL; s2 += t*t; }
 		} else all = false;
 		double *pc = pconst + ((size_t)trow*W + cx)*4;
 		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
 	}
+#ifdef SRH_PROFILE_PHASES
+	GEO_STAMP(3)
+	if (i == 0 && rowok) {
+		for (int k = 0; k < 4; ++k) atomicAdd(&g_geo_phase[k], gph[k]);
+		atomicAdd(&g_geo_phase[4], 1ull);
+	}
+#endif
 }
+#undef GEO_STAMP
 
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst, bool wimg)
 {
 	const int tiles = (width + GW_TW - 1)/GW_TW;
-	const dim3 grid((unsigned)(tiles*nrows)), block(GW_TW);
+	const dim3 grid((unsigned)(tiles*((nrows + GW_ROWS - 1)/GW_ROWS))), block(GW_TW*GW_ROWS);
 	const int wi = wimg ? 1 : 0;
 	switch (P.window_radius) {
 	case 5:

@@ -145,6 +145,9 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const uint8_t *oth_fullp, double *cost, int cstride, Counters *cnt, int arith, int num_cus,
                                int lanes);
 
+#ifdef SRH_PROFILE_PHASES
+void geodesic_phases_fetch(unsigned long long out[5]);
+#endif
 #ifdef SRH_EXPERIMENT
 void exp_set(int repeat, int lds_pad);
 void exp_set_scan(int mode);
@@ -174,10 +177,16 @@ void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave);
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
                      Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin);
+void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
+                            const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
+                            const uint32_t *cand, int cmax, const int32_t *count, double *best,
+                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt);
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                          double *unit_peaks, double *peaks, const uint32_t *wdesc, const int32_t *nwin, Counters *cnt);
+                          double *unit_peaks, bool peaks, const int32_t *nwin);
+void launch_mvs_combine(hipStream_t st, const ViewDev *views, int ref, int nneigh, int width, const srh_params &P,
+                        int y0, int nrows, const double *best, const double *unit_peaks, double *peaks);
 void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, int h, const srh_params &P,
                         double *xyz, uint8_t *rgb, uint8_t *valid, unsigned long long *counts);
 // MRF stage (srh_mrf.hip): one scratch buffer, carved the same way by every launch

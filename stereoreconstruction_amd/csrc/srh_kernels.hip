@@ -1272,10 +1272,22 @@ void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_
 	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW, MS_CAP);
 }
 
+// the three steps of the list path's second stage; nwin (or null): the waves with nwin >= 0 are the staged kernel's
+void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
+                            const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
+                            const uint32_t *cand, int cmax, const int32_t *count, double *best,
+                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt)
+{
+	const size_t n = (size_t)nrows*width;
+	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
+	hipLaunchKernelGGL(mvs_staged_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh), P, y0, nrows,
+	                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt);
+}
+
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                          double *unit_peaks, double *peaks, const uint32_t *wdesc, const int32_t *nwin, Counters *cnt)
+                          double *unit_peaks, bool peaks, const int32_t *nwin)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
@@ -1283,13 +1295,15 @@ void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const i
 	if (peaks)
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
 		                   wbuf, wstride, cand, cmax, count, best, unit_peaks, (const int32_t *)nullptr);
-	else {
-		if (nwin)
-			hipLaunchKernelGGL(mvs_staged_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-			                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt);
+	else
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
 		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr, nwin);
-	}
+}
+
+void launch_mvs_combine(hipStream_t st, const ViewDev *views, int ref, int nneigh, int width, const srh_params &P,
+                        int y0, int nrows, const double *best, const double *unit_peaks, double *peaks)
+{
+	const size_t n = (size_t)nrows*width;
 	hipLaunchKernelGGL(mvs_combine_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, views, ref, nneigh, y0, nrows, best,
 	                   unit_peaks, peaks, P.top_k);
 }
