@@ -51,6 +51,11 @@ struct ViewHost {
 	// how the candidate lists of this view against slot j are best evaluated, learnt from the last run:
 	// 0 unknown, 1 row runs (srh_rows.hip), 2 list order (srh_list.hip: steep curves)
 	uint8_t   list_mode[SRH_MAX_VIEWS] = {0};
+	// MultiViewStereo list path: the masked-in pixels (y*w + x) row by row, even rows left to right, odd rows right to
+	// left, so that consecutive entries are neighbours in the image also across a row change; act_row[y] = first entry of
+	// row y (h + 1 values).  A wave of the walk / cost kernels takes 64 consecutive entries.
+	uint32_t *act = nullptr;
+	std::vector<uint32_t> act_row;
 	srh_camera cam;
 	// MRF branch over several views (srh_mvs_initial_estimate_peaks / srh_mvs_mrf_estimate_views)
 	double   *peaks = nullptr; size_t peaks_cap = 0; int peaks_k = 0;   // top-K peaks of the last initial estimate
@@ -431,6 +436,7 @@ static void free_view(ViewHost &v) {
 	if (v.fullp) hipFree(v.fullp);
 	if (v.peaks) hipFree(v.peaks);
 	if (v.mrf) hipFree(v.mrf);
+	if (v.act) hipFree(v.act);
 	v = ViewHost();
 }
 
@@ -542,6 +548,24 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	HIP_TRY(hipMemcpyAsync(v.rgba, rgba, n*4, hipMemcpyHostToDevice, c->stream));
 	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
 	else      HIP_TRY(hipMemsetAsync(v.mask, 1, n, c->stream));
+	{
+		// serpentine list of the masked-in pixels (mask.pixel == WHITE <=> byte 1; no mask: every pixel)
+		std::vector<uint32_t> act;
+		act.reserve(n);
+		v.act_row.assign((size_t)h + 1, 0u);
+		for (int y = 0; y < h; ++y) {
+			v.act_row[y] = (uint32_t)act.size();
+			const uint8_t *mr = mask ? mask + (size_t)y*w : nullptr;
+			if (!(y & 1)) { for (int x = 0; x < w; ++x) if (!mr || mr[x] == 1) act.push_back((uint32_t)((size_t)y*w + x)); }
+			else          { for (int x = w - 1; x >= 0; --x) if (!mr || mr[x] == 1) act.push_back((uint32_t)((size_t)y*w + x)); }
+		}
+		v.act_row[h] = (uint32_t)act.size();
+		if (v.act) { HIP_TRY(hipFree(v.act)); v.act = nullptr; }
+		if (!act.empty()) {
+			HIP_TRY(hipMalloc((void **)&v.act, act.size()*sizeof(uint32_t)));
+			HIP_TRY(hipMemcpy(v.act, act.data(), act.size()*sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
+	}
 	{ Scope s(c, "prep_view_kernel"); launch_prep_view(c->stream, v.rgba, v.mask, w, h, v.gray, v.gray_tv); }
 	{ Scope s(c, "edge_planes_kernel"); launch_edge_planes(c->stream, v.rgba, w, h, v.edges); }
 	launch_fill(c->stream, v.depth, n, __builtin_nan(""));
@@ -1071,34 +1095,43 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 				else { const size_t nb = (rows + lrows - 1)/lrows; lrows = (rows + nb - 1)/nb; }
 			}
 			const size_t units = lrows*W*(size_t)nneigh;
+			// the list kernels' units: the masked-in pixels of a band, padded to whole 128-pixel blocks per link
+			size_t lunits = 0;
+			for (int by = y0; by < y1; by += (int)lrows) {
+				const int nr = std::min((int)lrows, y1 - by);
+				const size_t na = (size_t)A.act_row[by + nr] - A.act_row[by];
+				lunits = std::max(lunits, ((na + 127) & ~(size_t)127)*(size_t)nneigh);
+			}
 			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
-			if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K
-			if ((rc = ensure(c->lcand, c->lcand_cap, ((units + 63) & ~(size_t)63)*(size_t)cmax))) return rc;   // wave-tiled lists
-			if ((rc = ensure(c->lcount, c->lcount_cap, units))) return rc;
+			if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K, by pixel
+			if ((rc = ensure(c->lcand, c->lcand_cap, std::max<size_t>(lunits, 128)*(size_t)cmax))) return rc;   // wave-tiled lists
+			if ((rc = ensure(c->lcount, c->lcount_cap, std::max<size_t>(lunits, 128)))) return rc;
 			const bool staged = c->mvs_staged && !peaks_dev;
 			if (staged) {
 				int maxw; size_t words;
 				mvs_staging_shape(&maxw, &words);
-				const size_t waves = ((lrows*W + 127)/128)*2*(size_t)nneigh;
+				const size_t waves = std::max<size_t>(lunits, 128)/64;
 				if ((rc = ensure(c->mvs_wdesc, c->mvs_wdesc_cap, waves*words))) return rc;
 				if ((rc = ensure(c->mvs_nwin, c->mvs_nwin_cap, waves))) return rc;
 			}
 			for (int by = y0; by < y1; by += (int)lrows) {
 				if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 				const int nr = std::min((int)lrows, y1 - by);
+				const uint32_t *act = A.act ? A.act + A.act_row[by] : nullptr;
+				const int nact = (int)(A.act_row[by + nr] - A.act_row[by]);
 				run_weights(c, view, W, *p, by, nr, wstride);
 				{ Scope s(c, "mvs_walk_kernel");
 				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
-				                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr); }
+				                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
 				double *const upk = peaks_dev ? c->cost + units*2 : nullptr;
 				if (staged) {
 					Scope s(c, "mvs_staged_cost_kernel");
 					launch_mvs_staged_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-					                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt);
+					                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact);
 				}
 				{ Scope s(c, "mvs_list_cost_kernel");
 				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-				                       c->lcand, cmax, c->lcount, c->cost, upk, peaks_dev != nullptr, staged ? c->mvs_nwin : nullptr); }
+				                       c->lcand, cmax, c->lcount, c->cost, upk, peaks_dev != nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
 				{ Scope s(c, "mvs_combine_kernel");
 				  launch_mvs_combine(c->stream, c->d_views, view, nneigh, W, *p, by, nr, c->cost, upk, (double *)peaks_dev); }
 			}

@@ -171,20 +171,22 @@ bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int
                               const int32_t *count, const uint32_t *cand, double *cost, int cmax, Counters *cnt);
 void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, const double *cost, int cmax);
+// act / nact: the band's masked-in pixels (y*w + x) in the view's serpentine order -- the units of the launch, 128 per
+// block and link, so that every wave is full and its 64 pixels lie side by side (also across a row change).
 // wdesc / nwin (or null): per wave of the walk launch (2 per 128-pixel block and link), the windows of list slots whose
 // box of the other view fits the LDS (mvs_staged_cost_kernel); mvs_staging_shape gives the buffer sizes
 void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave);
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
-                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin);
+                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact);
 void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                             const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                             const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt);
+                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt, const uint32_t *act, int nact);
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                          double *unit_peaks, bool peaks, const int32_t *nwin);
+                          double *unit_peaks, bool peaks, const int32_t *nwin, const uint32_t *act, int nact);
 void launch_mvs_combine(hipStream_t st, const ViewDev *views, int ref, int nneigh, int width, const srh_params &P,
                         int y0, int nrows, const double *best, const double *unit_peaks, double *peaks);
 void launch_point_cloud(hipStream_t st, const ViewDev *views, int slot, int w, int h, const srh_params &P,

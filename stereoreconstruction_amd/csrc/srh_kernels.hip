@@ -696,7 +696,8 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
                      int y0, int nrows, const double *__restrict__ tnum, uint32_t *__restrict__ cand, int cmax,
                      int32_t *__restrict__ count,
                      Counters *__restrict__ cnt, int *__restrict__ max_count,
-                     uint4 *__restrict__ wdesc, int32_t *__restrict__ nwin, int maxw, int lds_cap)
+                     uint4 *__restrict__ wdesc, int32_t *__restrict__ nwin, int maxw, int lds_cap,
+                     const uint32_t *__restrict__ act, int nact)
 {
 	__shared__ uint32_t s_q[MQ_QN][MQ_T];
 	__shared__ int s_max;
@@ -709,11 +710,12 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w, OH = B.h;
 	const int tid = threadIdx.x;
-	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
-	const size_t npix = (size_t)nrows*W;
-	const size_t unit = (size_t)blockIdx.y*npix + q;
-	const int x = (int)(q % W), y = y0 + (int)(q / W);
-	const bool active = q < npix && A.mask[(size_t)y*W + x] == 1;
+	// the units of a launch: the band's masked-in pixels in the view's serpentine order (ViewHost::act), 128 per block
+	const size_t j = (size_t)blockIdx.x*MQ_T + tid;
+	const bool active = j < (size_t)nact;
+	const uint32_t pix = active ? act[j] : 0u;
+	const int x = (int)(pix % (uint32_t)W), y = (int)(pix / (uint32_t)W);
+	const size_t unit = (size_t)blockIdx.y*((size_t)gridDim.x*MQ_T) + j;     // list and count index
 	int nk = 0;                                                     // list slots written so far (candidates and pads)
 	int nreal = 0;                                                  // candidates kept so far
 	if (tid == 0) s_max = 0;
@@ -834,7 +836,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		}
 		flush();
 	}
-	if (q < npix) count[unit] = nk;
+	count[unit] = nk;
 	if (nwin && (tid & 63) == 0) nwin[waveid] = wstaged ? nw : -1;
 	__syncthreads();
 	if (nk) atomicMax(&s_max, nk);
@@ -928,7 +930,8 @@ __global__ __launch_bounds__(MQ_T, SRH_MVS_WAVES)
 void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                           int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                           const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
-                          double *__restrict__ best, double *__restrict__ upk, const int32_t *__restrict__ nwin)
+                          double *__restrict__ best, double *__restrict__ upk, const int32_t *__restrict__ nwin,
+                          const uint32_t *__restrict__ act, int nact)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
 	// waves whose windows all fit the LDS are mvs_staged_cost_kernel's
@@ -939,16 +942,18 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w, OH = B.h;
 	const int tid = threadIdx.x;
-	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
+	const size_t j = (size_t)blockIdx.x*MQ_T + tid;                 // the walk kernel's unit order
+	if (j >= (size_t)nact) return;
+	const uint32_t pix = act[j];
+	const int x = (int)(pix % (uint32_t)W), y = (int)(pix / (uint32_t)W);
 	const size_t npix = (size_t)nrows*W;
+	const size_t q = (size_t)(y - y0)*W + x;                        // pixel of the band: results are stored by pixel
 	const size_t unit = (size_t)blockIdx.y*npix + q;
-	if (q >= npix) return;
-	const int x = (int)(q % W), y = y0 + (int)(q / W);
-	if (A.mask[(size_t)y*W + x] != 1) return;                      // mvs_combine_kernel does not read masked pixels
+	const size_t ul = (size_t)blockIdx.y*((size_t)gridDim.x*MQ_T) + j;
 	double *bout = best + unit*2;
 	double *pk = PEAKS ? upk + unit*(size_t)P.top_k*2 : nullptr;
 	if (PEAKS) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }
-	const int n = count[unit] < cmax ? count[unit] : cmax;
+	const int n = count[ul] < cmax ? count[ul] : cmax;
 	if (n <= 0) { bout[0] = 0.0; bout[1] = -1.0; return; }
 
 	// ---- per-pixel constants: weights and a_t = w_t*gl_t - meanL in this thread's LDS column
@@ -980,7 +985,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 	double bestCost = 0.0;
 	uint32_t be = 0xffffffffu;
 	bool redo = !all;                                               // this unit needs mvs_unit_general
-	const uint32_t *cl = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);
+	const uint32_t *cl = cand + (ul >> 6)*(size_t)cmax*64 + (ul & 63);
 
 	// one candidate per iteration: its 25-tap window arrives in g[], is turned in place into p_t = w_t*g_t
 	// (the products both sweeps need), and the next candidate's window is requested as soon as the second
@@ -1069,7 +1074,7 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
                             int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                             const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
                             double *__restrict__ best, const uint4 *__restrict__ wdesc, const int32_t *__restrict__ nwin,
-                            Counters *__restrict__ cnt)
+                            Counters *__restrict__ cnt, const uint32_t *__restrict__ act, int nact)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
 #ifdef SRH_PROFILE_PHASES
@@ -1089,17 +1094,20 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	const int nw = nwin[waveid];
 	if (nw < 0) return;                                             // mvs_list_cost_kernel's wave
 	double *const sb = s_box[tid >> 6];
-	const size_t q = (size_t)blockIdx.x*MQ_T + tid;
+	const size_t j = (size_t)blockIdx.x*MQ_T + tid;                 // the walk kernel's unit order
+	const bool active = j < (size_t)nact;                           // (the other lanes help with the copies)
+	const uint32_t pix = active ? act[j] : 0u;
+	const int x = (int)(pix % (uint32_t)W), y = active ? (int)(pix / (uint32_t)W) : y0;
 	const size_t npix = (size_t)nrows*W;
+	const size_t q = (size_t)(y - y0)*W + x;                        // pixel of the band: results are stored by pixel
 	const size_t unit = (size_t)blockIdx.y*npix + q;
-	const int x = (int)(q % W), y = y0 + (int)(q / W);
-	const bool active = q < npix && A.mask[(size_t)y*W + x] == 1;    // (the other lanes help with the copies)
+	const size_t ul = (size_t)blockIdx.y*((size_t)gridDim.x*MQ_T) + j;
 	double *bout = best + unit*2;
 	if (nw == 0) {                                                  // no candidate anywhere in the wave
 		if (active) { bout[0] = 0.0; bout[1] = -1.0; }
 		return;
 	}
-	const int n = active ? (count[unit] < cmax ? count[unit] : cmax) : 0;
+	const int n = active ? (count[ul] < cmax ? count[ul] : cmax) : 0;
 
 	// ---- per-pixel constants: weights and a_t = w_t*gl_t - meanL
 	const double *wq = wbuf + wbuf_offset(W, T, active ? (int)(q / W) : 0, active ? x : 0);
@@ -1134,7 +1142,7 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	bool redo = active && !all;                                     // this unit needs mvs_unit_general
 	const SharedDivisor twd = shared_divisor(tw);
 	const double thr0 = P.peak_threshold > 0.0 ? P.peak_threshold : 0.0;
-	const uint32_t *cl = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);
+	const uint32_t *cl = cand + (ul >> 6)*(size_t)cmax*64 + (ul & 63);
 	const uint4 *wd = wdesc + waveid*(size_t)MS_MAXW;
 	typedef const __attribute__((address_space(1))) double *gptr;
 
@@ -1264,40 +1272,40 @@ void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave) { *maxw = MS_MAXW
 // wdesc / nwin: window descriptors (MS_MAXW uint4 per wave) and window counts of the launch's waves, or null (no staging)
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
-                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin)
+                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact)
 {
-	const size_t n = (size_t)nrows*width;
-	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
+	if (nact <= 0) return;
+	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
-	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW, MS_CAP);
+	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW, MS_CAP, act, nact);
 }
 
 // the three steps of the list path's second stage; nwin (or null): the waves with nwin >= 0 are the staged kernel's
 void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                             const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                             const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt)
+                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt, const uint32_t *act, int nact)
 {
-	const size_t n = (size_t)nrows*width;
-	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
+	if (nact <= 0) return;
+	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	hipLaunchKernelGGL(mvs_staged_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh), P, y0, nrows,
-	                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt);
+	                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact);
 }
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                          double *unit_peaks, bool peaks, const int32_t *nwin)
+                          double *unit_peaks, bool peaks, const int32_t *nwin, const uint32_t *act, int nact)
 {
-	const size_t n = (size_t)nrows*width;
-	const dim3 grid((unsigned)((n + MQ_T - 1)/MQ_T), (unsigned)nneigh);
+	if (nact <= 0) return;
+	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	const NeighList nl = make_neigh_list(neigh, nneigh);
 	if (peaks)
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, unit_peaks, (const int32_t *)nullptr);
+		                   wbuf, wstride, cand, cmax, count, best, unit_peaks, (const int32_t *)nullptr, act, nact);
 	else
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr, nwin);
+		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr, nwin, act, nact);
 }
 
 void launch_mvs_combine(hipStream_t st, const ViewDev *views, int ref, int nneigh, int width, const srh_params &P,
