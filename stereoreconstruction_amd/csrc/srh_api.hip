@@ -65,6 +65,26 @@ struct ViewHost {
 struct ProfEntry { double ms = 0; int64_t n = 0; };
 struct PendingEvt { std::string name; hipEvent_t a, b; };
 
+// one MultiViewStereo estimate in flight (srh_mvs_initial_estimate, "two estimates in flight")
+struct MvsSlot {
+	hipStream_t stream = nullptr;
+	hipEvent_t ev = nullptr;
+	int *h_maxc = nullptr;                              // pinned: longest list of the queued pass
+	bool own_buffers = false;                           // slot 1: its own band buffers, swapped into the context for its launches
+	double *wbuf = nullptr; size_t wbuf_cap = 0;
+	double *cost = nullptr; size_t cost_cap = 0;
+	double *tnum = nullptr; size_t tnum_cap = 0;
+	int32_t *lcount = nullptr; size_t lcount_cap = 0;
+	uint32_t *lcand = nullptr; size_t lcand_cap = 0;
+	uint32_t *mvs_wdesc = nullptr; size_t mvs_wdesc_cap = 0;
+	int32_t *mvs_nwin = nullptr; size_t mvs_nwin_cap = 0;
+	Counters *d_cnt = nullptr; int *d_span = nullptr;
+	bool pending = false;                               // kernels queued, capacity check outstanding
+	int view = -1, nneigh = 0, y0 = 0, y1 = 0, cmax = 0;
+	int32_t neigh[SRH_MAX_NEIGH] = {0};
+	srh_params p;
+};
+
 struct srh_context {
 	int device = 0;
 	hipStream_t own_stream = nullptr;
@@ -92,6 +112,10 @@ struct srh_context {
 	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
 	int list_smax_hint = 0;                             // most cost slots a pixel needed so far (run-blocked lists)
 	int mvs_cmax_hint = 0;                              // longest MultiViewStereo candidate list seen so far
+	int mvs_async = 1;                                  // option "mvs_async": srh_mvs_initial_estimate queues a view on one of two side streams and returns (default); 0 = waits for each view
+	MvsSlot mvs_slot[2];
+	int mvs_turn = 0, mvs_last = -1;
+	bool in_settle = false;
 	int mvs_staged = 1;                                 // option "mvs_staged": the list cost kernel takes its windows from LDS copies of the other view where they fit (default), 0 = gathers only
 	uint32_t *mvs_wdesc = nullptr; size_t mvs_wdesc_cap = 0;   // window descriptors of the walk kernel's waves
 	int32_t *mvs_nwin = nullptr; size_t mvs_nwin_cap = 0;
@@ -158,8 +182,11 @@ static int ensure(T *&ptr, size_t &cap, size_t need) {
 	return SRH_OK;
 }
 
-static int check_slot(srh_context *c, int slot, bool must_exist) {
+static int mvs_settle_all(srh_context *c);
+// settle: finish the MultiViewStereo estimates in flight first (every entry point but srh_mvs_initial_estimate itself)
+static int check_slot(srh_context *c, int slot, bool must_exist, bool settle = true) {
 	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (settle) { const int rc = mvs_settle_all(c); if (rc) return rc; }
 	if (slot < 0 || slot >= SRH_MAX_VIEWS) return fail(SRH_E_INVALID, "view slot %d out of range [0,%d)", slot, SRH_MAX_VIEWS);
 	if (must_exist && !c->views[slot].present) return fail(SRH_E_INVALID, "view slot %d has no image", slot);
 	return SRH_OK;
@@ -402,6 +429,7 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
 	if (const char *s = getenv("SRH_STRIP")) c->strip = atoi(s);
 	if (const char *s = getenv("SRH_MVS_STAGED")) c->mvs_staged = atoi(s) != 0;
+	if (const char *s = getenv("SRH_MVS_ASYNC")) c->mvs_async = atoi(s) != 0;
 	{ int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
 	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
 	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
@@ -444,7 +472,25 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (!c) return;
 	hipSetDevice(c->device);
 	if (c->own_stream) hipStreamSynchronize(c->own_stream);
+	for (MvsSlot &S : c->mvs_slot) {
+		if (S.stream) { hipStreamSynchronize(S.stream); }
+		S.pending = false;
+	}
 	drain_profile(c);
+	for (MvsSlot &S : c->mvs_slot) {
+		if (S.stream) hipStreamDestroy(S.stream);
+		if (S.ev) hipEventDestroy(S.ev);
+		if (S.h_maxc) hipHostFree(S.h_maxc);
+		if (S.wbuf) hipFree(S.wbuf);
+		if (S.cost) hipFree(S.cost);
+		if (S.tnum) hipFree(S.tnum);
+		if (S.lcount) hipFree(S.lcount);
+		if (S.lcand) hipFree(S.lcand);
+		if (S.mvs_wdesc) hipFree(S.mvs_wdesc);
+		if (S.mvs_nwin) hipFree(S.mvs_nwin);
+		if (S.d_cnt) hipFree(S.d_cnt);
+		if (S.d_span) hipFree(S.d_span);
+	}
 	for (auto &v : c->views) free_view(v);
 	if (c->d_views) hipFree(c->d_views);
 	if (c->d_slots) hipFree(c->d_slots);
@@ -472,6 +518,7 @@ extern "C" void srh_destroy(srh_context *c) {
 
 extern "C" int srh_set_stream(srh_context *c, void *hip_stream) {
 	if (!c) return fail(SRH_E_INVALID, "null context");
+	{ const int rc = mvs_settle_all(c); if (rc) return rc; }
 	c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
 	return SRH_OK;
 }
@@ -497,6 +544,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		c->strip = (int)value; return SRH_OK;
 	}
 	if (!strcmp(name, "mvs_staged")) { c->mvs_staged = value != 0; return SRH_OK; }
+	if (!strcmp(name, "mvs_async")) { const int rc = mvs_settle_all(c); if (rc) return rc; c->mvs_async = value != 0; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
@@ -513,6 +561,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 extern "C" int srh_synchronize(srh_context *c) {
 	if (!c) return fail(SRH_E_INVALID, "null context");
 	HIP_TRY(hipSetDevice(c->device));
+	{ const int rc = mvs_settle_all(c); if (rc) return rc; }
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return SRH_OK;
 }
@@ -1046,16 +1095,156 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 }
 
 extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t *neigh, int nneigh,
+                                        const srh_params *p, int y0, int y1, void *peaks_dev);
+
+// One pass of the list path of srh_mvs_initial_estimate for list capacity cmax: everything is queued on c->stream with
+// c's band buffers, nothing is waited for.  d_span[0] receives the longest list (slots), for the caller to compare with cmax.
+static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int nneigh, const srh_params *p, int y0, int y1,
+                           void *peaks_dev, int cmax)
+{
+	int rc;
+	const ViewHost &A = c->views[view];
+	const int W = A.w;
+	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
+	const size_t wstride = SRH_WTILE;
+	// without a refractive interface every ray of the view starts at the camera centre: the per-label
+	// part of pointFromDepth is tabulated once (same operands and operations, see srh_walk.hpp)
+	const bool table = !A.cam.is_refractive;
+	if (table) {
+		if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
+		Scope s(c, "pinhole_label_table_kernel");
+		launch_pinhole_label_table(c->stream, c->d_views, view, *p, true, c->tnum);
+	}
+		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
+		HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
+		const size_t per_px = (size_t)T*sizeof(double) + (size_t)nneigh*((size_t)cmax*sizeof(uint32_t) + sizeof(int32_t) + 2*sizeof(double)
+		                      + (peaks_dev ? (size_t)p->top_k*2*sizeof(double) : 0));
+		size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
+		if (lrows < 1) lrows = 1;
+		{
+			// the budget is a target, not a limit: no sliver band for a few rows over it, and bands of equal height
+			const size_t rows = (size_t)(y1 - y0);
+			if (rows <= lrows + lrows/4) lrows = rows;
+			else { const size_t nb = (rows + lrows - 1)/lrows; lrows = (rows + nb - 1)/nb; }
+		}
+		const size_t units = lrows*W*(size_t)nneigh;
+		// the list kernels' units: the masked-in pixels of a band, padded to whole 128-pixel blocks per link
+		size_t lunits = 0;
+		for (int by = y0; by < y1; by += (int)lrows) {
+			const int nr = std::min((int)lrows, y1 - by);
+			const size_t na = (size_t)A.act_row[by + nr] - A.act_row[by];
+			lunits = std::max(lunits, ((na + 127) & ~(size_t)127)*(size_t)nneigh);
+		}
+		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
+		if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K, by pixel
+		if ((rc = ensure(c->lcand, c->lcand_cap, std::max<size_t>(lunits, 128)*(size_t)cmax))) return rc;   // wave-tiled lists
+		if ((rc = ensure(c->lcount, c->lcount_cap, std::max<size_t>(lunits, 128)))) return rc;
+		const bool staged = c->mvs_staged && !peaks_dev;
+		if (staged) {
+			int maxw; size_t words;
+			mvs_staging_shape(&maxw, &words);
+			const size_t waves = std::max<size_t>(lunits, 128)/64;
+			if ((rc = ensure(c->mvs_wdesc, c->mvs_wdesc_cap, waves*words))) return rc;
+			if ((rc = ensure(c->mvs_nwin, c->mvs_nwin_cap, waves))) return rc;
+		}
+		for (int by = y0; by < y1; by += (int)lrows) {
+			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+			const int nr = std::min((int)lrows, y1 - by);
+			const uint32_t *act = A.act ? A.act + A.act_row[by] : nullptr;
+			const int nact = (int)(A.act_row[by + nr] - A.act_row[by]);
+			run_weights(c, view, W, *p, by, nr, wstride);
+			{ Scope s(c, "mvs_walk_kernel");
+			  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
+			                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
+			double *const upk = peaks_dev ? c->cost + units*2 : nullptr;
+			if (staged) {
+				Scope s(c, "mvs_staged_cost_kernel");
+				launch_mvs_staged_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
+				                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact);
+			}
+			{ Scope s(c, "mvs_list_cost_kernel");
+			  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
+			                       c->lcand, cmax, c->lcount, c->cost, upk, peaks_dev != nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
+			{ Scope s(c, "mvs_combine_kernel");
+			  launch_mvs_combine(c->stream, c->d_views, view, nneigh, W, *p, by, nr, c->cost, upk, (double *)peaks_dev); }
+		}
+	HIP_TRY(hipGetLastError());
+	return SRH_OK;
+}
+
+#ifdef SRH_PROFILE_PHASES
+static void mvs_print_phases(srh_context *c) {
+	Counters h;
+	if (hipMemcpy(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+	if (h.dbg_waves)
+		fprintf(stderr, "[srh prof] staged MVS cost: %llu waves, %.1f windows and %.1f slots per wave; cycles per wave: life %.0f = "
+		        "set-up %.0f + copies %.0f + slots %.0f (%.0f per slot) + end %.0f\n", h.dbg_waves, (double)h.dbg_cycles/h.dbg_waves,
+		        (double)h.dbg_blocks/h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_phase[0]/h.dbg_waves,
+		        (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
+		        h.dbg_blocks ? (double)h.dbg_phase[2]/h.dbg_blocks : 0.0, (double)h.dbg_phase[3]/h.dbg_waves);
+}
+#endif
+
+// ---- two estimates in flight ------------------------------------------------------------------------------------
+// The kernels of one view end in tails (the last, longest waves of the walk and cost kernels) and the call used to end
+// in a host synchronisation for the list-capacity check.  The default list path now only QUEUES a view's kernels, on
+// one of two side streams in turn (slot 1 with its own band buffers), so that the next view's kernels fill the
+// tails of this one's; the capacity check is made when the slot is used again or when any other entry point touches
+// the context (check_slot), and a view whose lists were cut is then redone.  Results are complete whenever a caller
+// can observe them.
+static void mvs_slot_swap(srh_context *c, MvsSlot &S) {
+	std::swap(c->stream, S.stream);
+	if (!S.own_buffers) return;
+	std::swap(c->wbuf, S.wbuf); std::swap(c->wbuf_cap, S.wbuf_cap);
+	std::swap(c->cost, S.cost); std::swap(c->cost_cap, S.cost_cap);
+	std::swap(c->tnum, S.tnum); std::swap(c->tnum_cap, S.tnum_cap);
+	std::swap(c->lcount, S.lcount); std::swap(c->lcount_cap, S.lcount_cap);
+	std::swap(c->lcand, S.lcand); std::swap(c->lcand_cap, S.lcand_cap);
+	std::swap(c->mvs_wdesc, S.mvs_wdesc); std::swap(c->mvs_wdesc_cap, S.mvs_wdesc_cap);
+	std::swap(c->mvs_nwin, S.mvs_nwin); std::swap(c->mvs_nwin_cap, S.mvs_nwin_cap);
+	std::swap(c->d_cnt, S.d_cnt); std::swap(c->d_span, S.d_span);
+}
+
+static int mvs_settle_slot(srh_context *c, int k) {
+	MvsSlot &S = c->mvs_slot[k];
+	if (!S.pending) return SRH_OK;
+	HIP_TRY(hipStreamSynchronize(S.stream));
+	S.pending = false;
+	if (k == c->mvs_last && S.own_buffers)                       // srh_get_stats reads the context's counters
+		HIP_TRY(hipMemcpy(c->d_cnt, S.d_cnt, sizeof(Counters), hipMemcpyDeviceToDevice));
+#ifdef SRH_PROFILE_PHASES
+	mvs_slot_swap(c, S); mvs_print_phases(c); mvs_slot_swap(c, S);
+#endif
+	const int maxc = *S.h_maxc;
+	if (maxc <= S.cmax) { if (S.cmax > c->mvs_cmax_hint) c->mvs_cmax_hint = S.cmax; return SRH_OK; }
+	// a list was cut: redo the view, waiting for it, with the true maximum as the capacity (on the context's own
+	// buffers, which slot 0 shares: nothing may be in flight)
+	for (MvsSlot &O : c->mvs_slot) if (O.stream) HIP_TRY(hipStreamSynchronize(O.stream));
+	c->mvs_cmax_hint = std::max(c->mvs_cmax_hint, (maxc + 7) & ~7);
+	c->in_settle = true;
+	const int rc = srh_mvs_initial_estimate(c, S.view, S.neigh, S.nneigh, &S.p, S.y0, S.y1, nullptr);
+	c->in_settle = false;
+	return rc;
+}
+
+static int mvs_settle_all(srh_context *c) {
+	if (c->in_settle) return SRH_OK;
+	int rc;
+	for (int k = 0; k < 2; ++k) if ((rc = mvs_settle_slot(c, k))) return rc;
+	return SRH_OK;
+}
+
+extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t *neigh, int nneigh,
                                         const srh_params *p, int y0, int y1, void *peaks_dev)
 {
 	int rc;
-	if ((rc = check_slot(c, view, true)) || (rc = check_params(p))) return rc;
+	if ((rc = check_slot(c, view, true, false)) || (rc = check_params(p))) return rc;
 	if (nneigh < 0 || nneigh > SRH_MAX_NEIGH)
 		return fail(SRH_E_UNSUPPORTED, "nneigh %d outside [0,%d] (the reference's NUM_NEIGHBOURING_VIEWS is 3)", nneigh, SRH_MAX_NEIGH);
 	if (nneigh > 0 && !neigh) return fail(SRH_E_INVALID, "null neighbour list");
 	if (peaks_dev && p->top_k < 1) return fail(SRH_E_INVALID, "top_k < 1");
 	for (int i = 0; i < nneigh; ++i) {
-		if ((rc = check_slot(c, neigh[i], true))) return rc;
+		if ((rc = check_slot(c, neigh[i], true, false))) return rc;
 		if (neigh[i] == view) return fail(SRH_E_INVALID, "view %d listed as its own neighbour", view);
 	}
 	HIP_TRY(hipSetDevice(c->device));
@@ -1073,90 +1262,55 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 	// neighbours.  Other radii stay on the one-thread-per-pixel kernels.
 	if (!c->force_generic && nneigh > 0 && p->window_radius == 2 && W < 65536 && H < 65536) {
 		int cmax = c->mvs_cmax_hint > 0 ? c->mvs_cmax_hint : ((2*p->num_depth_levels + 7) & ~7);
-		// without a refractive interface every ray of the view starts at the camera centre: the per-label
-		// part of pointFromDepth is tabulated once (same operands and operations, see srh_walk.hpp)
-		const bool table = !A.cam.is_refractive;
-		if (table) {
-			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
-			Scope s(c, "pinhole_label_table_kernel");
-			launch_pinhole_label_table(c->stream, c->d_views, view, *p, true, c->tnum);
-		}
-		for (int pass = 0; pass < 3; ++pass) {
-			HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
-			HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
-			const size_t per_px = (size_t)T*sizeof(double) + (size_t)nneigh*((size_t)cmax*sizeof(uint32_t) + sizeof(int32_t) + 2*sizeof(double)
-			                      + (peaks_dev ? (size_t)p->top_k*2*sizeof(double) : 0));
-			size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
-			if (lrows < 1) lrows = 1;
-			{
-				// the budget is a target, not a limit: no sliver band for a few rows over it, and bands of equal height
-				const size_t rows = (size_t)(y1 - y0);
-				if (rows <= lrows + lrows/4) lrows = rows;
-				else { const size_t nb = (rows + lrows - 1)/lrows; lrows = (rows + nb - 1)/nb; }
-			}
-			const size_t units = lrows*W*(size_t)nneigh;
-			// the list kernels' units: the masked-in pixels of a band, padded to whole 128-pixel blocks per link
-			size_t lunits = 0;
-			for (int by = y0; by < y1; by += (int)lrows) {
-				const int nr = std::min((int)lrows, y1 - by);
-				const size_t na = (size_t)A.act_row[by + nr] - A.act_row[by];
-				lunits = std::max(lunits, ((na + 127) & ~(size_t)127)*(size_t)nneigh);
-			}
-			if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
-			if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K, by pixel
-			if ((rc = ensure(c->lcand, c->lcand_cap, std::max<size_t>(lunits, 128)*(size_t)cmax))) return rc;   // wave-tiled lists
-			if ((rc = ensure(c->lcount, c->lcount_cap, std::max<size_t>(lunits, 128)))) return rc;
-			const bool staged = c->mvs_staged && !peaks_dev;
-			if (staged) {
-				int maxw; size_t words;
-				mvs_staging_shape(&maxw, &words);
-				const size_t waves = std::max<size_t>(lunits, 128)/64;
-				if ((rc = ensure(c->mvs_wdesc, c->mvs_wdesc_cap, waves*words))) return rc;
-				if ((rc = ensure(c->mvs_nwin, c->mvs_nwin_cap, waves))) return rc;
-			}
-			for (int by = y0; by < y1; by += (int)lrows) {
-				if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
-				const int nr = std::min((int)lrows, y1 - by);
-				const uint32_t *act = A.act ? A.act + A.act_row[by] : nullptr;
-				const int nact = (int)(A.act_row[by + nr] - A.act_row[by]);
-				run_weights(c, view, W, *p, by, nr, wstride);
-				{ Scope s(c, "mvs_walk_kernel");
-				  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
-				                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
-				double *const upk = peaks_dev ? c->cost + units*2 : nullptr;
-				if (staged) {
-					Scope s(c, "mvs_staged_cost_kernel");
-					launch_mvs_staged_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-					                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact);
+		if (c->mvs_async && !peaks_dev && !c->in_settle) {
+			// queue the view on the next slot and return
+			const int k = c->mvs_turn;
+			c->mvs_turn ^= 1;
+			MvsSlot &S = c->mvs_slot[k];
+			if ((rc = mvs_settle_slot(c, k))) return rc;
+			cmax = std::max(cmax, c->mvs_cmax_hint);
+			if (!S.stream) {
+				HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+				HIP_TRY(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+				HIP_TRY(hipHostMalloc((void **)&S.h_maxc, sizeof(int)));
+				S.own_buffers = k == 1;
+				if (S.own_buffers) {
+					HIP_TRY(hipMalloc((void **)&S.d_cnt, sizeof(Counters)));
+					HIP_TRY(hipMalloc((void **)&S.d_span, 4*sizeof(int)));
 				}
-				{ Scope s(c, "mvs_list_cost_kernel");
-				  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-				                       c->lcand, cmax, c->lcount, c->cost, upk, peaks_dev != nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
-				{ Scope s(c, "mvs_combine_kernel");
-				  launch_mvs_combine(c->stream, c->d_views, view, nneigh, W, *p, by, nr, c->cost, upk, (double *)peaks_dev); }
 			}
+			HIP_TRY(hipEventRecord(S.ev, c->stream));                 // after whatever the caller's stream holds
+			HIP_TRY(hipStreamWaitEvent(S.stream, S.ev, 0));
+			mvs_slot_swap(c, S);
+			rc = mvs_list_launch(c, view, neigh, nneigh, p, y0, y1, nullptr, cmax);
+			if (!rc && hipMemcpyAsync(S.h_maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+				rc = fail(SRH_E_DEVICE, "queueing the list-length read-back failed");
+			mvs_slot_swap(c, S);
+			S.pending = true;                                          // (also after a failure: the stream is drained before reuse)
+			S.view = view; S.nneigh = nneigh; S.y0 = y0; S.y1 = y1; S.cmax = cmax; S.p = *p;
+			for (int i = 0; i < nneigh; ++i) S.neigh[i] = neigh[i];
+			c->mvs_last = k;
+			c->stats.used_dense_path = 0;
+			return rc;
+		}
+		if ((rc = mvs_settle_all(c))) return rc;
+		for (int pass = 0; pass < 3; ++pass) {
+			if ((rc = mvs_list_launch(c, view, neigh, nneigh, p, y0, y1, peaks_dev, cmax))) return rc;
 			int maxc = 0;
 			HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
 			HIP_TRY(hipStreamSynchronize(c->stream));
 #ifdef SRH_PROFILE_PHASES
-			{
-				Counters h;
-				HIP_TRY(hipMemcpy(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost));
-				if (h.dbg_waves)
-					fprintf(stderr, "[srh prof] staged MVS cost: %llu waves, %.1f windows and %.1f slots per wave; cycles per wave: life %.0f = "
-					        "set-up %.0f + copies %.0f + slots %.0f (%.0f per slot) + end %.0f\n", h.dbg_waves, (double)h.dbg_cycles/h.dbg_waves,
-					        (double)h.dbg_blocks/h.dbg_waves, (double)h.dbg_total_cycles/h.dbg_waves, (double)h.dbg_phase[0]/h.dbg_waves,
-					        (double)h.dbg_phase[1]/h.dbg_waves, (double)h.dbg_phase[2]/h.dbg_waves,
-					        h.dbg_blocks ? (double)h.dbg_phase[2]/h.dbg_blocks : 0.0, (double)h.dbg_phase[3]/h.dbg_waves);
-			}
+			mvs_print_phases(c);
 #endif
 			if (maxc <= cmax) { if (cmax > c->mvs_cmax_hint) c->mvs_cmax_hint = cmax; break; }
 			cmax = (maxc + 7) & ~7;                                   // a list was cut: repeat with the true maximum
 		}
+		c->mvs_last = -1;
 		HIP_TRY(hipGetLastError());
 		c->stats.used_dense_path = 0;
 		return SRH_OK;
 	}
+	if ((rc = mvs_settle_all(c))) return rc;
 
 	const int rows = band_rows(c, W, H, T);
 	if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, rows, T)))) return rc;
@@ -1605,7 +1759,9 @@ extern "C" int srh_comm_destroy(srh_context *c) {
 extern "C" int srh_get_stats(srh_context *c, srh_stats *out) {
 	if (!c || !out) return fail(SRH_E_INVALID, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
-	int rc = fetch_counters(c, c->stats.used_dense_path);
+	int rc = mvs_settle_all(c);
+	if (rc) return rc;
+	rc = fetch_counters(c, c->stats.used_dense_path);
 	if (rc) return rc;
 	*out = c->stats;
 	return SRH_OK;

@@ -148,11 +148,12 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
     for v in range(NV):
         hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
     res = {}
-    for tag, generic, budget, staged in (("two_stage", 0, 8192, 1), ("two_stage_bands", 0, 64, 1), ("gathering", 0, 8192, 0),
-                                        ("inline", 1, 8192, 1)):
+    for tag, generic, budget, staged, in_flight in (("two_stage", 0, 8192, 1, 0), ("two_stage_bands", 0, 64, 1, 0),
+                                                   ("gathering", 0, 8192, 0, 0), ("inline", 1, 8192, 1, 0)):
         hip_ctx.set_option("force_generic", generic)
         hip_ctx.set_option("band_budget_mb", budget)
         hip_ctx.set_option("mvs_staged", staged)
+        hip_ctx.set_option("mvs_async", in_flight)
         maps, evals = [], []
         for v in range(NV):
             hip_ctx.mvs_initial_estimate(v, neigh[v], p)
@@ -162,6 +163,14 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
     hip_ctx.set_option("force_generic", 0)
     hip_ctx.set_option("band_budget_mb", 8192)
     hip_ctx.set_option("mvs_staged", 1)
+    # the default: the calls only queue the views' kernels (two views in flight on two streams); the maps are complete
+    # whenever they are looked at.  All four queued back to back, then read; the last call's counters are its own.
+    hip_ctx.set_option("mvs_async", 1)
+    for v in range(NV):
+        hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+    assert hip_ctx.stats()["n_eval"] == res["two_stage"][1][NV - 1]
+    for v in range(NV):
+        assert _same_bits(res["two_stage"][0][v], hip_ctx.download_depth(v)), ("in flight", v)
     for v in range(NV):
         for tag in ("two_stage_bands", "gathering", "inline"):
             assert _same_bits(res["two_stage"][0][v], res[tag][0][v]), (tag, v)
