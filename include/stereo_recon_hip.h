@@ -157,6 +157,12 @@ int  srh_synchronize(srh_context *ctx);
  *   "strip"           1 (default): the dense cost kernel runs in its persistent strip form (one workgroup walks a
  *                     tile column down the rows, every input enters LDS by LDS-DMA); 0: one workgroup per tile;
  *                     4 / 8: force the 4-wave / 8-wave form of the strip kernel.  Results are identical bits.
+ *   "mvs_staged"      1 (default): the MultiViewStereo list cost kernel takes its 25-tap windows from LDS copies of the
+ *                     other view (one box per stretch of list slots and wave) where they fit; 0: every window is gathered
+ *                     from memory (round 2's kernel).  Results are identical bits.
+ *   "mvs_async"       1 (default): srh_mvs_initial_estimate only queues a view's kernels, on one of two side streams in
+ *                     turn (two views in flight); 0: one view at a time, the call returns when the view is done.
+ *                     Either way the maps are complete whenever another entry point can observe them.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
  *   "band_budget_mb"  device scratch per row band (default 8192) */
 int  srh_set_option(srh_context *ctx, const char *name, long value);
@@ -204,7 +210,11 @@ int  srh_twoview_compute(srh_context *ctx, int left_slot, int right_slot, const 
  * computeInitialEstimate(view) non-MRF result (multiviewstereo.cpp:524-604,654-660)
  * for `view_slot` against `nneigh` neighbour slots (0..8; the reference keeps 3), rows [y0,y1).
  * peaks_dev (optional, DEVICE pointer, w*h*top_k*2 doubles) receives the sorted
- * top-K (cost,depth) pairs the MRF branch would consume. */
+ * top-K (cost,depth) pairs the MRF branch would consume.
+ * With option "mvs_async" (default) and no peaks_dev the call queues the view's kernels on a side stream and returns:
+ * consecutive calls overlap two views; every other entry point of the context (downloads, copies, cross-checks,
+ * srh_synchronize, srh_get_stats ...) first completes what is in flight, so a caller never sees an unfinished map.
+ * An error of a queued view (cancellation, device error) is reported by the call that completes it. */
 int  srh_mvs_initial_estimate(srh_context *ctx, int view_slot, const int32_t *neigh_slots, int nneigh,
                               const srh_params *p, int y0, int y1, void *peaks_dev);
 /* crossCheck(view) (multiviewstereo.cpp:666-729) over `nviews` slots listed in view

@@ -19,6 +19,9 @@ timeout -k 10 300 $B --workload c3 --arith f32 --steps 5 --warmup 2 --cpu-rows 0
 SRH_BENCH_STRIP=0 timeout -k 10 300 $B --workload c3 --steps 5 --warmup 2 --cpu-rows 0 --no-configs > "$OUT/c3_per_tile_kernel_bench.json" 2>/dev/null
 echo "bench lines done"
 # per-kernel time
+# (C4: one view in flight, SRH_MVS_ASYNC=0 -- with the default two, a kernel's traced duration includes its neighbour's share
+# of the GPU; bench.py takes its kernels_ms from such a pass as well)
+export SRH_MVS_ASYNC=0
 for w in c3 c4 c5; do
 	rocprofv3 --kernel-trace --stats -d "$OUT/stats_$w" --output-format csv -- $B --workload $w --steps 3 --warmup 1 --cpu-rows 0 --no-configs > "$OUT/stats_$w.log" 2>&1
 	cp "$(find "$OUT/stats_$w" -name '*kernel_stats.csv' | head -1)" "$OUT/${w}_kernel_stats.csv" 2>/dev/null
@@ -45,12 +48,16 @@ for w in c4 c5; do
 	pmc ${w}_tcp $w TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
 	pmc ${w}_tcc $w TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 done
+unset SRH_MVS_ASYNC
 for w in c3 c4 c5; do python3 profiles/pmc_table.py $(ls "$OUT"/pmc_${w}_mix*.csv "$OUT"/pmc_${w}_tc*.csv 2>/dev/null) > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
 # per-phase stamps of the strip kernel (diagnostic build: never the shipped library), both forms
 for strip in 8 4; do
 	SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so SRH_BENCH_STRIP=$strip timeout -k 10 200 $B --workload c3 --steps 2 --warmup 1 --cpu-rows 0 --no-configs > /dev/null 2> "$OUT/phases_strip$strip.err"
 	grep "srh dbg" "$OUT/phases_strip$strip.err" | grep -v rows | tail -9 > "$OUT/c3_strip${strip}_phases.txt"
 done
+# phases of the geodesic kernel (C3) and of the staged MVS cost kernel (C4), diagnostic build
+SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so timeout -k 10 200 $B --workload c3 --steps 1 --warmup 1 --cpu-rows 0 --no-configs 2>&1 >/dev/null | grep "geodesic kernel" | tail -1 > "$OUT/c3_geodesic_phases.txt"
+SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so SRH_MVS_ASYNC=0 timeout -k 10 200 $B --workload c4 --steps 1 --warmup 1 --cpu-rows 0 --no-configs 2>&1 >/dev/null | grep "staged MVS" | tail -8 > "$OUT/c4_staged_phases.txt"
 # what the block loops cost: every tile's loops repeated 1, 2, 3 times (timing experiment build), per-tile and strip kernels
 {
 	for strip in 0 8; do for rep in 1 2 3; do
@@ -65,6 +72,7 @@ print('strip option $strip  loops x $rep :  %s %.3f ms per launch' % (k[0], k[1]
 rm -f "$OUT/rep.json"
 ./profiles/microbench/fp64_sustained > "$OUT/fp64_sustained_mi355x.txt" 2>&1
 ./profiles/microbench/fp64_dep_distance > "$OUT/fp64_dep_distance_mi355x.txt" 2>&1
+./profiles/microbench/fp64_chain_latency > "$OUT/fp64_chain_latency_mi355x.txt" 2>&1
 ./profiles/microbench/lds_dma_alignment > "$OUT/lds_dma_alignment_mi355x.txt" 2>&1
 rm -f "$OUT"/pmc_*.log "$OUT"/stats_*.log
 ls "$OUT"

@@ -56,7 +56,7 @@ for name in sorted(os.listdir(SRC)):
     if name.endswith("_bench.json") or name.endswith("_kernel_stats.csv") or name.endswith("_instruction_mix.txt") \
             or name.endswith("_phases.txt") or name == "c3_repeat_experiment.txt":
         shutil.copy(os.path.join(SRC, name), os.path.join(HERE, "r03_" + name))
-for name in ("fp64_sustained_mi355x.txt", "fp64_dep_distance_mi355x.txt", "lds_dma_alignment_mi355x.txt"):
+for name in ("fp64_sustained_mi355x.txt", "fp64_dep_distance_mi355x.txt", "fp64_chain_latency_mi355x.txt", "lds_dma_alignment_mi355x.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(HERE, "microbench", name))
 print(json.dumps({k: v for k, v in traffic.items() if k != "_source"}, indent=1)[:3000])
