@@ -1210,8 +1210,8 @@ static int mvs_settle_slot(srh_context *c, int k) {
 	if (!S.pending) return SRH_OK;
 	HIP_TRY(hipStreamSynchronize(S.stream));
 	S.pending = false;
-	if (k == c->mvs_last && S.own_buffers)                       // srh_get_stats reads the context's counters
-		HIP_TRY(hipMemcpy(c->d_cnt, S.d_cnt, sizeof(Counters), hipMemcpyDeviceToDevice));
+	if (k == c->mvs_last && S.own_buffers)                       // srh_get_stats reads the context's counters, on its stream
+		HIP_TRY(hipMemcpyAsync(c->d_cnt, S.d_cnt, sizeof(Counters), hipMemcpyDeviceToDevice, c->stream));
 #ifdef SRH_PROFILE_PHASES
 	mvs_slot_swap(c, S); mvs_print_phases(c); mvs_slot_swap(c, S);
 #endif
