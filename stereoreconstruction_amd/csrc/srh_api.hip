@@ -531,6 +531,7 @@ extern "C" int srh_set_hooks(srh_context *c, const volatile int *cancel, srh_pro
 
 extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
+	{ const int rc = mvs_settle_all(c); if (rc) return rc; }       // options apply to work queued from here on
 	if (!strcmp(name, "list_rows")) { c->list_rows = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "fused")) { c->use_fused = value != 0; return SRH_OK; }
@@ -544,7 +545,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		c->strip = (int)value; return SRH_OK;
 	}
 	if (!strcmp(name, "mvs_staged")) { c->mvs_staged = value != 0; return SRH_OK; }
-	if (!strcmp(name, "mvs_async")) { const int rc = mvs_settle_all(c); if (rc) return rc; c->mvs_async = value != 0; return SRH_OK; }
+	if (!strcmp(name, "mvs_async")) { c->mvs_async = value != 0; return SRH_OK; }
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
