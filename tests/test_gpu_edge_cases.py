@@ -211,3 +211,47 @@ def test_mvs_more_than_three_neighbours(hip_ctx):
             ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(v), want, 1e-9)
             assert ok, (v, generic, msg)
             assert hip_ctx.stats()["n_eval"] == n_eval
+
+
+def test_mvs_estimates_in_flight_interleaved_with_other_calls(hip_ctx):
+    """srh_mvs_initial_estimate only queues a view (two views in flight on two streams): whatever a caller does next --
+    more estimates, a re-upload of a neighbour, downloads, the ordered cross-check -- sees complete maps.  Against a
+    second context that waits for every view (option mvs_async 0), bit for bit, and a list capacity that is too small
+    on first use (a fresh context's hint) is found out later and the view redone."""
+    case = cases.get_mvs("mvs_five_views")
+    cams, p = cases.hip_inputs(case)
+    neigh = [list(map(int, n)) for n in capi.mvs_neighbours(cams, p)]
+    nv = len(cams)
+    ref = capi.Context(0)                                       # fresh: its list-capacity hint starts at the default
+    try:
+        ref.set_option("mvs_async", 0)
+        cases.upload_case(ref, case, cams)
+        want = []
+        for v in range(nv):
+            ref.mvs_initial_estimate(v, neigh[v], p)
+            want.append(ref.download_depth(v))
+        evals_last = ref.stats()["n_eval"]
+        for v in range(nv):
+            ref.mvs_cross_check(list(range(nv)), v, p)
+        want_cc = [ref.download_depth(v) for v in range(nv)]
+    finally:
+        ref.close()
+    ctx = capi.Context(0)
+    try:
+        cases.upload_case(ctx, case, cams)
+        for v in range(nv):                                     # five views queued back to back: slots reused twice
+            ctx.mvs_initial_estimate(v, neigh[v], p)
+        assert ctx.stats()["n_eval"] == evals_last
+        rgba, mask, _, _, _ = case["views"][1]
+        ctx.upload_view(1, rgba, mask, cams[1])                 # re-upload of a view while nothing may be in flight any more
+        ctx.mvs_initial_estimate(1, neigh[1], p)
+        ctx.mvs_initial_estimate(0, neigh[0], p)
+        for v in range(nv):
+            assert np.array_equal(ctx.download_depth(v).view(np.uint64), want[v].view(np.uint64)), v
+        ctx.mvs_initial_estimate(3, neigh[3], p)                # queued, then consumed by the cross-check chain directly
+        for v in range(nv):
+            ctx.mvs_cross_check(list(range(nv)), v, p)
+        for v in range(nv):
+            assert np.array_equal(ctx.download_depth(v).view(np.uint64), want_cc[v].view(np.uint64)), v
+    finally:
+        ctx.close()
