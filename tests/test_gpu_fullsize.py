@@ -8,6 +8,7 @@
 import numpy as np
 import pytest
 
+import cases
 import oracle_ffi as O
 from stereoreconstruction_amd import capi, synthetic
 
@@ -313,3 +314,36 @@ def test_c5_full_size_tilted_interface(hip_ctx):
         want = O.twoview_wta(oi[ref], oi[oth], oc[ref], oc[oth], op, y, y + 1)
         ok, msg, _ = _cmp(maps[ref][y], want[y])
         assert ok, (ref, y, msg)
+
+
+@pytest.mark.parametrize("name", ["mvs_distorted", "mvs_refractive", "mvs_scaled"])
+def test_mvs_list_path_medium_size_other_camera_models(hip_ctx, name):
+    """The list path's machinery -- serpentine units, aligned lists, window boxes, staged cost kernel, views in flight --
+    with lens distortion, a refractive interface and an image scale at 320x240 (the small parity cases are mostly
+    image border): default == gathering kernel == inline kernel bit for bit, two rows of view 1 against the oracle."""
+    case = cases.get_mvs(name, w=320, h=240, D=40, nviews=3)
+    cams, p = cases.hip_inputs(case)
+    neigh = [list(map(int, n)) for n in capi.mvs_neighbours(cams, p)]
+    cases.upload_case(hip_ctx, case, cams)
+    nv = len(cams)
+    res = {}
+    for tag, opts in (("default", {}), ("gathering", {"mvs_staged": 0, "mvs_async": 0}), ("inline", {"force_generic": 1})):
+        for k, val in opts.items():
+            hip_ctx.set_option(k, val)
+        try:
+            for v in range(nv):
+                hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+            res[tag] = [hip_ctx.download_depth(v) for v in range(nv)]
+        finally:
+            hip_ctx.set_option("mvs_staged", 1)
+            hip_ctx.set_option("mvs_async", 1)
+            hip_ctx.set_option("force_generic", 0)
+    for v in range(nv):
+        for tag in ("gathering", "inline"):
+            assert _same_bits(res["default"][v], res[tag][v]), (name, tag, v)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    y = case["views"][1][1].shape[0] // 2
+    want, _ = O.mvs_initial_estimate(imgs, ocams, 1, neigh[1], op, y, y + 2)
+    ok, msg, _ = cases.compare_depth(res["default"][1][y:y + 2], want[y:y + 2], 1e-9)
+    assert ok, (name, msg)
+    assert (res["default"][1][case["views"][1][1] == 1] > 0).any()
