@@ -686,6 +686,7 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 // fit (box over an image border, larger than the LDS share, more than `maxw` windows) is left to
 // mvs_list_cost_kernel, which gathers from memory: nwin[wave] = -1.
 #define MQ_PAD 0xffffffffu
+#define MQ_PQ 4                    // top-K request: pairs above the threshold a lane may have waiting for their depth
 #define MQ_T 128
 #define MQ_QN 32
 #define MQ_FLUSH 24
@@ -986,6 +987,22 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 	uint32_t be = 0xffffffffu;
 	bool redo = !all;                                               // this unit needs mvs_unit_general
 	const uint32_t *cl = cand + (ul >> 6)*(size_t)cmax*64 + (ul & 63);
+	// PEAKS: a pair above the threshold needs its depth (unproject + closestPoints, ~300 instructions) and a place in the
+	// unit's sorted K-list.  Done on the spot, a wave walks that path at nearly every candidate for the one or two lanes
+	// that passed; so the passing (cost, candidate) pairs wait in a short per-lane queue and the wave works them off
+	// together when a lane's queue is full (the K largest pairs of a multiset do not depend on the order of insertion).
+	__shared__ double s_pc[PEAKS ? MQ_PQ : 1][PEAKS ? MQ_T : 1];
+	__shared__ uint32_t s_pe[PEAKS ? MQ_PQ : 1][PEAKS ? MQ_T : 1];
+	int pqn = 0;
+	auto pflush = [&]() {
+		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		while (__any(pqn > 0))
+			if (pqn > 0) {
+				--pqn;
+				const uint32_t pe = s_pe[pqn][tid];
+				mvs_peaks_insert(pk, P.top_k, s_pc[pqn][tid], candidate_depth(A.cam, B.cam, P, ray, (int)(pe & 0xffffu), (int)(pe >> 16)));
+			}
+	};
 
 	// one candidate per iteration: its 25-tap window arrives in g[], is turned in place into p_t = w_t*g_t
 	// (the products both sweeps need), and the next candidate's window is requested as soon as the second
@@ -1037,14 +1054,13 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 		}
 		if (e != MQ_PAD && c > P.peak_threshold) {                   // multiviewstereo.cpp:589-594, 654-660
 			if (PEAKS) {
-				if (fast) {
-					const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
-					mvs_peaks_insert(pk, P.top_k, c, candidate_depth(A.cam, B.cam, P, ray, (int)(e & 0xffffu), (int)(e >> 16)));
-				}
+				if (fast) { s_pc[pqn][tid] = c; s_pe[pqn][tid] = e; ++pqn; }
 			} else if (c > bestCost) { bestCost = c; be = e; }
 			else if (c == bestCost && e != be) redo = true;              // exact tie of two candidates: depths decide
 		}
+		if (PEAKS && __any(pqn == MQ_PQ)) pflush();
 	}
+	if (PEAKS) pflush();
 	if (redo) { mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout, pk); return; }
 	if (PEAKS) { bout[0] = pk[2*(P.top_k - 1)]; bout[1] = pk[2*(P.top_k - 1) + 1]; return; }
 	double bestDepth = -1.0;                                        // no peak above the threshold
