@@ -1081,7 +1081,7 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 #define MS_AHEAD 4                    // list entries in flight per lane
 #endif
 #ifndef MS_NC
-#define MS_NC 1                       // slots evaluated side by side
+#define MS_NC 1                       // slots evaluated side by side (2 was measured: slower)
 #endif
 
 template <int R>
@@ -1199,8 +1199,10 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 #ifdef SRH_PROFILE_PHASES
 		ph_slots += (unsigned long long)(ke - kb);
 #endif
-		// two slots per trip: their sums are independent chains, which is what keeps the FP64 pipe busy at two waves per
-		// SIMD (a single dependent chain issues once in 12 cycles, profiles/microbench/fp64_chain_latency.hip)
+		// MS_NC slots per trip.  A candidate's sums are single dependent chains (a dependent FP64 instruction issues 12
+		// cycles after its producer, profiles/microbench/fp64_chain_latency.hip); two slots side by side would give two
+		// independent chains, but their 100 product registers spill -- measured slower than one slot per trip with the
+		// SIMD's second wave filling the gaps.  MS_NC = 1 is what ships.
 		for (int k = kb; k < ke; k += MS_NC) {
 			uint32_t e[MS_NC];
 			const double *gp[MS_NC];
