@@ -347,3 +347,62 @@ def test_mvs_list_path_medium_size_other_camera_models(hip_ctx, name):
     ok, msg, _ = cases.compare_depth(res["default"][1][y:y + 2], want[y:y + 2], 1e-9)
     assert ok, (name, msg)
     assert (res["default"][1][case["views"][1][1] == 1] > 0).any()
+
+
+def _rot(axis, ang):
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mvs_list_path_random_rigs_and_ragged_masks(hip_ctx, seed):
+    """Random rigs around the sphere -- cameras rolled about their axes by up to 90 degrees and tilted, so that epipolar
+    curves run in every direction through the other image --, masks with random holes and ragged rows, odd image sizes:
+    the list path (serpentine units, aligned lists, window boxes, LDS-staged and gathering cost kernels, two views in
+    flight) gives the inline one-thread-per-pixel kernel's maps bit for bit, with the same evaluation counts."""
+    rng = np.random.default_rng(0xC0FFEE + seed)
+    W, H, D, NV = int(rng.integers(70, 200)), int(rng.integers(50, 140)), int(rng.integers(12, 40)), 3
+    cams3 = synthetic.semicircle_rig(NV, W, H, radius=10.0, step_deg=float(rng.uniform(6.0, 25.0)), focal=float(rng.uniform(0.9, 1.6)) * W)
+    for v in range(NV):
+        K, R, t = cams3[v]
+        Q = _rot([0, 0, 1], rng.uniform(-np.pi / 2, np.pi / 2)) @ _rot(rng.normal(size=3), rng.uniform(0, 0.08))
+        cams3[v] = (K, Q @ R, Q @ t)                         # the camera turned about its own centre
+    rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, 0xABCD00 + seed, sphere_radius=2.0, tex_size=256)
+    for v in range(NV):
+        holes = rng.random((H, W)) < 0.03                    # isolated masked-out pixels
+        masks[v] = np.where(holes, 0, masks[v]).astype(np.uint8)
+        y = int(rng.integers(0, H))
+        masks[v][y, : W // 2] = 0                            # a ragged row
+        if seed % 3 == 0:
+            masks[v][:] = 1                                  # every pixel a unit (also those that see no sphere)
+    cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
+    p = capi.params_mvs(min_depth=7.5, max_depth=12.5, num_depth_levels=D, cross_check_threshold=0.3)
+    neigh = [list(map(int, n)) for n in capi.mvs_neighbours(cams, p)]
+    for v in range(NV):
+        hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
+    out = {}
+    for tag, opts in (("default", {}), ("gathering", {"mvs_staged": 0}), ("inline", {"force_generic": 1})):
+        for k, val in opts.items():
+            hip_ctx.set_option(k, val)
+        try:
+            maps, evals = [], []
+            for v in range(NV):
+                hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+            for v in range(NV):
+                maps.append(hip_ctx.download_depth(v))
+            for v in range(NV):                              # (counters: one view at a time)
+                hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+                evals.append(hip_ctx.stats()["n_eval"])
+            out[tag] = (maps, evals)
+        finally:
+            hip_ctx.set_option("mvs_staged", 1)
+            hip_ctx.set_option("force_generic", 0)
+    for v in range(NV):
+        for tag in ("gathering", "inline"):
+            assert _same_bits(out["default"][0][v], out[tag][0][v]), (seed, tag, v, W, H, D)
+            assert out["default"][1][v] == out[tag][1][v], (seed, tag, v)
+        assert np.isposinf(out["default"][0][v][masks[v] != 1]).all()
+    assert sum(out["default"][1]) > 20000, "degenerate rig: hardly any candidate"
+    assert any((m[np.isfinite(m)] > 0).any() for m in out["default"][0]), "no NCC peak anywhere"
