@@ -1140,7 +1140,7 @@ static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int n
 		if ((rc = ensure(c->cost, c->cost_cap, units*2 + (peaks_dev ? units*(size_t)p->top_k*2 : 0)))) return rc;   // best pairs + per-unit top-K, by pixel
 		if ((rc = ensure(c->lcand, c->lcand_cap, std::max<size_t>(lunits, 128)*(size_t)cmax))) return rc;   // wave-tiled lists
 		if ((rc = ensure(c->lcount, c->lcount_cap, std::max<size_t>(lunits, 128)))) return rc;
-		const bool staged = c->mvs_staged && !peaks_dev;
+		const bool staged = c->mvs_staged != 0;
 		if (staged) {
 			int maxw; size_t words;
 			mvs_staging_shape(&maxw, &words);
@@ -1156,12 +1156,13 @@ static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int n
 			run_weights(c, view, W, *p, by, nr, wstride);
 			{ Scope s(c, "mvs_walk_kernel");
 			  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
-			                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, act, nact); }
+			                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, act, nact,
+			                  peaks_dev != nullptr); }
 			double *const upk = peaks_dev ? c->cost + units*2 : nullptr;
 			if (staged) {
 				Scope s(c, "mvs_staged_cost_kernel");
 				launch_mvs_staged_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-				                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact);
+				                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact, upk);
 			}
 			{ Scope s(c, "mvs_list_cost_kernel");
 			  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,

@@ -1076,6 +1076,8 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 // LDS copy of the current window's box of the other view instead of 15 gathers per candidate (which kept that
 // kernel on the L1 address path at a quarter of the FP64 rate).  Weights and a_t live in registers.
 #define MS_CAP 2432                   // doubles of LDS per wave: 4 workgroups of 2 waves fill a compute unit's 160 KB
+#define MS_CAP_PEAKS 2240             // the same for the top-K request (room for its queue)
+#define MS_PQ 2                       // top-K request: pairs a lane may have waiting
 #define MS_MAXW 96                    // windows per wave
 #ifndef MS_AHEAD
 #define MS_AHEAD 4                    // list entries in flight per lane
@@ -1084,13 +1086,15 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 #define MS_NC 1                       // slots evaluated side by side (2 was measured: slower)
 #endif
 
-template <int R>
+// PEAKS: the top-K request (every pair above the threshold into the unit's sorted K-list upk[unit][K][2], as in
+// mvs_list_cost_kernel<R, true>); its LDS share of the box is smaller by the queue of pairs waiting for their depth.
+template <int R, bool PEAKS>
 __global__ __launch_bounds__(MQ_T, 2)
 void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                             int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                             const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
                             double *__restrict__ best, const uint4 *__restrict__ wdesc, const int32_t *__restrict__ nwin,
-                            Counters *__restrict__ cnt, const uint32_t *__restrict__ act, int nact)
+                            Counters *__restrict__ cnt, const uint32_t *__restrict__ act, int nact, double *__restrict__ upk)
 {
 	constexpr int WS = 2*R + 1, T = WS*WS;
 #ifdef SRH_PROFILE_PHASES
@@ -1101,7 +1105,9 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 #else
 #define MS_STAMP(i)
 #endif
-	__shared__ double s_box[MQ_T/64][MS_CAP];
+	__shared__ double s_box[MQ_T/64][PEAKS ? MS_CAP_PEAKS : MS_CAP];
+	__shared__ double s_pc[PEAKS ? MS_PQ : 1][PEAKS ? MQ_T : 1];     // PEAKS: pairs above the threshold waiting for their depth
+	__shared__ uint32_t s_pe[PEAKS ? MS_PQ : 1][PEAKS ? MQ_T : 1];
 	const ViewDev &A = views[ref];
 	const ViewDev &B = views[nl.n[blockIdx.y]];
 	const int W = A.w, OW = B.w;
@@ -1119,6 +1125,8 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	const size_t unit = (size_t)blockIdx.y*npix + q;
 	const size_t ul = (size_t)blockIdx.y*((size_t)gridDim.x*MQ_T) + j;
 	double *bout = best + unit*2;
+	double *pk = PEAKS ? upk + unit*(size_t)P.top_k*2 : nullptr;
+	if (PEAKS && active) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }
 	if (nw == 0) {                                                  // no candidate anywhere in the wave
 		if (active) { bout[0] = 0.0; bout[1] = -1.0; }
 		return;
@@ -1158,6 +1166,17 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	bool redo = active && !all;                                     // this unit needs mvs_unit_general
 	const SharedDivisor twd = shared_divisor(tw);
 	const double thr0 = P.peak_threshold > 0.0 ? P.peak_threshold : 0.0;
+	int pqn = 0;
+	auto pflush = [&]() {                                           // (all lanes together)
+		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		while (__any(pqn > 0))
+			if (pqn > 0) {
+				--pqn;
+				const uint32_t pe = s_pe[pqn][tid];
+				mvs_peaks_insert(pk, P.top_k, s_pc[pqn][tid], candidate_depth(A.cam, B.cam, P, ray, (int)(pe & 0xffffu), (int)(pe >> 16)));
+			}
+		if (active) bestCost = pk[0];                                // the K-th largest cost so far: nothing below it can enter the list
+	};
 	const uint32_t *cl = cand + (ul >> 6)*(size_t)cmax*64 + (ul & 63);
 	const uint4 *wd = wdesc + waveid*(size_t)MS_MAXW;
 	typedef const __attribute__((address_space(1))) double *gptr;
@@ -1254,15 +1273,19 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 				if (__all(hopeless)) continue;
 				const double c = (den < 1e-10) ? 0.0 : s1[u] / sqrt(den);
 				if (e[u] != MQ_PAD && c > P.peak_threshold) {                // multiviewstereo.cpp:589-594, 654-660
-					if (c > bestCost) { bestCost = c; be = e[u]; }
+					if (PEAKS) { if (all) { s_pc[pqn][tid] = c; s_pe[pqn][tid] = e[u]; ++pqn; } }
+					else if (c > bestCost) { bestCost = c; be = e[u]; }
 					else if (c == bestCost && e[u] != be) redo = true;       // exact tie of two candidates: depths decide
 				}
 			}
+			if (PEAKS && __any(pqn == MS_PQ)) pflush();
 		}
 		MS_STAMP(2)
 	}
+	if (PEAKS) pflush();
 	if (active) {
-		if (redo) mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout, nullptr);
+		if (redo) mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout, pk);
+		else if (PEAKS) { bout[0] = pk[2*(P.top_k - 1)]; bout[1] = pk[2*(P.top_k - 1) + 1]; }
 		else {
 			double bestDepth = -1.0;                                    // no peak above the threshold
 			if (be != 0xffffffffu) {
@@ -1290,24 +1313,31 @@ void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave) { *maxw = MS_MAXW
 // wdesc / nwin: window descriptors (MS_MAXW uint4 per wave) and window counts of the launch's waves, or null (no staging)
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
-                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact)
+                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact, bool peaks)
 {
 	if (nact <= 0) return;
 	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
-	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW, MS_CAP, act, nact);
+	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW,
+	                   peaks ? MS_CAP_PEAKS : MS_CAP, act, nact);
 }
 
 // the three steps of the list path's second stage; nwin (or null): the waves with nwin >= 0 are the staged kernel's
 void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                             const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                             const uint32_t *cand, int cmax, const int32_t *count, double *best,
-                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt, const uint32_t *act, int nact)
+                            const uint32_t *wdesc, const int32_t *nwin, Counters *cnt, const uint32_t *act, int nact,
+                            double *unit_peaks)
 {
 	if (nact <= 0) return;
 	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
-	hipLaunchKernelGGL(mvs_staged_cost_kernel<2>, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh), P, y0, nrows,
-	                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact);
+	const NeighList nl = make_neigh_list(neigh, nneigh);
+	if (unit_peaks)
+		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, unit_peaks);
+	else
+		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, (double *)nullptr);
 }
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
@@ -1320,7 +1350,7 @@ void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const i
 	const NeighList nl = make_neigh_list(neigh, nneigh);
 	if (peaks)
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, unit_peaks, (const int32_t *)nullptr, act, nact);
+		                   wbuf, wstride, cand, cmax, count, best, unit_peaks, nwin, act, nact);
 	else
 		hipLaunchKernelGGL((mvs_list_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
 		                   wbuf, wstride, cand, cmax, count, best, (double *)nullptr, nwin, act, nact);
