@@ -410,4 +410,18 @@ def test_mvs_list_path_random_rigs_and_ragged_masks(hip_ctx, seed):
             assert out["default"][1][v] == out[tag][1][v], (seed, tag, v)
         assert np.isposinf(out["default"][0][v][masks[v] != 1]).all()
     assert sum(out["default"][1]) > 20000, "degenerate rig: hardly any candidate"
+    # the top-K request (what the MRF branch consumes): staged + gathering list kernels against the inline kernel, view 0
+    import torch
+    pks = []
+    for generic in (0, 1):
+        pk = torch.full((H, W, p.top_k, 2), 7.0, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        hip_ctx.set_option("force_generic", generic)
+        try:
+            hip_ctx.mvs_initial_estimate(0, neigh[0], p, peaks_dev=pk.data_ptr())
+            hip_ctx.synchronize()
+        finally:
+            hip_ctx.set_option("force_generic", 0)
+        pks.append(pk.cpu().numpy())
+    assert np.array_equal(pks[0].view(np.uint64), pks[1].view(np.uint64)), (seed, "top-K lists")
     assert thr == 0.9 or any((m[np.isfinite(m)] > 0).any() for m in out["default"][0]), "no NCC peak anywhere"
