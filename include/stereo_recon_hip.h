@@ -164,7 +164,7 @@ int  srh_synchronize(srh_context *ctx);
  *                     turn (two views in flight); 0: one view at a time, the call returns when the view is done.
  *                     Either way the maps are complete whenever another entry point can observe them.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
- *   "band_budget_mb"  device scratch per row band (default 8192) */
+ *   "band_budget_mb"  device scratch per row band (default 32768: a 1920x1080x256 refractive pair in one band) */
 int  srh_set_option(srh_context *ctx, const char *name, long value);
 
 /* ---- views: what VectorImage::fromQImage + the mask test hold (util/vectorimage.cpp:48-64) ----

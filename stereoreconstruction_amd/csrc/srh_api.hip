@@ -123,7 +123,7 @@ struct srh_context {
 	uint32_t *lrowinfo = nullptr; size_t lrowinfo_cap = 0;
 	int32_t *lmeta = nullptr; size_t lmeta_cap = 0;
 	void *comm = nullptr; int comm_ranks = 0, comm_rank = 0;   // RCCL communicator (srh_comm_init)
-	size_t wbuf_budget = (size_t)8192 << 20;            // bytes per band of scratch (windows, cost rows, candidate lists); the GPU has 288 GB
+	size_t wbuf_budget = (size_t)32768 << 20;           // bytes per band of scratch (windows, cost rows, candidate lists): the GPU has 288 GB, and every band ends in the tail of its kernels
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
 	void *user = nullptr;

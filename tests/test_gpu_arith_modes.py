@@ -99,13 +99,13 @@ def test_f32_mode_on_masked_views_bands_and_row_ranges(hip_ctx):
         hip_ctx.set_option("band_budget_mb", 1)
         hip_ctx.twoview_wta(0, 1, p)
         banded = hip_ctx.download_depth(0)
-        hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.set_option("band_budget_mb", 32768)
         hip_ctx.upload_depth(0, np.full_like(whole, -3.0))
         hip_ctx.twoview_wta(0, 1, p, 7, 41)
         part = hip_ctx.download_depth(0)
     finally:
         hip_ctx.set_option("arith", 0)
-        hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.set_option("band_budget_mb", 32768)
     assert np.array_equal(whole.view(np.uint64), banded.view(np.uint64))          # deterministic, band-independent
     assert np.array_equal(part[7:41].view(np.uint64), whole[7:41].view(np.uint64))
     assert (part[:7] == -3.0).all() and (part[41:] == -3.0).all()

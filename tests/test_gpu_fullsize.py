@@ -76,14 +76,14 @@ def test_c5_refractive_rows_equal_ordered_lists(hip_ctx):
     hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr, None, *plane))
     p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
     res = {}
-    for tag, rows, budget in (("rows", 1, 8192), ("rows_bands", 1, 96), ("ordered", 0, 8192)):
+    for tag, rows, budget in (("rows", 1, 32768), ("rows_bands", 1, 96), ("ordered", 0, 32768)):
         hip_ctx.set_option("list_rows", rows)
         hip_ctx.set_option("band_budget_mb", budget)
         hip_ctx.twoview_wta(1, 0, p)
         res[tag] = hip_ctx.download_depth(1)
         assert not hip_ctx.stats()["used_dense_path"]
     hip_ctx.set_option("list_rows", 1)
-    hip_ctx.set_option("band_budget_mb", 8192)
+    hip_ctx.set_option("band_budget_mb", 32768)
     assert _same_bits(res["rows"], res["rows_bands"]) and _same_bits(res["rows"], res["ordered"])
     assert np.isfinite(res["rows"]).mean() > 0.2
     op = O.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
@@ -98,7 +98,7 @@ def test_c3_full_size_band_invariance(hip_ctx):
     split (one band at the default 8 GB budget vs ~50 bands at 128 MB), left->right pass."""
     W, H, D = 1920, 1080, 256
     (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
-    hip_ctx.set_option("band_budget_mb", 8192)
+    hip_ctx.set_option("band_budget_mb", 32768)
     hip_ctx.twoview_wta(0, 1, p)
     a = hip_ctx.download_depth(0)
     st_a = hip_ctx.stats()
@@ -108,7 +108,7 @@ def test_c3_full_size_band_invariance(hip_ctx):
     b = hip_ctx.download_depth(0)
     st_b = hip_ctx.stats()
     assert not st_b["used_strip_kernel"]                  # ... ~50 thin bands: one workgroup per tile
-    hip_ctx.set_option("band_budget_mb", 8192)
+    hip_ctx.set_option("band_budget_mb", 32768)
     assert st_a["used_dense_path"] and st_b["used_dense_path"]
     assert _same_bits(a, b)
     # one full-width row per direction against the oracle (the right -> left pass at full size is compared nowhere else)
@@ -149,8 +149,8 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
     for v in range(NV):
         hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
     res = {}
-    for tag, generic, budget, staged, in_flight in (("two_stage", 0, 8192, 1, 0), ("two_stage_bands", 0, 64, 1, 0),
-                                                   ("gathering", 0, 8192, 0, 0), ("inline", 1, 8192, 1, 0)):
+    for tag, generic, budget, staged, in_flight in (("two_stage", 0, 32768, 1, 0), ("two_stage_bands", 0, 64, 1, 0),
+                                                   ("gathering", 0, 32768, 0, 0), ("inline", 1, 32768, 1, 0)):
         hip_ctx.set_option("force_generic", generic)
         hip_ctx.set_option("band_budget_mb", budget)
         hip_ctx.set_option("mvs_staged", staged)
@@ -162,7 +162,7 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
             evals.append(hip_ctx.stats()["n_eval"])
         res[tag] = (maps, evals)
     hip_ctx.set_option("force_generic", 0)
-    hip_ctx.set_option("band_budget_mb", 8192)
+    hip_ctx.set_option("band_budget_mb", 32768)
     hip_ctx.set_option("mvs_staged", 1)
     # the default: the calls only queue the views' kernels (two views in flight on two streams); the maps are complete
     # whenever they are looked at.  All four queued back to back, then read; the last call's counters are its own.
@@ -205,7 +205,7 @@ def test_c4_full_size(hip_ctx):
     for v in range(NV):
         hip_ctx.upload_view(v, rgba[v], masks[v], cams[v])
     res = {}
-    for tag, generic, budget in (("two_stage", 0, 8192), ("two_stage_bands", 0, 256), ("inline", 1, 8192)):
+    for tag, generic, budget in (("two_stage", 0, 32768), ("two_stage_bands", 0, 256), ("inline", 1, 32768)):
         hip_ctx.set_option("force_generic", generic)
         hip_ctx.set_option("band_budget_mb", budget)
         maps, evals = [], []
@@ -215,7 +215,7 @@ def test_c4_full_size(hip_ctx):
             evals.append(hip_ctx.stats()["n_eval"])
         res[tag] = (maps, evals)
     hip_ctx.set_option("force_generic", 0)
-    hip_ctx.set_option("band_budget_mb", 8192)
+    hip_ctx.set_option("band_budget_mb", 32768)
     for v in range(NV):
         for tag in ("two_stage_bands", "inline"):
             assert _same_bits(res["two_stage"][0][v], res[tag][0][v]), (tag, v)

@@ -95,7 +95,7 @@ def test_fused_band_split_and_row_range(hip_ctx):
     try:
         banded, st2 = _run(hip_ctx, 0, 1, p, 1)
     finally:
-        hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.set_option("band_budget_mb", 32768)
     assert st2["used_fused_kernel"] and np.array_equal(_bits(full), _bits(banded))
     hip_ctx.upload_depth(0, np.full_like(full, -7.0))
     hip_ctx.twoview_wta(0, 1, p, 11, 23)

@@ -186,7 +186,7 @@ def test_dense_path_matches_oracle_and_generic(hip_ctx, name, over):
             assert not st2["used_dense_path"] and st2["n_eval"] == diag["n_eval"]
         hip_ctx.set_option("force_generic", 0)
         hip_ctx.set_option("list_rows", 1)
-        hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.set_option("band_budget_mb", 32768)
         ok, msg, _ = cases.compare_depth(dense, want, RTOL)
         assert ok, "dense vs oracle (ref %d): %s" % (ref, msg)
         for tag, other in others.items():

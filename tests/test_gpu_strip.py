@@ -81,7 +81,7 @@ def test_strip_row_bands_and_small_budget(hip_ctx):
         assert hip_ctx.stats()["used_strip_kernel"]
         assert np.array_equal(hip_ctx.download_depth(0).view(np.uint64), full.view(np.uint64))
     finally:
-        hip_ctx.set_option("band_budget_mb", 8192)
+        hip_ctx.set_option("band_budget_mb", 32768)
         hip_ctx.set_option("strip", 1)
 
 
