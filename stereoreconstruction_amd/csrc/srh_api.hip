@@ -112,6 +112,9 @@ struct srh_context {
 	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
 	int list_smax_hint = 0;                             // most cost slots a pixel needed so far (run-blocked lists)
 	int mvs_cmax_hint = 0;                              // longest MultiViewStereo candidate list seen so far
+	// side stream of the row-run list path: the support windows are computed while the list kernel's last waves drain
+	hipStream_t side_stream = nullptr;
+	hipEvent_t side_go = nullptr, side_done = nullptr;
 	int mvs_async = 1;                                  // option "mvs_async": srh_mvs_initial_estimate queues a view on one of two side streams and returns (default); 0 = waits for each view
 	MvsSlot mvs_slot[2];
 	int mvs_turn = 0, mvs_last = -1;
@@ -476,6 +479,9 @@ extern "C" void srh_destroy(srh_context *c) {
 		if (S.stream) { hipStreamSynchronize(S.stream); }
 		S.pending = false;
 	}
+	if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+	if (c->side_go) hipEventDestroy(c->side_go);
+	if (c->side_done) hipEventDestroy(c->side_done);
 	drain_profile(c);
 	for (MvsSlot &S : c->mvs_slot) {
 		if (S.stream) hipStreamDestroy(S.stream);
@@ -902,11 +908,25 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 					if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 					const int nr = std::min((int)lrows, y1 - by);
 					int32_t *cnt_band = c->lcount + (size_t)(by - y0)*W;
-					run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
 					if (rows_mode) {
+						// The list kernel does not need the support windows, and its last waves drain for long (a wave walks
+						// its 64 curves for ~2 ms): the windows are computed on a side stream queued behind it -- the geodesic
+						// kernel's register-heavy waves only find room on a SIMD once the list kernel's have left it.
+						if (!c->side_stream) {
+							HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+							HIP_TRY(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
+							HIP_TRY(hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
+						}
+						HIP_TRY(hipEventRecord(c->side_go, c->stream));             // the window buffer's last readers are done by then
 						{ Scope s(c, "twoview_rows_list_kernel");
 						  launch_twoview_rows_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
 						                           cnt_band, c->lrowinfo, c->lmeta, smax, c->d_cnt, c->d_span, c->tnum); }
+						HIP_TRY(hipStreamWaitEvent(c->side_stream, c->side_go, 0));
+						std::swap(c->stream, c->side_stream);
+						run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+						std::swap(c->stream, c->side_stream);
+						HIP_TRY(hipEventRecord(c->side_done, c->side_stream));
+						HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
@@ -915,6 +935,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 						                           c->lrowinfo, c->lmeta, c->cost, smax); }
 						continue;
 					}
+					run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
 					{ Scope s(c, "twoview_list_kernel");
 					  launch_twoview_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
 					                      cnt_band, c->d_cnt, c->d_span, c->tnum); }
