@@ -65,6 +65,9 @@ struct ViewHost {
 struct ProfEntry { double ms = 0; int64_t n = 0; };
 struct PendingEvt { std::string name; hipEvent_t a, b; };
 
+#ifndef SRH_MVS_SLOTS
+#define SRH_MVS_SLOTS 2
+#endif
 // one MultiViewStereo estimate in flight (srh_mvs_initial_estimate, "two estimates in flight")
 struct MvsSlot {
 	hipStream_t stream = nullptr;
@@ -116,7 +119,7 @@ struct srh_context {
 	hipStream_t side_stream = nullptr;
 	hipEvent_t side_go = nullptr, side_done = nullptr;
 	int mvs_async = 1;                                  // option "mvs_async": srh_mvs_initial_estimate queues a view on one of two side streams and returns (default); 0 = waits for each view
-	MvsSlot mvs_slot[2];
+	MvsSlot mvs_slot[SRH_MVS_SLOTS];
 	int mvs_turn = 0, mvs_last = -1;
 	bool in_settle = false;
 	int mvs_staged = 1;                                 // option "mvs_staged": the list cost kernel takes its windows from LDS copies of the other view where they fit (default), 0 = gathers only
@@ -1253,7 +1256,7 @@ static int mvs_settle_slot(srh_context *c, int k) {
 static int mvs_settle_all(srh_context *c) {
 	if (c->in_settle) return SRH_OK;
 	int rc;
-	for (int k = 0; k < 2; ++k) if ((rc = mvs_settle_slot(c, k))) return rc;
+	for (int k = 0; k < SRH_MVS_SLOTS; ++k) if ((rc = mvs_settle_slot(c, k))) return rc;
 	return SRH_OK;
 }
 
@@ -1288,7 +1291,7 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 		if (c->mvs_async && !peaks_dev && !c->in_settle) {
 			// queue the view on the next slot and return
 			const int k = c->mvs_turn;
-			c->mvs_turn ^= 1;
+			c->mvs_turn = (c->mvs_turn + 1) % SRH_MVS_SLOTS;
 			MvsSlot &S = c->mvs_slot[k];
 			if ((rc = mvs_settle_slot(c, k))) return rc;
 			cmax = std::max(cmax, c->mvs_cmax_hint);
@@ -1296,7 +1299,7 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 				HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
 				HIP_TRY(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
 				HIP_TRY(hipHostMalloc((void **)&S.h_maxc, sizeof(int)));
-				S.own_buffers = k == 1;
+				S.own_buffers = k >= 1;
 				if (S.own_buffers) {
 					HIP_TRY(hipMalloc((void **)&S.d_cnt, sizeof(Counters)));
 					HIP_TRY(hipMalloc((void **)&S.d_span, 4*sizeof(int)));
