@@ -7,9 +7,11 @@ the TwoView cost-volume / support-weight / WTA path on synthetic 1920x1080x256 p
 A "step" is one pass of the hot path over one stereo pair per GPU: WTA left->right,
 WTA right->left, cross-check, and the device-side hand-over of the two depth maps
 (N>1: RCCL gather to rank 0).  Inputs are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line (contract in the task description).  N>1 is launched
-by torch.distributed.run, one rank per GPU; pairs are sharded (weak scaling), there
-is no data-path collective other than the final gather.
+Rank 0 prints ONE JSON line (contract in the task description).  N>1: one rank per GPU, either
+under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or,
+invoked plainly as `python bench.py --gpus N`, with this process starting the N ranks itself as
+child processes (self_launch); pairs are sharded (weak scaling), there is no data-path collective
+other than the final gather.
 
 --workload c4 is the MultiViewStereo configuration (8 views 1280x960, 128 levels, r=2): a step is
 runTask over all 8 views -- initial estimates, the all-gather of the depth maps (N>1: views are
@@ -483,6 +485,41 @@ def other_configs(args, rank, world, dev, dev_index, backend):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one -- before
+    anything here has initialised HIP or torch.cuda; a process that has touched the GPU is never exec'ed over -- with the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR 127.0.0.1, a free
+    MASTER_PORT).  Rank 0's stdout (the ONE JSON line) is passed through; the other ranks' stdout joins stderr.  If a
+    rank fails, the others are terminated (their exact PIDs) and its exit code is returned."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=None if r == 0 else sys.stderr))
+    code = 0
+    alive = list(procs)
+    while alive:
+        for pr in list(alive):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            alive.remove(pr)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 128 - rc
+                for other in alive:                               # a rank is gone: the others would wait in a collective for ever
+                    other.terminate()
+        if alive:
+            time.sleep(0.05)
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,9 +540,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (nothing here has touched HIP yet)
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
     import torch

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 3
+#define SRH_ABI_VERSION 4
 
 enum {
 	SRH_OK = 0,
@@ -91,7 +91,12 @@ typedef struct srh_stats {
 	int32_t used_dense_path; /* 1 if the row-aligned dense kernels ran */
 	int32_t used_fused_kernel; /* 1 if that was the single fused kernel (cost rows never leave the CU) */
 	int32_t used_strip_kernel; /* 1 if the cost kernel was the persistent strip form (srh_strip.hip) */
-	int32_t reserved;
+	int32_t band_retries;    /* runs repeated with thinner row bands after a band buffer did not fit (since srh_create) */
+	/* certified arithmetic (option "arith" = 3), last TwoView pass: reference pixels scanned on fused costs, and those of
+	 * them whose decisions the error bound did not cover and that were re-evaluated in the reference's arithmetic */
+	int64_t n_certified;
+	int64_t n_flagged;
+	int64_t band_budget_bytes;  /* band budget the last run worked with (requested, capped by free device memory) */
 } srh_stats;
 
 typedef struct srh_context srh_context;
@@ -164,7 +169,12 @@ int  srh_synchronize(srh_context *ctx);
  *                     turn (two views in flight); 0: one view at a time, the call returns when the view is done.
  *                     Either way the maps are complete whenever another entry point can observe them.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
- *   "band_budget_mb"  device scratch per row band (default 32768: a 1920x1080x256 refractive pair in one band) */
+ *   "band_budget_mb"  device scratch per row band the caller asks for (default 32768: a 1920x1080x256 refractive pair
+ *                     in one band).  A run never plans with more than a quarter of the device memory that is free at
+ *                     that moment (hipMemGetInfo), and a run whose band buffers still do not fit is repeated with the
+ *                     budget halved (srh_stats.band_retries) instead of failing: results do not depend on the split.
+ *   "mem_limit_mb"    pretend the device has at most this much memory to give (0 = off; tests of the above)
+ *   "debug_alloc_limit_mb"  refuse band buffers above this size as if the device were out of memory (0 = off; tests) */
 int  srh_set_option(srh_context *ctx, const char *name, long value);
 
 /* ---- views: what VectorImage::fromQImage + the mask test hold (util/vectorimage.cpp:48-64) ----

@@ -66,7 +66,8 @@ class Stats(C.Structure):
     """srh_stats"""
     _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
                 ("used_dense_path", C.c_int32), ("used_fused_kernel", C.c_int32),
-                ("used_strip_kernel", C.c_int32), ("reserved", C.c_int32)]
+                ("used_strip_kernel", C.c_int32), ("band_retries", C.c_int32),
+                ("n_certified", C.c_int64), ("n_flagged", C.c_int64), ("band_budget_bytes", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
@@ -159,6 +160,7 @@ def lib():
     L.srh_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.srh_comm_gather_depth.argtypes = [vp, C.c_int, C.c_int, vp]
     L.srh_comm_allgather_depth.argtypes = [vp, C.c_int, vp]
+    L.srh_comm_allgather_host.argtypes = [vp, c_double_p, C.c_size_t, c_double_p]
     L.srh_comm_destroy.argtypes = [vp]
     L.srh_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.srh_profile_enable.argtypes = [vp, C.c_int]
@@ -273,6 +275,7 @@ class Context:
         self._h = C.c_void_p()
         _check(lib().srh_create(device, C.byref(self._h)))
         self._keep = []
+        self._comm_ranks = 0
 
     def close(self):
         if self._h:
@@ -474,12 +477,20 @@ class Context:
 
     def comm_init(self, nranks, rank, unique_id):
         _check(lib().srh_comm_init(self._h, nranks, rank, C.c_char_p(unique_id)))
+        self._comm_ranks = nranks
 
     def comm_gather_depth(self, slot, root, recv_dev_ptr):
         _check(lib().srh_comm_gather_depth(self._h, slot, root, C.c_void_p(recv_dev_ptr)))
 
     def comm_allgather_depth(self, slot, recv_dev_ptr):
         _check(lib().srh_comm_allgather_depth(self._h, slot, C.c_void_p(recv_dev_ptr)))
+
+    def comm_allgather_host(self, send):
+        """Every rank contributes `send` (float64 host array), every rank receives ranks*len(send) values (host)."""
+        a = np.ascontiguousarray(send, dtype=np.float64).reshape(-1)
+        out = np.empty(a.size * max(1, self._comm_ranks), dtype=np.float64)
+        _check(lib().srh_comm_allgather_host(self._h, a.ctypes.data_as(c_double_p), a.size, out.ctypes.data_as(c_double_p)))
+        return out
 
     def comm_allgather_views(self, view_slots):
         """Sharded MultiViewStereo: every rank contributes the depth maps of its shard of `view_slots`, device to device."""
@@ -495,7 +506,8 @@ class Context:
         _check(lib().srh_get_stats(self._h, C.byref(s)))
         return dict(n_pixels=s.n_pixels, n_eval=s.n_eval, n_eval_device=s.n_eval_device,
                     used_dense_path=bool(s.used_dense_path), used_fused_kernel=bool(s.used_fused_kernel),
-                    used_strip_kernel=bool(s.used_strip_kernel))
+                    used_strip_kernel=bool(s.used_strip_kernel), band_retries=s.band_retries,
+                    n_certified=s.n_certified, n_flagged=s.n_flagged, band_budget_bytes=s.band_budget_bytes)
 
     def profile_enable(self, on=True):
         _check(lib().srh_profile_enable(self._h, int(on)))

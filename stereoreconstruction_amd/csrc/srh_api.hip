@@ -54,8 +54,10 @@ struct ViewHost {
 	// MultiViewStereo list path: the masked-in pixels (y*w + x) row by row, even rows left to right, odd rows right to
 	// left, so that consecutive entries are neighbours in the image also across a row change; act_row[y] = first entry of
 	// row y (h + 1 values).  A wave of the walk / cost kernels takes 64 consecutive entries.
-	uint32_t *act = nullptr;
-	std::vector<uint32_t> act_row;
+	uint32_t *act = nullptr; size_t act_cap = 0;
+	std::vector<uint32_t> act_row, act_host;
+	std::vector<uint8_t> hmask;    // host copy of the mask bytes (empty: no mask, every pixel counts): `act` is built from it
+	bool act_valid = false;        //   when the MultiViewStereo list path first asks (ensure_act); TwoView callers never pay for it
 	srh_camera cam;
 	// MRF branch over several views (srh_mvs_initial_estimate_peaks / srh_mvs_mrf_estimate_views)
 	double   *peaks = nullptr; size_t peaks_cap = 0; int peaks_k = 0;   // top-K peaks of the last initial estimate
@@ -71,7 +73,7 @@ struct PendingEvt { std::string name; hipEvent_t a, b; };
 // one MultiViewStereo estimate in flight (srh_mvs_initial_estimate, "two estimates in flight")
 struct MvsSlot {
 	hipStream_t stream = nullptr;
-	hipEvent_t ev = nullptr;
+	hipEvent_t ev = nullptr, done = nullptr;
 	int *h_maxc = nullptr;                              // pinned: longest list of the queued pass
 	bool own_buffers = false;                           // slot 1: its own band buffers, swapped into the context for its launches
 	double *wbuf = nullptr; size_t wbuf_cap = 0;
@@ -107,6 +109,7 @@ struct srh_context {
 	int mrf_w = 0, mrf_h = 0, mrf_k = 0;
 	double *pconst = nullptr; size_t pconst_cap = 0;    // per-pixel constants of the dense kernel's fast form (4 doubles per pixel of a band)
 	PixRange *prange = nullptr; size_t prange_cap = 0;  // per-pixel candidate column range of a band (strip kernel, scan)
+	uint32_t *cflag = nullptr; size_t cflag_cap = 0;    // certified arithmetic: [count | band pixels whose decisions the bound does not cover]
 	int strip = 1;                                      // option "strip": 1 = persistent strip cost kernel (default), 0 = one workgroup per tile, 4 / 8 = force the 4- / 8-wave form
 	int num_cus = 256;
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
@@ -129,7 +132,14 @@ struct srh_context {
 	uint32_t *lrowinfo = nullptr; size_t lrowinfo_cap = 0;
 	int32_t *lmeta = nullptr; size_t lmeta_cap = 0;
 	void *comm = nullptr; int comm_ranks = 0, comm_rank = 0;   // RCCL communicator (srh_comm_init)
-	size_t wbuf_budget = (size_t)32768 << 20;           // bytes per band of scratch (windows, cost rows, candidate lists): the GPU has 288 GB, and every band ends in the tail of its kernels
+	// bytes per band of scratch (windows, cost rows, candidate lists) the caller ASKS for: every band ends in the tails of
+	// its kernels, so the largest configuration should take one band where the device has the room (MI355X: 288 GB).
+	// What a run uses is band_budget(): this, capped by a share of the memory that is free right now, halved after an
+	// allocation failure (budget_cap).
+	size_t wbuf_budget = (size_t)32768 << 20;
+	size_t budget_cap = 0;                              // 0 = none; set by with_thinner_bands after an out-of-memory run
+	size_t budget_used = 0;                             // what band_budget() returned last
+	size_t mem_limit = 0;                               // option "mem_limit_mb": pretend the device has only this much free (tests)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
 	void *user = nullptr;
@@ -179,11 +189,27 @@ struct Scope {
 	}
 };
 
+// Band buffers grow on demand.  A request the device cannot serve is not the end of the call: g_oom tells the entry
+// point (with_thinner_bands below) to release the band buffers, halve the band budget and run again.
+// g_alloc_limit (option "debug_alloc_limit_mb") makes requests above a size fail the same way: the test of that path.
+static thread_local bool g_oom = false;
+static thread_local size_t g_alloc_limit = 0;
+
 template <class T>
 static int ensure(T *&ptr, size_t &cap, size_t need) {
 	if (cap >= need) return SRH_OK;
 	if (ptr) { HIP_TRY(hipFree(ptr)); ptr = nullptr; cap = 0; }
-	HIP_TRY(hipMalloc((void **)&ptr, need*sizeof(T)));
+	if (g_alloc_limit && need*sizeof(T) > g_alloc_limit) {
+		g_oom = true;
+		return fail(SRH_E_DEVICE, "band buffer of %zu bytes refused (debug_alloc_limit_mb)", need*sizeof(T));
+	}
+	const hipError_t e = hipMalloc((void **)&ptr, need*sizeof(T));
+	if (e != hipSuccess) {
+		ptr = nullptr;
+		(void)hipGetLastError();
+		if (e == hipErrorOutOfMemory) g_oom = true;
+		return fail(SRH_E_DEVICE, "hipMalloc of a %zu-byte band buffer: %s", need*sizeof(T), hipGetErrorString(e));
+	}
 	cap = need;
 	return SRH_OK;
 }
@@ -489,6 +515,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	for (MvsSlot &S : c->mvs_slot) {
 		if (S.stream) hipStreamDestroy(S.stream);
 		if (S.ev) hipEventDestroy(S.ev);
+		if (S.done) hipEventDestroy(S.done);
 		if (S.h_maxc) hipHostFree(S.h_maxc);
 		if (S.wbuf) hipFree(S.wbuf);
 		if (S.cost) hipFree(S.cost);
@@ -510,6 +537,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->tnum) hipFree(c->tnum);
 	if (c->pconst) hipFree(c->pconst);
 	if (c->prange) hipFree(c->prange);
+	if (c->cflag) hipFree(c->cflag);
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
 	for (int i = 0; i < SRH_MAX_VIEWS; ++i) if (c->mrf_stream[i]) hipStreamDestroy(c->mrf_stream[i]);
@@ -558,8 +586,12 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "band_budget_mb")) {
 		if (value < 1) return fail(SRH_E_INVALID, "band_budget_mb must be >= 1");
 		c->wbuf_budget = (size_t)value << 20;
+		c->budget_cap = 0;                                         // a new request: earlier out-of-memory halvings are forgotten
 		return SRH_OK;
 	}
+	// tests of the budget logic: pretend the device has only `value` MB to give / refuse band buffers above `value` MB
+	if (!strcmp(name, "mem_limit_mb")) { c->mem_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
+	if (!strcmp(name, "debug_alloc_limit_mb")) { g_alloc_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
 #ifdef SRH_EXPERIMENT
 	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
@@ -607,24 +639,8 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	HIP_TRY(hipMemcpyAsync(v.rgba, rgba, n*4, hipMemcpyHostToDevice, c->stream));
 	if (mask) HIP_TRY(hipMemcpyAsync(v.mask, mask, n, hipMemcpyHostToDevice, c->stream));
 	else      HIP_TRY(hipMemsetAsync(v.mask, 1, n, c->stream));
-	{
-		// serpentine list of the masked-in pixels (mask.pixel == WHITE <=> byte 1; no mask: every pixel)
-		std::vector<uint32_t> act;
-		act.reserve(n);
-		v.act_row.assign((size_t)h + 1, 0u);
-		for (int y = 0; y < h; ++y) {
-			v.act_row[y] = (uint32_t)act.size();
-			const uint8_t *mr = mask ? mask + (size_t)y*w : nullptr;
-			if (!(y & 1)) { for (int x = 0; x < w; ++x) if (!mr || mr[x] == 1) act.push_back((uint32_t)((size_t)y*w + x)); }
-			else          { for (int x = w - 1; x >= 0; --x) if (!mr || mr[x] == 1) act.push_back((uint32_t)((size_t)y*w + x)); }
-		}
-		v.act_row[h] = (uint32_t)act.size();
-		if (v.act) { HIP_TRY(hipFree(v.act)); v.act = nullptr; }
-		if (!act.empty()) {
-			HIP_TRY(hipMalloc((void **)&v.act, act.size()*sizeof(uint32_t)));
-			HIP_TRY(hipMemcpy(v.act, act.data(), act.size()*sizeof(uint32_t), hipMemcpyHostToDevice));
-		}
-	}
+	if (mask) v.hmask.assign(mask, mask + n); else v.hmask.clear();
+	v.act_valid = false;
 	{ Scope s(c, "prep_view_kernel"); launch_prep_view(c->stream, v.rgba, v.mask, w, h, v.gray, v.gray_tv); }
 	{ Scope s(c, "edge_planes_kernel"); launch_edge_planes(c->stream, v.rgba, w, h, v.edges); }
 	launch_fill(c->stream, v.depth, n, __builtin_nan(""));
@@ -694,8 +710,66 @@ extern "C" int srh_view_depth_copy_from_device(srh_context *c, int slot, const v
 }
 
 // ------------------------------------------------------------------ runs
+// bytes of device memory the band buffers hold now (they are re-used or re-allocated by the next run)
+static size_t held_band_bytes(const srh_context *c) {
+	size_t b = c->wbuf_cap*8 + c->cost_cap*8 + c->pconst_cap*8 + c->prange_cap*sizeof(PixRange) + c->lcount_cap*4 + c->lcand_cap*4
+	         + c->lrowinfo_cap*4 + c->lmeta_cap*4 + c->mvs_wdesc_cap*4 + c->mvs_nwin_cap*4 + c->cflag_cap*4;
+	for (const MvsSlot &S : c->mvs_slot)
+		b += S.wbuf_cap*8 + S.cost_cap*8 + S.lcount_cap*4 + S.lcand_cap*4 + S.mvs_wdesc_cap*4 + S.mvs_nwin_cap*4;
+	return b;
+}
+
+// The band budget of a run: what the caller asked for, but no more than a quarter of what the device can give right now
+// (free memory + what the band buffers already hold): the MultiViewStereo path treats the budget as a target (bands up
+// to 1.25x) and keeps two views' band buffers, the TwoView path adds the per-pixel constant planes.  A GPU shared with
+// other processes, several contexts on one GPU or a smaller device get thinner bands instead of an allocation failure.
+static size_t band_budget(srh_context *c) {
+	size_t b = c->wbuf_budget;
+	if (c->budget_cap && b > c->budget_cap) b = c->budget_cap;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+		size_t avail = free_b + held_band_bytes(c);
+		if (c->mem_limit && avail > c->mem_limit) avail = c->mem_limit;
+		if (b > avail/4) b = avail/4;
+	} else (void)hipGetLastError();
+	if (b < ((size_t)1 << 20)) b = (size_t)1 << 20;
+	c->budget_used = b;
+	return b;
+}
+
+static void release_band_buffers(srh_context *c) {
+	auto drop = [](auto *&p, size_t &cap) { if (p) (void)hipFree(p); p = nullptr; cap = 0; };
+	drop(c->wbuf, c->wbuf_cap); drop(c->cost, c->cost_cap); drop(c->pconst, c->pconst_cap); drop(c->prange, c->prange_cap);
+	drop(c->lcount, c->lcount_cap); drop(c->lcand, c->lcand_cap); drop(c->lrowinfo, c->lrowinfo_cap); drop(c->lmeta, c->lmeta_cap);
+	drop(c->mvs_wdesc, c->mvs_wdesc_cap); drop(c->mvs_nwin, c->mvs_nwin_cap); drop(c->cflag, c->cflag_cap);
+	for (MvsSlot &S : c->mvs_slot) {
+		drop(S.wbuf, S.wbuf_cap); drop(S.cost, S.cost_cap); drop(S.lcount, S.lcount_cap); drop(S.lcand, S.lcand_cap);
+		drop(S.mvs_wdesc, S.mvs_wdesc_cap); drop(S.mvs_nwin, S.mvs_nwin_cap);
+	}
+}
+
+// Run `body`; when it fails because a band buffer could not be allocated, wait for everything in flight, release the
+// band buffers, halve the band budget and run it again -- down to one-megabyte bands (a band is at least one image row).
+template <class F>
+static int with_thinner_bands(srh_context *c, F body) {
+	for (;;) {
+		g_oom = false;
+		const int rc = body();
+		if (rc != SRH_E_DEVICE || !g_oom) return rc;
+		g_oom = false;
+		const size_t used = c->budget_used;
+		if (used <= ((size_t)1 << 20)) return rc;                   // already the thinnest bands there are
+		for (MvsSlot &S : c->mvs_slot) if (S.stream) { (void)hipStreamSynchronize(S.stream); S.pending = false; }
+		if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+		(void)hipStreamSynchronize(c->stream);
+		release_band_buffers(c);
+		c->budget_cap = used/2;
+		c->stats.band_retries += 1;
+	}
+}
+
 static int band_rows(srh_context *c, int W, int H, int T) {
-	size_t rows = c->wbuf_budget / ((size_t)T*sizeof(double)*(size_t)W);
+	size_t rows = band_budget(c) / ((size_t)T*sizeof(double)*(size_t)W);
 	if (rows < 1) rows = 1;
 	if (rows > (size_t)H) rows = H;
 	return (int)rows;
@@ -785,9 +859,16 @@ static bool rig_is_row_aligned(const srh_camera &a, const srh_camera &b, double 
 	return true;
 }
 
+static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1);
+
 extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1) {
 	int rc;
 	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
+	return with_thinner_bands(c, [&] { return twoview_wta_run(c, ref, oth, p, y0, y1); });
+}
+
+static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1) {
+	int rc;
 	if (ref == oth) return fail(SRH_E_INVALID, "ref and other view are the same slot");
 	const ViewHost &L = c->views[ref], &Rv = c->views[oth];
 	if (L.w != Rv.w || L.h != Rv.h)
@@ -800,6 +881,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 	if (y1 <= y0) return SRH_OK;
 	const int R = p->window_radius;
 	const int T = (2*R + 1)*(2*R + 1);
+	const size_t budget = band_budget(c);
 
 	// ---- plan: dense row-aligned kernels, or the general curve-walk kernel
 	bool dense = !c->force_generic && (R == 5 || R == 2);
@@ -827,7 +909,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
 		{ Scope s(c, "pinhole_label_table_kernel");
 		  launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum); }
-		size_t rows = c->wbuf_budget / ((size_t)T*sizeof(double)*(size_t)W);
+		size_t rows = budget / ((size_t)T*sizeof(double)*(size_t)W);
 		if (rows < 1) rows = 1;
 		if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
 		if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)rows, T)))) return rc;
@@ -895,7 +977,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 				const int ccap = rows_mode ? smax : cmax;             // cost values per pixel
 				const size_t per_px = (size_t)T*sizeof(double) + (size_t)ccap*sizeof(double) + (size_t)cmax*sizeof(uint32_t)
 				                      + (rows_mode ? (SRH_ROWS_NR + 1)*sizeof(uint32_t) : 0);
-				size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
+				size_t lrows = budget / (per_px*(size_t)W);
 				if (lrows < 1) lrows = 1;
 				if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
 				if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
@@ -991,7 +1073,7 @@ extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_param
 		for (int pass = 0; pass < 2; ++pass) {
 			const int wdoubles = strip ? (2*R + 1)*wimg_wp(R) : T;     // doubles per pixel window in the band buffer
 			const size_t per_pixel = (size_t)wdoubles*sizeof(double) + (dense ? (size_t)cstride*sizeof(double) : 0);
-			rows = c->wbuf_budget / (per_pixel*(size_t)W);
+			rows = budget / (per_pixel*(size_t)W);
 			if (rows < 1) rows = 1;
 			if (rows > (size_t)(y1 - y0)) rows = (size_t)(y1 - y0);
 			// the strip kernel wants dozens of tiles per persistent workgroup and launch; thin bands take the per-tile kernel
@@ -1122,12 +1204,43 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t *neigh, int nneigh,
                                         const srh_params *p, int y0, int y1, void *peaks_dev);
 
+// The serpentine list of a view's masked-in pixels (mask.pixel == WHITE <=> byte 1; no mask: every pixel), built when the
+// MultiViewStereo list path first needs it after an upload.  The device buffer keeps its capacity across uploads.
+static int ensure_act(srh_context *c, ViewHost &v) {
+	if (v.act_valid) return SRH_OK;
+	const int w = v.w, h = v.h;
+	std::vector<uint32_t> &act = v.act_host;
+	act.clear();
+	act.reserve((size_t)w*h);
+	v.act_row.assign((size_t)h + 1, 0u);
+	for (int y = 0; y < h; ++y) {
+		v.act_row[y] = (uint32_t)act.size();
+		const uint8_t *mr = v.hmask.empty() ? nullptr : v.hmask.data() + (size_t)y*w;
+		if (!(y & 1)) { for (int x = 0; x < w; ++x) if (!mr || mr[x] == 1) act.push_back((uint32_t)((size_t)y*w + x)); }
+		else          { for (int x = w - 1; x >= 0; --x) if (!mr || mr[x] == 1) act.push_back((uint32_t)((size_t)y*w + x)); }
+	}
+	v.act_row[h] = (uint32_t)act.size();
+	if (!act.empty()) {
+		if (v.act_cap < act.size()) {
+			// (other streams may still read the old list: estimates of this view queued before the re-upload were settled by it)
+			if (v.act) { HIP_TRY(hipFree(v.act)); v.act = nullptr; v.act_cap = 0; }
+			HIP_TRY(hipMalloc((void **)&v.act, (size_t)w*h*sizeof(uint32_t)));
+			v.act_cap = (size_t)w*h;
+		}
+		HIP_TRY(hipMemcpyAsync(v.act, act.data(), act.size()*sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));                  // once per upload: either slot's stream may read it next
+	}
+	v.act_valid = true;
+	return SRH_OK;
+}
+
 // One pass of the list path of srh_mvs_initial_estimate for list capacity cmax: everything is queued on c->stream with
 // c's band buffers, nothing is waited for.  d_span[0] receives the longest list (slots), for the caller to compare with cmax.
 static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int nneigh, const srh_params *p, int y0, int y1,
                            void *peaks_dev, int cmax)
 {
 	int rc;
+	if ((rc = ensure_act(c, c->views[view]))) return rc;
 	const ViewHost &A = c->views[view];
 	const int W = A.w;
 	const int T = (2*p->window_radius + 1)*(2*p->window_radius + 1);
@@ -1144,7 +1257,7 @@ static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int n
 		HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
 		const size_t per_px = (size_t)T*sizeof(double) + (size_t)nneigh*((size_t)cmax*sizeof(uint32_t) + sizeof(int32_t) + 2*sizeof(double)
 		                      + (peaks_dev ? (size_t)p->top_k*2*sizeof(double) : 0));
-		size_t lrows = c->wbuf_budget / (per_px*(size_t)W);
+		size_t lrows = band_budget(c) / (per_px*(size_t)W);
 		if (lrows < 1) lrows = 1;
 		{
 			// the budget is a target, not a limit: no sliver band for a few rows over it, and bands of equal height
@@ -1260,8 +1373,19 @@ static int mvs_settle_all(srh_context *c) {
 	return SRH_OK;
 }
 
+static int mvs_initial_estimate_run(srh_context *c, int view, const int32_t *neigh, int nneigh,
+                                    const srh_params *p, int y0, int y1, void *peaks_dev);
+
 extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t *neigh, int nneigh,
                                         const srh_params *p, int y0, int y1, void *peaks_dev)
+{
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (c->in_settle) return mvs_initial_estimate_run(c, view, neigh, nneigh, p, y0, y1, peaks_dev);   // (the redo of a settle: its caller retries)
+	return with_thinner_bands(c, [&] { return mvs_initial_estimate_run(c, view, neigh, nneigh, p, y0, y1, peaks_dev); });
+}
+
+static int mvs_initial_estimate_run(srh_context *c, int view, const int32_t *neigh, int nneigh,
+                                    const srh_params *p, int y0, int y1, void *peaks_dev)
 {
 	int rc;
 	if ((rc = check_slot(c, view, true, false)) || (rc = check_params(p))) return rc;
@@ -1298,7 +1422,9 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 			if (!S.stream) {
 				HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
 				HIP_TRY(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+				HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
 				HIP_TRY(hipHostMalloc((void **)&S.h_maxc, sizeof(int)));
+				*S.h_maxc = 0;
 				S.own_buffers = k >= 1;
 				if (S.own_buffers) {
 					HIP_TRY(hipMalloc((void **)&S.d_cnt, sizeof(Counters)));
@@ -1307,17 +1433,30 @@ extern "C" int srh_mvs_initial_estimate(srh_context *c, int view, const int32_t 
 			}
 			HIP_TRY(hipEventRecord(S.ev, c->stream));                 // after whatever the caller's stream holds
 			HIP_TRY(hipStreamWaitEvent(S.stream, S.ev, 0));
+			*S.h_maxc = 0;                                             // (a queue that fails half-way must not leave a stale length behind)
 			mvs_slot_swap(c, S);
 			rc = mvs_list_launch(c, view, neigh, nneigh, p, y0, y1, nullptr, cmax);
 			if (!rc && hipMemcpyAsync(S.h_maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
 				rc = fail(SRH_E_DEVICE, "queueing the list-length read-back failed");
 			mvs_slot_swap(c, S);
-			S.pending = true;                                          // (also after a failure: the stream is drained before reuse)
+			if (rc) {
+				// nothing of this view counts: drain what was queued, the slot is free again
+				(void)hipStreamSynchronize(S.stream);
+				S.pending = false;
+				return rc;
+			}
+			// A caller-owned stream (srh_set_stream) keeps its contract: work the caller enqueues on it after this call
+			// is ordered after the estimate.  (The context's own stream needs no such edge: every entry point settles.)
+			if (c->stream != c->own_stream) {
+				HIP_TRY(hipEventRecord(S.done, S.stream));
+				HIP_TRY(hipStreamWaitEvent(c->stream, S.done, 0));
+			}
+			S.pending = true;
 			S.view = view; S.nneigh = nneigh; S.y0 = y0; S.y1 = y1; S.cmax = cmax; S.p = *p;
 			for (int i = 0; i < nneigh; ++i) S.neigh[i] = neigh[i];
 			c->mvs_last = k;
 			c->stats.used_dense_path = 0;
-			return rc;
+			return SRH_OK;
 		}
 		if ((rc = mvs_settle_all(c))) return rc;
 		for (int pass = 0; pass < 3; ++pass) {
@@ -1726,6 +1865,9 @@ extern "C" int srh_comm_allgather_host(srh_context *c, const double *send_host, 
 	if (!c->comm) return fail(SRH_E_INVALID, "srh_comm_init has not been called");
 	HIP_TRY(hipSetDevice(c->device));
 	int rc;
+	// the staging below is the band scratch, which a queued MultiViewStereo estimate (slot 0) still reads its support
+	// windows from on its own stream: finish the estimates in flight first, like every other entry point
+	if ((rc = mvs_settle_all(c))) return rc;
 	// staging in the band scratch (free between runs): [send | recv]
 	if ((rc = ensure(c->wbuf, c->wbuf_cap, count*(size_t)(c->comm_ranks + 1)))) return rc;
 	HIP_TRY(hipMemcpyAsync(c->wbuf, send_host, count*sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1789,6 +1931,7 @@ extern "C" int srh_get_stats(srh_context *c, srh_stats *out) {
 	if (rc) return rc;
 	rc = fetch_counters(c, c->stats.used_dense_path);
 	if (rc) return rc;
+	c->stats.band_budget_bytes = (int64_t)c->budget_used;
 	*out = c->stats;
 	return SRH_OK;
 }

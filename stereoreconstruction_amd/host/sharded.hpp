@@ -74,6 +74,13 @@ private:
 	std::vector<double> buf_, out_;
 };
 
+// Engines whose initialEstimate only QUEUES a view (HipViewEngine: two estimates in flight) offer finish(): wait for the
+// queued estimates and say whether all of them succeeded.  Engines without the member are complete when the call returns.
+template <class Engine>
+auto finishEstimates(Engine &e, int) -> decltype(e.finish()) { return e.finish(); }
+template <class Engine>
+bool finishEstimates(Engine &, long) { return true; }
+
 // MultiViewStereo::runTask for the shard `rank` of `t.ranks()`.  Engine: viewSize(v) -> pixels, initialEstimate(v),
 // getDepth(v, double*), setDepth(v, const double*), crossCheck(v); all return false on error.  Views may differ
 // in size: maps travel padded with NaN to the largest view.  Returns false on an engine / transport error.
@@ -85,6 +92,9 @@ bool runMultiView(Engine &e, int nviews, Transport *t, int rank, std::vector<int
 	if (mine) { mine->clear(); for (int v = lo; v < hi; ++v) mine->push_back(v); }
 	bool ok = true;
 	for (int v = lo; v < hi && ok; ++v) ok = e.initialEstimate(v);               // multiviewstereo.cpp:365-376
+	// a queued estimate reports a device error, or the failure of its cut-list redo, only when it is waited for: the status
+	// below must cover that -- a shard that learnt of it inside the map exchange would leave the others in the collective
+	ok = finishEstimates(e, 0) && ok;
 	if (world > 1) {
 		// every shard says whether its estimates succeeded BEFORE the maps travel: a shard that failed must not leave
 		// the others waiting in the collective for ever -- all of them return false together
@@ -173,6 +183,7 @@ public:
 	bool ok() const { return ok_; }
 	size_t viewSize(int v) const { int w = 0, h = 0; srh_view_size(ctx_, v, &w, &h); return static_cast<size_t>(w)*h; }
 	bool initialEstimate(int v) { return srh_mvs_initial_estimate(ctx_, v, &neigh_[static_cast<size_t>(v)*nn_], count_[v], &p_, 0, 0, nullptr) == SRH_OK; }
+	bool finish() { return srh_synchronize(ctx_) == SRH_OK; }                     // settles the estimates in flight (capacity check, redo)
 	bool getDepth(int v, double *out) { return srh_view_depth_download(ctx_, v, out) == SRH_OK; }
 	bool setDepth(int v, const double *in) { return srh_view_depth_upload(ctx_, v, in) == SRH_OK; }
 	bool crossCheck(int v) { return srh_mvs_cross_check(ctx_, slots_.data(), static_cast<int>(slots_.size()), v, &p_) == SRH_OK; }

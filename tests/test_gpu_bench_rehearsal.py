@@ -47,3 +47,23 @@ def test_two_rank_pairs_and_row_bands():
 def test_two_rank_multiview():
     c = _bench2(["--workload", "c4"], {"SRH_BENCH_C4_SMALL": "1"})
     assert c["n_gpus"] == 2 and c["scaling"] == "strong" and c["value"] > 0
+
+
+def test_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2`, plainly: bench.py starts its two ranks itself (child processes, before anything in the
+    parent has touched the GPU), rank 0's single JSON line comes through on stdout, the exit status is the ranks'."""
+    env = dict(os.environ, SRH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-rows", "0",
+           "--workload", "small"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    a = json.loads(lines[0])
+    assert a["n_gpus"] == 2 and a["steps"] == 2 and a["scaling"] == "weak" and a["value"] > 0
+    # a failing rank takes the launch down with its exit code instead of leaving the others in a collective
+    bad = subprocess.run(cmd, cwd=ROOT, env=dict(env, SRH_LIBRARY="/nonexistent/libstereo_recon_hip.so"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

@@ -169,3 +169,38 @@ def test_one_rank_native_view_exchange(hip_ctx):
             assert np.array_equal(hip_ctx.download_depth(v).view(np.uint64), before[v].view(np.uint64))
     finally:
         hip_ctx.comm_destroy()
+
+
+def test_host_allgather_waits_for_the_estimates_in_flight(hip_ctx):
+    """srh_comm_allgather_host stages [send | recv] in the band scratch -- the buffer a queued MultiViewStereo estimate
+    (slot 0 of the two in flight) reads its support windows from on its own stream.  sharded::runMultiView calls it right
+    after queueing its views (the status word), with no other entry point in between: the maps must equal those of
+    one-view-at-a-time runs bit for bit, i.e. the exchange has to finish the estimates first."""
+    from stereoreconstruction_amd import capi
+    case = cases.get_mvs("mvs_geodesic", nviews=3, w=320, h=240, D=48)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    neigh = capi.mvs_neighbours(cams, p)
+    hip_ctx.set_option("mvs_async", 0)
+    try:
+        for v in range(3):
+            hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+        want = [hip_ctx.download_depth(v) for v in range(3)]
+    finally:
+        hip_ctx.set_option("mvs_async", 1)
+    try:
+        hip_ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+    except capi.StereoHipError as e:
+        if e.code == capi.SRH_E_UNSUPPORTED:
+            pytest.skip("librccl not available")
+        raise
+    try:
+        payload = np.arange(1 << 21, dtype=np.float64)                 # 16 MB over the start of the band scratch, twice
+        for v in range(3):
+            hip_ctx.mvs_initial_estimate(v, neigh[v], p)               # only queued
+        back = hip_ctx.comm_allgather_host(payload)
+        assert np.array_equal(back, payload)
+        for v in range(3):
+            assert np.array_equal(hip_ctx.download_depth(v).view(np.uint64), want[v].view(np.uint64)), v
+    finally:
+        hip_ctx.comm_destroy()

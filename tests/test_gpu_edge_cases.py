@@ -255,3 +255,71 @@ def test_mvs_estimates_in_flight_interleaved_with_other_calls(hip_ctx):
             assert np.array_equal(ctx.download_depth(v).view(np.uint64), want_cc[v].view(np.uint64)), v
     finally:
         ctx.close()
+
+
+def _bits(a):
+    return a.view(np.uint64)
+
+
+def test_band_budget_follows_free_memory_and_survives_allocation_failures(hip_ctx):
+    """The band budget is a request: a run plans with at most a quarter of the device memory that is free (option
+    mem_limit_mb pretends there is little), and a run whose band buffers are refused (debug_alloc_limit_mb: as if the
+    device were out of memory) is repeated with thinner bands instead of failing.  Same bits either way: TwoView dense,
+    TwoView candidate lists (refractive), MultiViewStereo list path."""
+    tv = cases.get_twoview("geodesic_masks", w=160, h=96, D=24)
+    rf = cases.get_twoview("adaptive_refractive", w=128, h=80, D=20, radius=5)
+    mv = cases.get_mvs("mvs_geodesic", nviews=3, w=128, h=96, D=24)
+
+    def run_all():
+        out = []
+        for case in (tv, rf):
+            cams, p = cases.hip_inputs(case)
+            cases.upload_case(hip_ctx, case, cams)
+            hip_ctx.twoview_wta(0, 1, p)
+            out.append(hip_ctx.download_depth(0))
+        cams, p = cases.hip_inputs(mv)
+        cases.upload_case(hip_ctx, mv, cams)
+        neigh = capi.mvs_neighbours(cams, p)
+        for v in range(3):
+            hip_ctx.mvs_initial_estimate(v, neigh[v], p)
+        out += [hip_ctx.download_depth(v) for v in range(3)]
+        return out
+
+    want = run_all()
+    st0 = hip_ctx.stats()
+    assert 0 < st0["band_budget_bytes"] <= 32768 << 20
+    try:
+        hip_ctx.set_option("mem_limit_mb", 16)                    # a quarter of it: 4 MB bands
+        got = run_all()
+        st = hip_ctx.stats()
+        assert st["band_budget_bytes"] == 4 << 20 and st["band_retries"] == st0["band_retries"]
+        for a, b in zip(want, got):
+            assert np.array_equal(_bits(a), _bits(b))
+        hip_ctx.set_option("mem_limit_mb", 0)
+        hip_ctx.set_option("band_budget_mb", 32768)
+        hip_ctx.set_option("debug_alloc_limit_mb", 2)             # every band buffer above 2 MB is "out of memory"
+        got = run_all()
+        st = hip_ctx.stats()
+        assert st["band_retries"] > st0["band_retries"] and st["band_budget_bytes"] < 64 << 20
+        for a, b in zip(want, got):
+            assert np.array_equal(_bits(a), _bits(b))
+    finally:
+        hip_ctx.set_option("debug_alloc_limit_mb", 0)
+        hip_ctx.set_option("mem_limit_mb", 0)
+        hip_ctx.set_option("band_budget_mb", 32768)               # (forgets the halvings)
+
+
+def test_two_contexts_share_one_gpu(hip_ctx):
+    """A second context on the same GPU (a GUI host beside a batch job, the loopback transport's shards): each plans its
+    bands from what is free when it runs; both give the same bits."""
+    case = cases.get_twoview("geodesic_masks", w=160, h=96, D=24)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    a_l, a_r = hip_ctx.twoview_compute(0, 1, p)
+    with capi.Context(0) as other:
+        cases.upload_case(other, case, cams)
+        b_l, b_r = other.twoview_compute(0, 1, p)
+        c_l, c_r = hip_ctx.twoview_compute(0, 1, p)               # interleaved with the other context's buffers alive
+        assert other.stats()["band_budget_bytes"] > 0
+    assert np.array_equal(_bits(a_l), _bits(b_l)) and np.array_equal(_bits(a_r), _bits(b_r))
+    assert np.array_equal(_bits(a_l), _bits(c_l)) and np.array_equal(_bits(a_r), _bits(c_r))

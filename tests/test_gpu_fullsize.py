@@ -93,9 +93,26 @@ def test_c5_refractive_rows_equal_ordered_lists(hip_ctx):
     assert np.allclose(res["rows"][y], want[y], rtol=1e-9, equal_nan=True)
 
 
+def _oracle_rows(li, ri, cl, cr, op, rows):
+    """One-row oracle WTA passes on a thread pool (the C oracle runs outside the GIL): {y: row of the map}."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, len(rows))) as ex:
+        maps = list(ex.map(lambda y: O.twoview_wta(li, ri, cl, cr, op, y, y + 1)[y], rows))
+    return dict(zip(rows, maps))
+
+
+def _assert_rows(got, want_rows, tag):
+    for y, want in want_rows.items():
+        ok, msg, _ = cases.compare_depth(got[y], want, 1e-9)
+        assert ok, (tag, y, msg)
+
+
 def test_c3_full_size_band_invariance(hip_ctx):
     """C3: 1920x1080, 256 levels, GeodesicWeight r=5: the depth map must not depend on the band
-    split (one band at the default 8 GB budget vs ~50 bands at 128 MB), left->right pass."""
+    split (one band at the default 32 GB budget vs ~50 bands at 128 MB), left->right pass.  Then, through the STRIP
+    kernel: an interior row and the border rows 0, 3, H-4, H-1 of both directions against the oracle (rows within R
+    of the top / bottom take the select form and the phase-2 work lists), and the whole left / right cross-check
+    (twoviewstereo.cpp:596-672) against the oracle's pass over the same two maps."""
     W, H, D = 1920, 1080, 256
     (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
     hip_ctx.set_option("band_budget_mb", 32768)
@@ -111,23 +128,26 @@ def test_c3_full_size_band_invariance(hip_ctx):
     hip_ctx.set_option("band_budget_mb", 32768)
     assert st_a["used_dense_path"] and st_b["used_dense_path"]
     assert _same_bits(a, b)
-    # one full-width row per direction against the oracle (the right -> left pass at full size is compared nowhere else)
     hip_ctx.twoview_wta(1, 0, p)
     ar = hip_ctx.download_depth(1)
+    assert hip_ctx.stats()["used_strip_kernel"]
     (Kl, Rl, tl), (Kr, Rr, tr) = cams3
     li, ri, cl, cr = O.OImage(L, ml), O.OImage(R, mr), O.camera_set(Kl, Rl, tl), O.camera_set(Kr, Rr, tr)
-    y = H // 2 + 7
-    want_l = O.twoview_wta(li, ri, cl, cr, op, y, y + 1)
-    want_r = O.twoview_wta(ri, li, cr, cl, op, y, y + 1)
-    for got, want, tag in ((a, want_l, "left->right"), (ar, want_r, "right->left")):
-        same_cls = (np.isnan(got[y]) == np.isnan(want[y])) & (np.isinf(got[y]) == np.isinf(want[y]))
-        fin = np.isfinite(got[y]) & np.isfinite(want[y])
-        assert same_cls.all(), tag
-        assert np.all(np.abs(got[y][fin] - want[y][fin]) <= 1e-9*np.maximum(1.0, np.abs(want[y][fin]))), tag
+    rows = [0, 3, H // 2 + 7, H - 4, H - 1]
+    _assert_rows(a, _oracle_rows(li, ri, cl, cr, op, rows), "left->right")
+    _assert_rows(ar, _oracle_rows(ri, li, cr, cl, op, rows), "right->left")
     assert st_a["n_eval"] == st_b["n_eval"] and st_a["n_pixels"] == W * H
     # every reference pixel got a verdict: finite depth or +INF (ratio test); NaN only without candidates
     assert np.isnan(a).mean() < 0.01
     assert np.isfinite(a).mean() > 0.3
+    # the order-dependent cross-check at full size: the oracle's two passes over the device's WTA maps
+    want_l, want_r = O.twoview_cross_check(cl, cr, op, a, ar)
+    hip_ctx.twoview_wta(0, 1, p)                          # (view 0 holds the 50-band map: the same bits, but be plain)
+    hip_ctx.twoview_cross_check(0, 1, p)
+    for got, want, tag in ((hip_ctx.download_depth(0), want_l, "left"), (hip_ctx.download_depth(1), want_r, "right")):
+        ok, msg, _ = cases.compare_depth(got, want, 1e-9)
+        assert ok, ("cross-check", tag, msg)
+    assert np.isnan(want_l[np.isfinite(a)]).any()         # the cross-check rejects something
 
 
 def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
@@ -277,10 +297,9 @@ def test_c5_full_size(hip_ctx, seed):
     op = O.params_twoview(**kw)
     oc = [O.camera_set(Kl, Rl, tl, None, *plane), O.camera_set(Kr, Rr, tr, None, *plane)]
     oi = [O.OImage(L, ml), O.OImage(R, mr)]
-    for ref, oth, y in ((0, 1, H // 2), (1, 0, H // 3)):
-        want = O.twoview_wta(oi[ref], oi[oth], oc[ref], oc[oth], op, y, y + 1)
-        ok, msg, _ = _cmp(res["rows"][ref][0][y], want[y])
-        assert ok, (ref, y, msg)
+    # an interior row and the border rows (windows cut by the image's top / bottom: the blocked select form)
+    for ref, oth, rows in ((0, 1, [0, 3, H // 2, H - 1]), (1, 0, [0, H // 3, H - 4, H - 1])):
+        _assert_rows(res["rows"][ref][0], _oracle_rows(oi[ref], oi[oth], oc[ref], oc[oth], op, rows), (hex(seed), ref))
 
 
 def test_c5_full_size_tilted_interface(hip_ctx):
