@@ -489,7 +489,7 @@ def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one -- before
     anything here has initialised HIP or torch.cuda; a process that has touched the GPU is never exec'ed over -- with the
     environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR 127.0.0.1, a free
-    MASTER_PORT).  Rank 0's stdout (the ONE JSON line) is passed through; the other ranks' stdout joins stderr.  If a
+    MASTER_PORT).  Rank 0's JSON line is passed through on stdout; everything else the ranks print joins stderr.  If a
     rank fails, the others are terminated (their exact PIDs) and its exit code is returned."""
     import socket
     import subprocess
@@ -502,7 +502,16 @@ def self_launch(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+
+    def pump(stream):
+        # stdout carries the JSON line and nothing else: what libraries print there (gloo's connection notes) joins stderr
+        for line in stream:
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+    import threading
+    reader = threading.Thread(target=pump, args=(procs[0].stdout,), daemon=True)
+    reader.start()
     code = 0
     alive = list(procs)
     while alive:
@@ -517,6 +526,7 @@ def self_launch(n):
                     other.terminate()
         if alive:
             time.sleep(0.05)
+    reader.join(timeout=10)
     return code
 
 
