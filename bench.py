@@ -65,33 +65,40 @@ NO_FMA_CEILING_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12   # separate v_mul_f64 / v_ad
 SUSTAINED_NO_FMA_TLANE = 34.5                        # measured: profiles/microbench/fp64_sustained (2 waves/SIMD, 2344 MHz held under load)
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/), or None."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def _pmc_section(fname, workload, mode):
+    """The section of a committed PMC summary (profiles/) for this workload and arithmetic -- only if it was collected on
+    the very build of the library that is loaded now (srh_build_id): counts of another build are not evidence for this run."""
     try:
-        t = json.load(open(tpath))
-        return t.get(workload, {}).get(kernel) or t.get(workload + "_fused", {}).get(kernel)
+        t = json.load(open(os.path.join(ROOT, "profiles", fname)))
     except Exception:
         return None
+    sec = t.get(workload if mode in ("certified", None) else workload + "_" + mode)
+    if not isinstance(sec, dict) or sec.get("_build_id") != capi.build_id():
+        return None
+    return sec
 
 
-def pmc_executed(workload, kernel, avg_launch_ms):
+def pmc_traffic(workload, kernel, mode=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json), or None."""
+    sec = _pmc_section("pmc_traffic.json", workload, mode)
+    return sec.get(kernel) if sec else None
+
+
+def pmc_executed(workload, kernel, avg_launch_ms, mode=None):
     """What the kernel EXECUTES, from the committed rocprofv3 --pmc instruction counts (profiles/pmc_instr.json:
-    SQ_INSTS_VALU_MUL_F64 + ADD_F64 wave-instructions per launch, x64 lanes) over the launch time measured live,
-    against the no-contraction ceiling (separate multiply and add: half the FMA datasheet rate)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_instr.json")))
-        e = t.get(workload, {}).get(kernel) or t.get(workload + "_fused", {}).get(kernel)
-    except Exception:
-        e = None
+    SQ_INSTS_VALU_MUL_F64 + ADD_F64 + FMA_F64 wave-instructions per launch, x64 lanes) over the launch time measured
+    live, against the FP64 issue ceiling (one instruction per lane and clock, fused or not: 39.3 T lane-op/s)."""
+    sec = _pmc_section("pmc_instr.json", workload, mode)
+    e = sec.get(kernel) if sec else None
     if not e:
         return None
-    lane_ops = 64.0 * (e["mul_f64"] + e["add_f64"])
+    lane_ops = 64.0 * (e["mul_f64"] + e["add_f64"] + e.get("fma_f64", 0))
     rate = lane_ops / (avg_launch_ms * 1e-3) / 1e12
-    return {"mul_add_f64_lane_ops_per_launch": round(lane_ops), "rate": round(rate, 3), "unit": "T lane-op/s",
+    return {"f64_lane_ops_per_launch": round(lane_ops), "rate": round(rate, 3), "unit": "T lane-op/s",
             "ceiling": round(NO_FMA_CEILING_TLANE, 2), "frac": round(rate / NO_FMA_CEILING_TLANE, 4),
             "sustained_ceiling": SUSTAINED_NO_FMA_TLANE, "frac_of_sustained": round(rate / SUSTAINED_NO_FMA_TLANE, 4),
-            "fma_f64_wave_instr_per_launch": e.get("fma_f64")}
+            "wave_instr_per_launch": {k: e.get(k) for k in ("mul_f64", "add_f64", "fma_f64", "valu")},
+            "pmc_build_id": sec.get("_build_id")}
 
 
 def host_cpu():
@@ -177,7 +184,7 @@ def run_c4(args, rank, world, dev, dev_index, backend):
         hbm = alg_bytes / (ms * 1e-3) / 1e9
         result = {
             "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(hyp_per_step * args.steps / dt / 1e6, 3),
-            "unit": "Mhyp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "Mhyp/s", "build_id": capi.build_id(), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + "; initial estimates + depth-map all-gather + ordered cross-check",
@@ -301,15 +308,19 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
     ctx.upload_view(0, L, ml, cl)
     ctx.upload_view(1, R, mr, cr)
     mismatch = None
-    if args.arith in ("fma", "f32"):
-        if workload in ("c1", "c4", "c5"):
-            sys.exit("--arith fma applies to the dense row-aligned TwoView path (c2, c3, small)")
+    if args.arith in ("fma", "f32") and workload in ("c1", "c4", "c5"):
+        sys.exit("--arith fma / f32 apply to the dense row-aligned TwoView path (c2, c3, small)")
+    arith_code = {"certified": capi.ARITH_CERTIFIED, "exact": capi.ARITH_EXACT, "fma": capi.ARITH_FMA, "f32": capi.ARITH_F32}[args.arith]
+    if args.arith != "exact" and workload not in ("c1", "c5"):
+        # untimed: the same pass in the reference's arithmetic, to count the depths the chosen arithmetic changes
+        # (certified: must be 0 -- it is the parity mode; fma / f32: the measured winner-mismatch rate)
+        ctx.set_option("arith", capi.ARITH_EXACT)
         ctx.twoview_wta(0, 1, p)
         exact_l = ctx.download_depth(0)
-        ctx.set_option("arith", 1 if args.arith == "fma" else 2)
+        ctx.set_option("arith", arith_code)
         ctx.twoview_wta(0, 1, p)
-        fma_l = ctx.download_depth(0)
-        mismatch = float((exact_l.view(np.uint64) != fma_l.view(np.uint64)).mean())
+        mismatch = float((exact_l.view(np.uint64) != ctx.download_depth(0).view(np.uint64)).mean())
+    ctx.set_option("arith", arith_code)
     # Depth hand-over: both maps are copied device-to-device into a staging tensor; with N > 1 ranks they are
     # gathered on rank 0 (RCCL over xGMI).  The gather of step k runs while step k+1 computes (two staging
     # buffers, async collective); everything is drained inside the timed region by fence().
@@ -375,6 +386,11 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
 
     prof = ctx.profile()
     stats = ctx.stats()
+    certified = None
+    if stats["n_certified"]:
+        # (the last pass of the timed steps: right -> left)
+        certified = {"pixels_scanned_on_fused_costs": stats["n_certified"], "flagged_and_redone_exactly": stats["n_flagged"],
+                     "flagged_frac": round(stats["n_flagged"] / stats["n_certified"], 8)}
     hyp_per_step_per_gpu = 2 * W * H * D
     value = (1 if rows_shard else world) * hyp_per_step_per_gpu * args.steps / dt / 1e6
 
@@ -394,11 +410,12 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         flops_per_step = hyp_per_step_per_gpu * (15.0 * T + 8) * share
         valu_achieved = flops_per_step * args.steps / (ms * 1e-3) / 1e12
         # the PMC files were collected on the exact mode: no traffic / instruction figures are claimed for the opt-in modes
-        traffic = pmc_traffic(workload, name) if args.arith == "exact" else None
+        pmc_mode = args.arith if stats["n_certified"] or args.arith != "certified" else "exact"   # what the dominant kernel really ran
+        traffic = pmc_traffic(workload, name, pmc_mode)
         VALU_PEAK = 157.3 if args.arith == "f32" else FP64_VALU_PEAK_TFLOPS
         result = {
             "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(value, 3), "unit": "Mhyp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "build_id": capi.build_id(), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if rows_shard else "weak", "vs_baseline": None,
             "dtype": ("f32" if args.arith == "f32" else "f64"), "data": "synthetic" if workload != "c1" else "fixture (example project's bunny pair, Qt-scaled)",
@@ -408,9 +425,13 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
                        "pairs_per_gpu": 1, "parallelism": (("ONE pair in %d row bands, %s gather to rank 0, cross-check there" if rows_shard else "%.0s pairs sharded, %s gather")
                                                            % (world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                        "dense_path": bool(stats["used_dense_path"]),
-                       "arithmetic": ("exact: the reference's operation order, no contraction (bit parity)" if args.arith == "exact"
-                                      else "fma: multiply-adds of the cost loops fused (opt-in, NOT the parity mode)" if args.arith == "fma"
+                       "arithmetic": ("certified (default): fused multiply-adds in the strip kernel's cost loops, every WTA decision checked "
+                                      "against a proven error bound, uncovered pixels redone in the reference's arithmetic -- same bits as "
+                                      "'exact' (DESIGN.md 2b); kernels without a fused form run the reference's arithmetic" if args.arith == "certified"
+                                      else "exact: the reference's operation order, no contraction, everywhere" if args.arith == "exact"
+                                      else "fma: multiply-adds of the cost loops fused, UNCHECKED (opt-in, NOT a parity mode)" if args.arith == "fma"
                                       else "f32: cost loops in packed single precision (opt-in, NOT the parity mode, NOT the reference's precision)"),
+                       "certified_scan": certified,
                        "winner_mismatch_vs_exact": mismatch,
                        "n_eval_reference_last_pass": stats["n_eval"],
                        "n_eval_device_last_pass": stats["n_eval_device"]},
@@ -423,7 +444,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
             "roofline": {"bound": "valu_fp32" if args.arith == "f32" else "valu_fp64", "kernel": name,
                          "achieved": round(valu_achieved, 3), "peak": VALU_PEAK, "unit": "TFLOP/s",
                          "frac": round(valu_achieved / VALU_PEAK, 5), "traffic": traffic,
-                         "executed": pmc_executed(workload, name, avg_ms) if args.arith == "exact" else None,
+                         "executed": pmc_executed(workload, name, avg_ms, pmc_mode),
                          "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                          "alg_flops_per_launch": round(flops_per_step * args.steps / launches),
                          "flops_per_hyp": 15 * T + 8,
@@ -537,9 +558,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the CPU-baseline band (0 = skip)")
-    ap.add_argument("--arith", default="exact", choices=["exact", "fma", "f32"],
-                    help="exact (default): the reference's arithmetic, bit parity; fma: opt-in fused multiply-add in the "
-                         "dense cost loops -- the winner-mismatch rate against the exact mode is measured and reported")
+    ap.add_argument("--arith", default="certified", choices=["certified", "exact", "fma", "f32"],
+                    help="certified (default, the library's default): fused multiply-adds with every decision checked against an "
+                         "error bound -- the exact mode's bits; exact: the reference's arithmetic operation by operation; fma / f32: "
+                         "opt-in unchecked modes -- their winner-mismatch rate against the exact mode is measured and reported")
     ap.add_argument("--shard", default="pairs", choices=["pairs", "rows"],
                     help="N > 1, TwoView workloads: 'pairs' (default) = one pair per GPU, weak scaling; 'rows' = ONE pair cut "
                          "into N row bands, bands gathered on rank 0, cross-check there: strong scaling")
@@ -580,7 +602,7 @@ def main():
         return
 
     result = run_twoview(args, args.workload, rank, world, dev, dev_index, backend)
-    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_configs and args.arith == "exact":
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_configs and args.arith in ("certified", "exact"):
         result["configs"] = other_configs(args, rank, world, dev, dev_index, backend)
     if world > 1:
         dist.barrier()

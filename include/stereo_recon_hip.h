@@ -107,6 +107,8 @@ typedef void (*srh_progress_fn)(int step, const char *stage, void *user);
 
 /* ---- library ---- */
 int         srh_abi_version(void);
+/* 16 hex digits: hash of the library's sources at build time (which build produced a measurement) */
+const char *srh_build_id(void);
 const char *srh_last_error(void);
 int         srh_device_count(int *count);
 /* Hardware queues the HIP runtime was asked for (GPU_MAX_HW_QUEUES in the process environment, else the runtime's
@@ -143,19 +145,23 @@ void srh_destroy(srh_context *ctx);
 int  srh_set_stream(srh_context *ctx, void *hip_stream);
 int  srh_set_hooks(srh_context *ctx, const volatile int *cancel, srh_progress_fn progress, void *user);
 int  srh_synchronize(srh_context *ctx);
-/* Tuning / test switches (results never depend on them, "arith" excepted):
+/* Tuning / test switches (results never depend on them, "arith" = 1 / 2 excepted):
  *   "force_generic"   0 default paths; 1 never the dense row-aligned TwoView kernels nor the MVS list kernels;
  *                     2 additionally no candidate lists at all (one thread per pixel walks and costs its curve)
  *   "fused"           1: row-aligned pairs run the single fused kernel (geometry + cost + WTA per 16-pixel tile
  *                     in LDS: no cost rows or candidate lists in device memory); 0 (default): the three-kernel form
  *                     (cost rows staged in device memory, separate scan), which is the faster one on MI355X today
- *   "arith"           0 (default): the reference's arithmetic, operation by operation (bit parity).  1: opt-in "fma"
- *                     mode -- the multiply-adds of the dense cost loops are fused (half the FP64 instructions);
- *                     costs move in their last bits, a winner can change only between near-tied candidates
- *                     (mismatch rate measured by bench.py --arith fma).  2: opt-in "f32" mode -- the dense cost loops
- *                     run in single precision, two candidates per packed instruction (srh_dense_f32.hip); costs agree
- *                     with the reference's to ~6 digits, winners change where candidates are that close (rate measured
- *                     by bench.py --arith f32).  THE ONE OPTION THAT CHANGES RESULTS; row-aligned TwoView path only.
+ *   "arith"           3 (default) CERTIFIED: the strip kernel's cost loops run with fused multiply-adds (half the FP64
+ *                     instructions), the WTA scan checks every comparison it makes against a proven bound on the
+ *                     difference between fused and reference costs, and the pixels with a comparison inside the bound
+ *                     (srh_stats.n_flagged of n_certified) are re-evaluated in the reference's arithmetic: depth maps
+ *                     are the same bits as mode 0 (tests/test_gpu_arith_modes.py).  Kernels without a
+ *                     fused form run the reference's arithmetic.  0: the reference's arithmetic everywhere, operation
+ *                     by operation.  1: opt-in "fma" -- fused cost loops, UNCHECKED; a winner can change between
+ *                     near-tied candidates (rate measured by bench.py --arith fma).  2: opt-in "f32" -- the dense cost
+ *                     loops in single precision, two candidates per packed instruction (srh_dense_f32.hip); costs agree
+ *                     with the reference's to ~6 digits (rate measured by bench.py --arith f32).  MODES 1 AND 2 ARE THE
+ *                     ONLY OPTION VALUES THAT CHANGE RESULTS; row-aligned TwoView path only.
  *   "force_dense"     1: the row-aligned dense plan is proposed for every undistorted, non-refractive pair,
  *                     not only for rigs the host check accepts (the device verifies every candidate and the
  *                     run is repeated on the general kernels when one leaves its row: a test hook for that path)

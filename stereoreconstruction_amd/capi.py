@@ -62,6 +62,11 @@ class SrhMrfInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("energy_initial", C.c_double), ("energy_final", C.c_double)]
 
 
+# option "arith" (include/stereo_recon_hip.h)
+ARITH_EXACT, ARITH_FMA, ARITH_F32, ARITH_CERTIFIED = 0, 1, 2, 3
+ARITH_DEFAULT = ARITH_CERTIFIED
+
+
 class Stats(C.Structure):
     """srh_stats"""
     _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
@@ -74,7 +79,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 
 # every symbol include/stereo_recon_hip.h declares
 EXPORTS = [
-    "srh_abi_version", "srh_last_error", "srh_device_count", "srh_hw_queues_requested",
+    "srh_abi_version", "srh_build_id", "srh_last_error", "srh_device_count", "srh_hw_queues_requested",
     "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_camera_from_p",
     "srh_mvs_neighbours",
     "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
@@ -112,6 +117,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.srh_abi_version.restype = C.c_int
+    L.srh_build_id.restype = C.c_char_p
     L.srh_last_error.restype = C.c_char_p
     L.srh_device_count.argtypes = [C.POINTER(C.c_int)]
     L.srh_params_twoview_defaults.argtypes = [C.POINTER(Params)]
@@ -265,6 +271,11 @@ def _torch_runtime_first():
     torch = sys.modules.get("torch")
     if torch is not None and torch.cuda.is_available() and not torch.cuda.is_initialized():
         torch.cuda.init()
+
+
+def build_id():
+    """Hash of the sources the loaded library was built from (srh_build_id)."""
+    return lib().srh_build_id().decode()
 
 
 class Context:

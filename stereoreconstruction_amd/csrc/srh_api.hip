@@ -146,7 +146,10 @@ struct srh_context {
 	bool profiling = false;
 	bool force_generic = false;
  	bool use_fused = false;                             // option "fused": single fused kernel for row-aligned pairs
-	int arith = 0;                                      // option "arith": 0 = the reference's arithmetic, 1 = fused multiply-add, 2 = packed single precision in the dense cost loops
+	// option "arith": 0 = the reference's arithmetic everywhere; 3 (default) = CERTIFIED: fused multiply-adds in the strip
+	// kernel's cost loops, every decision checked against an error bound, uncovered pixels redone in the reference's
+	// arithmetic -- the reference's bits at the fused speed; 1 = fused multiply-adds unchecked; 2 = packed single precision
+	int arith = 3;
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
@@ -246,6 +249,11 @@ extern "C" int srh_hw_queues_requested(void) {
 }
 
 extern "C" int srh_abi_version(void) { return SRH_ABI_VERSION; }
+extern "C" const char *srh_build_id(void) {
+	return
+#include "build_id.inc"
+	;
+}
 extern "C" const char *srh_last_error(void) { return g_err; }
 
 extern "C" int srh_device_count(int *count) {
@@ -460,6 +468,7 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
 	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
 	if (const char *s = getenv("SRH_STRIP")) c->strip = atoi(s);
+	if (const char *s = getenv("SRH_ARITH")) { const int a = atoi(s); if (a >= 0 && a <= 3) c->arith = a; }
 	if (const char *s = getenv("SRH_MVS_STAGED")) c->mvs_staged = atoi(s) != 0;
 	if (const char *s = getenv("SRH_MVS_ASYNC")) c->mvs_async = atoi(s) != 0;
 	{ int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
@@ -566,6 +575,8 @@ extern "C" int srh_set_hooks(srh_context *c, const volatile int *cancel, srh_pro
 	return SRH_OK;
 }
 
+static void release_band_buffers(srh_context *c);
+
 extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
 	{ const int rc = mvs_settle_all(c); if (rc) return rc; }       // options apply to work queued from here on
@@ -573,7 +584,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "fused")) { c->use_fused = value != 0; return SRH_OK; }
 	if (!strcmp(name, "arith")) {
-		if (value < 0 || value > 2) return fail(SRH_E_INVALID, "arith must be 0 (exact), 1 (fma) or 2 (f32)");
+		if (value < 0 || value > 3) return fail(SRH_E_INVALID, "arith must be 0 (exact), 1 (fma), 2 (f32) or 3 (certified fma)");
 		c->arith = (int)value; return SRH_OK;
 	}
 	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
@@ -591,7 +602,15 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	}
 	// tests of the budget logic: pretend the device has only `value` MB to give / refuse band buffers above `value` MB
 	if (!strcmp(name, "mem_limit_mb")) { c->mem_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
-	if (!strcmp(name, "debug_alloc_limit_mb")) { g_alloc_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
+	if (!strcmp(name, "debug_alloc_limit_mb")) {
+		g_alloc_limit = value > 0 ? (size_t)value << 20 : 0;
+		// the band buffers a bigger run left behind would serve every later request without an allocation: start afresh
+		for (MvsSlot &S : c->mvs_slot) if (S.stream) HIP_TRY(hipStreamSynchronize(S.stream));
+		if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		release_band_buffers(c);
+		return SRH_OK;
+	}
 #ifdef SRH_EXPERIMENT
 	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
@@ -903,7 +922,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 
 	c->last_fused = false;
 	// ---- row-aligned rig whose candidate range fits an LDS cost row: one fused kernel per band (srh_fused.hip)
-	if (dense && c->use_fused && c->arith == 0 && p->num_depth_levels <= SRH_FUSED_MAXC &&
+	if (dense && c->use_fused && (c->arith == 0 || c->arith == 3) && p->num_depth_levels <= SRH_FUSED_MAXC &&
 	    fx_bx*p->image_scale*fabs(1.0/p->min_depth - 1.0/p->max_depth) + 1.0 <= (double)SRH_FUSED_MAXC) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
@@ -940,6 +959,10 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 	// (and enough tiles to keep every persistent workgroup busy for dozens of tiles: a small image is better served by
 	// one workgroup per tile; option strip = 4 / 8 forces the strip kernel for tests)
 	bool strip = dense && c->strip != 0 && c->arith != 2 && cstride + SRH_WTILE <= strip_chunk_columns();
+	// certified arithmetic (arith = 3, the default): fused cost loops in the strip kernel + the certified scan; where the
+	// strip kernel does not run, or the parameters leave the bound no room, the reference's arithmetic
+	const bool cert_ok = c->arith == 3 && cert_bound(*p).ok != 0;
+	c->stats.n_certified = c->stats.n_flagged = 0;
 	for (int attempt = 0; attempt < 3; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		// ---- arbitrary geometry: candidate lists (the one-thread-per-pixel walk kernel is the last resort)
@@ -1087,6 +1110,9 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*4))) return rc;
 		int lanes = 8;
 		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
+		const bool cert = strip && cert_ok;
+		const int cost_arith = c->arith == 3 ? (cert ? 3 : 0) : c->arith;
+		if (cert && (rc = ensure(c->cflag, c->cflag_cap, rows*(size_t)W + 1))) return rc;
 		if (strip) {
 			lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);
 			// NaN-bordered gray_tv planes of both views, zero-bordered "window fully usable" plane of the other view
@@ -1117,16 +1143,41 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				launch_pixel_range(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, cstride, c->prange);
 			}
 			if (dense && strip) {
-				HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));
-				{ Scope s(c, "twoview_strip_cost_kernel");
-				  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
-				                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
-				                            c->d_cnt, c->arith, c->num_cus, lanes); }
-				{ Scope s(c, "twoview_lazy_fill_kernel");
-				  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
-				                           c->views[ref].tvp, c->views[oth].tvp, lanes, c->cost, cstride, c->d_cnt); }
+				auto cost_pass = [&](int arith) -> int {
+					HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));
+					{ Scope s(c, "twoview_strip_cost_kernel");
+					  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
+					                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
+					                            c->d_cnt, arith, c->num_cus, lanes); }
+					{ Scope s(c, "twoview_lazy_fill_kernel");
+					  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
+					                           c->views[ref].tvp, c->views[oth].tvp, lanes, c->cost, cstride, c->d_cnt); }
+					return SRH_OK;
+				};
+				if (cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
+				if ((rc = cost_pass(cost_arith))) return rc;
 				{ Scope s(c, "twoview_scan_kernel");
-				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange); }
+				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
+				                      cert ? c->cflag : nullptr, -1); }
+				if (cert) {
+					// the pixels whose decisions the bound does not cover, in the reference's arithmetic: their cost rows are
+					// refilled and scanned again; a band with more than 1 in 32 of them is redone as a whole
+					uint32_t nflag = 0;
+					HIP_TRY(hipMemcpyAsync(&nflag, c->cflag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+					HIP_TRY(hipStreamSynchronize(c->stream));
+					if ((size_t)nflag*32 > (size_t)nr*W) {
+						if ((rc = cost_pass(0))) return rc;
+						Scope s(c, "twoview_scan_kernel");
+						launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, nullptr, c->prange);
+					} else if (nflag) {
+						{ Scope s(c, "twoview_refill_kernel");
+						  launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, (int)nflag, c->wbuf, c->views[ref].tvp,
+						                        c->views[oth].tvp, c->cost, cstride, c->d_cnt); }
+						Scope s(c, "twoview_rescan_kernel");
+						launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
+						                    c->cflag, (int)nflag);
+					}
+				}
 			} else if (dense) {
 				{ Scope s(c, "twoview_dense_cost_kernel");
 				  if (c->arith == 2)
@@ -1134,7 +1185,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst);
 				  else
 					launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-					                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith); }
+					                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith == 3 ? 0 : c->arith); }
 				{ Scope s(c, "twoview_lazy_fill_kernel");
 				  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
 				                           nullptr, nullptr, 8, c->cost, cstride, c->d_cnt); }
@@ -1152,6 +1203,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (strip && hc.strip_overflow != 0) { strip = false; continue; }   // a tile's ranges did not fit one chunk: per-tile kernel
+		c->stats.n_certified = (int64_t)hc.n_certified; c->stats.n_flagged = (int64_t)hc.n_flagged;
 		if (hc.not_row_aligned == 0) break;
 		dense = false;                                              // redo with the general kernel
 		strip = false;
@@ -1192,6 +1244,8 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 	c->stats.n_pixels += s_left.n_pixels;
 	c->stats.n_eval += s_left.n_eval;
 	c->stats.n_eval_device += s_left.n_eval_device;
+	c->stats.n_certified += s_left.n_certified;
+	c->stats.n_flagged += s_left.n_flagged;
 	progress(c, 5, "Detecting inconsistencies...");
 	if ((rc = srh_twoview_cross_check(c, left, right, p))) return rc;
 	if (left_out && (rc = srh_view_depth_download(c, left, left_out))) return rc;

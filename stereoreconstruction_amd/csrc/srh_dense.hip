@@ -900,6 +900,51 @@ __global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int 
 // The same for the strip path: windows in the LDS-image layout (a window row = 11 contiguous doubles), image rows from
 // the NaN-bordered planes (no bound tests), loops unrolled by window row so that a row's 33 loads travel together.
 // Same sums, same order as tv_cost (twoviewstereo.cpp:909-977): a skipped tap adds +0.0.
+// cost_ncc in the reference's arithmetic for ANY validity pattern, from the LDS-image windows and the NaN-bordered planes:
+// wq = the pixel's window, lp / rp = top-left tap of the two windows in the padded planes (stride SP)
+template <int R>
+__device__ __forceinline__ double wimg_exact_cost(const double *__restrict__ wq, int wrow, const double *__restrict__ lp,
+                                                  const double *__restrict__ rp, int SP, const srh_params &P)
+{
+	constexpr int WS = 2*R + 1;
+	double meanL = 0, meanR = 0, totalWeight = 0.0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
+			const double pl = wt[col]*gl[col], prr = wt[col]*gr[col];
+			meanL += ok ? pl : 0.0;
+			meanR += ok ? prr : 0.0;
+			totalWeight += ok ? wt[col] : 0.0;
+		}
+	}
+	if (totalWeight < 1e-10) return P.bad_ret;
+	meanL /= totalWeight;
+	meanR /= totalWeight;
+	double sum1 = 0, sum2 = 0, sum3 = 0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
+			const double a = wt[col]*gl[col] - meanL, b = wt[col]*gr[col] - meanR;
+			const double ab = a*b, aa = a*a, bb = b*b;
+			sum1 += ok ? ab : 0.0;
+			sum2 += ok ? aa : 0.0;
+			sum3 += ok ? bb : 0.0;
+		}
+	}
+	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
+	return (v < P.max_color_diff) ? v : P.max_color_diff;
+}
+
 template <int R>
 __global__ __launch_bounds__(256)
 void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const PixRange *__restrict__ prange,
@@ -907,7 +952,6 @@ void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const
                                    const double *__restrict__ oth_tvp, int ncb, int lanes, int pad,
                                    double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
 {
-	constexpr int WS = 2*R + 1;
 	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
 	unsigned n_lazy = 0;
 	if (q < (size_t)nrows*W) {
@@ -922,50 +966,49 @@ void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const
 			double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 			for (int c = cover + 1; c <= pr.hi; ++c) {
 				const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
-				double meanL = 0, meanR = 0, totalWeight = 0.0;
-#pragma unroll 1
-				for (int row = 0; row < WS; ++row) {
-					double gl[WS], gr[WS], wt[WS];
-#pragma unroll
-					for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
-#pragma unroll
-					for (int col = 0; col < WS; ++col) {
-						const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
-						const double pl = wt[col]*gl[col], prr = wt[col]*gr[col];
-						meanL += ok ? pl : 0.0;
-						meanR += ok ? prr : 0.0;
-						totalWeight += ok ? wt[col] : 0.0;
-					}
-				}
-				double result = P.bad_ret;
-				if (!(totalWeight < 1e-10)) {
-					meanL /= totalWeight;
-					meanR /= totalWeight;
-					double sum1 = 0, sum2 = 0, sum3 = 0;
-#pragma unroll 1
-					for (int row = 0; row < WS; ++row) {
-						double gl[WS], gr[WS], wt[WS];
-#pragma unroll
-						for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
-#pragma unroll
-						for (int col = 0; col < WS; ++col) {
-							const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
-							const double a = wt[col]*gl[col] - meanL, b = wt[col]*gr[col] - meanR;
-							const double ab = a*b, aa = a*a, bb = b*b;
-							sum1 += ok ? ab : 0.0;
-							sum2 += ok ? aa : 0.0;
-							sum3 += ok ? bb : 0.0;
-						}
-					}
-					const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
-					result = (v < P.max_color_diff) ? v : P.max_color_diff;
-				}
-				crow[(size_t)(c - pr.lo)*DC_TP] = result;
+				crow[(size_t)(c - pr.lo)*DC_TP] = wimg_exact_cost<R>(wq, wrow, lp, rp, SP, P);
 				++n_lazy;
 			}
 		}
 	}
 	block_count_add(&cnt->n_eval_device, n_lazy);
+}
+
+// Certified arithmetic: the cost rows of the flagged pixels (cflag[1 .. 1 + nlist)) once more, every column of the pixel's
+// range in the reference's arithmetic -- one 64-lane workgroup per pixel, a lane per column.
+template <int R>
+__global__ __launch_bounds__(64)
+void twoview_refill_kernel(int W, srh_params P, int y0, const PixRange *__restrict__ prange, const uint32_t *__restrict__ cflag,
+                           const double *__restrict__ wimg, const double *__restrict__ ref_tvp, const double *__restrict__ oth_tvp,
+                           double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
+{
+	const uint32_t q = cflag[1 + blockIdx.x];
+	const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
+	const PixRange pr = prange[q];
+	const int SP = padded_stride(W);
+	const double *wq = wimg + wimg_offset(W, R, trow, x);
+	const int wrow = wimg_row_stride(R);
+	const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SP + (x + SRH_PADL - R);
+	double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+	unsigned n = 0;
+	for (int c = pr.lo + (int)threadIdx.x; c <= pr.hi; c += 64) {
+		const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
+		crow[(size_t)(c - pr.lo)*DC_TP] = wimg_exact_cost<R>(wq, wrow, lp, rp, SP, P);
+		++n;
+	}
+	block_count_add(&cnt->n_eval_device, n);
+}
+
+bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int nlist,
+                           const double *wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt)
+{
+	if (nlist <= 0) return true;
+	if (P.window_radius == 5)
+		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)nlist), dim3(64), 0, st, width, P, y0, prange, cflag, wimg, ref_tvp, oth_tvp, cost, cstride, cnt);
+	else if (P.window_radius == 2)
+		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)nlist), dim3(64), 0, st, width, P, y0, prange, cflag, wimg, ref_tvp, oth_tvp, cost, cstride, cnt);
+	else return false;
+	return true;
 }
 
 void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -1000,32 +1043,62 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 	return v;
 }
 
+// certified scan: is this stored cost the very number the reference's arithmetic gives?  (+inf: the initial minCost / secondBest)
+__device__ __forceinline__ bool cert_sure(double x, double clamp, double m_hi) { return x == clamp || x > m_hi; }
+
 struct TwoViewScanState {
 	double minCost, secondBest;
 	int wcol;                 // winning column relative to lo, -1 = none
 };
 
-__global__ __launch_bounds__(SC_TW, SC_OCC)
+// CERT: the cost rows hold FUSED costs (twoview_strip_cost_kernel<.., 3>): the reference's decisions are replayed on
+// them, and a pixel is FLAGGED -- appended to cflag[1..], count in cflag[0] -- when a decision is not covered by the
+// error bound (CertBound, srh_internal.hpp).  What a stored value x says about the cost in the reference's arithmetic:
+//   x == max_color_diff, or x > max_color_diff + e0 (bad_ret)   the very same number ("sure": the strip kernel stores the
+//                                                               clamp itself only when the fused value is above it by more
+//                                                               than e0; larger values come from the exact select forms);
+//   x NaN                                                       an uncertified candidate: the pixel is flagged;
+//   anything else                                               within e0 of it (select-form candidates are exact and
+//                                                               counted as e0; a fused value in (clamp, clamp + e0] stands
+//                                                               for a reference value in [x - e0, clamp]).
+// A comparison a < b on fused values is the reference's when |a - b| exceeds the two bounds (+ the rounding of cost +
+// margin), or when both sides are sure (the same numbers go through the same operations).  The state (minCost,
+// secondBest, winner) then evolves identically, by induction over the candidate sequence; an unflagged pixel made every
+// comparison the way the reference's arithmetic makes it, so its winner -- and its depth, which is geometry -- are the
+// reference's bits.
+// LISTED: the exact scan of the flagged pixels only (lane k takes pixel cflag[1 + k]; their cost rows were refilled in
+// the reference's arithmetic by twoview_refill_kernel).
+template <bool CERT, bool LISTED>
+__global__ __launch_bounds__(SC_TW, CERT ? SC_OCC - 1 : SC_OCC)
 void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                          int y0, int nrows, const double *__restrict__ tnum,
                          const double *__restrict__ cost, int cstride,
-                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange)
+                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
+                         uint32_t *__restrict__ cflag, int nlist, CertBound cb)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
 	const int W = L.w, OW = Rv.w, OH = Rv.h;
 	const int tiles_per_row = (W + SC_TW - 1)/SC_TW;
-	const int trow = blockIdx.x / tiles_per_row;
-	const int x0 = (blockIdx.x % tiles_per_row)*SC_TW;
-	const int y = y0 + trow;
 	const int tid = threadIdx.x;
-	const int x = x0 + tid;
+	int trow, x;
+	bool listed_on = true;
+	if (LISTED) {
+		const int k = blockIdx.x*SC_TW + tid;
+		listed_on = k < nlist;
+		const uint32_t q = listed_on ? cflag[1 + k] : 0u;
+		trow = (int)(q / (uint32_t)W); x = (int)(q % (uint32_t)W);
+	} else {
+		trow = blockIdx.x / tiles_per_row;
+		x = (blockIdx.x % tiles_per_row)*SC_TW + tid;
+	}
+	const int y = y0 + trow;
 
 	__shared__ unsigned short queue[SC_QN][SC_TW];
 	__shared__ __align__(16) unsigned char mrow_raw[SC_MW + 16];
 
-	unsigned n_eval = 0, n_pix = 0, bad = 0;
-	const bool active = x < W && L.mask[(size_t)y*W + x] == 1;
+	unsigned n_eval = 0, n_pix = 0, bad = 0, n_flag = 0;
+	const bool active = listed_on && x < W && L.mask[(size_t)y*W + x] == 1;
 	Ray ray;
 	int lo = 0, hi = -1;
 	if (active) {
@@ -1033,7 +1106,8 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 		const PixRange pr = prange[(size_t)trow*W + x];      // pixel_range_kernel (pinhole_column_range)
 		lo = pr.lo; hi = pr.hi;
 	}
-	const int umin = wave_min_i32(hi >= lo ? lo : 2147483647);       // the workgroup is one wave
+	// LISTED: the lanes' pixels lie on different rows: no shared mask row, every mask byte comes from memory
+	const int umin = LISTED ? 2147483647 : wave_min_i32(hi >= lo ? lo : 2147483647);       // the workgroup is one wave
 	// mask bytes of row y of the other view, columns [umin, umin + SC_MW): 16 bytes per lane from the 4-byte granule
 	// that holds the first one (bytes past the row's end belong to the next row and are never looked at: every
 	// candidate column lies inside [lo, hi], inside the image)
@@ -1083,6 +1157,15 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 			for (int k = 0; k < SC_QN; ++k) {
 				if (k < count) {
 					const double cv = c[k];
+					if (CERT) {
+						// (a candidate column seen again while it is the winner compares its own cost with itself: false in
+						// either arithmetic since wta_margin >= 0)
+						// (tolerance: the two bounds + the rounding of cost + margin, 2u|t| <= e0/2: a side that is not sure is a
+						// cost, a clamp or a bad_ret of magnitude <= 1e5 -- CertBound::ok)
+						const double t = cv + P.wta_margin;
+						if (!(fabs(t - st.minCost) > 2.5*cb.e0) && col[k] != st.wcol &&
+						    !(cert_sure(cv, P.max_color_diff, cb.m_hi) && cert_sure(st.minCost, P.max_color_diff, cb.m_hi))) n_flag = 1;   // (NaN: flagged)
+					}
 					if (cv + P.wta_margin < st.minCost) {           // twoviewstereo.cpp:293-301
 						st.secondBest = st.minCost;
 						st.minCost = cv;
@@ -1116,7 +1199,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 					// ascending x whatever the direction of the segment (lineiter.hpp:96-111)
 					for (int tx = a; tx <= b; ++tx) {
 						const int k = tx - umin;
-						const bool white = (k >= 0 && k < SC_MW - 4) ? (mrow[k] == 1) : (Rv.mask[(size_t)y*OW + tx] == 1);
+						const bool white = (!LISTED && k >= 0 && k < SC_MW - 4) ? (mrow[k] == 1) : (Rv.mask[(size_t)y*OW + tx] == 1);
 						if (white) {
 							++n_eval;
 							queue[qn][tid] = (unsigned short)(tx - lo);
@@ -1152,24 +1235,45 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 			depth = candidate_depth(L.cam, Rv.cam, P, ray, lo + st.wcol, y);
 		if (st.minCost > P.second_best_factor*st.secondBest)
 			depth = __builtin_inf();
+		if (CERT && st.wcol >= 0) {
+			// the ratio test (twoviewstereo.cpp:303-305) on fused values: minCost within e0, factor*secondBest within |factor|*e0
+			const double rhs = P.second_best_factor*st.secondBest;
+			const double tol = __builtin_fma(fmin(fabs(rhs), 1e300), 1e-15, (1.0 + fabs(P.second_best_factor))*cb.e0);
+			if (!(fabs(st.minCost - rhs) > tol) &&
+			    !(cert_sure(st.minCost, P.max_color_diff, cb.m_hi) && cert_sure(st.secondBest, P.max_color_diff, cb.m_hi))) n_flag = 1;
+		}
+		if (CERT && n_flag) cflag[1 + atomicAdd(&cflag[0], 1u)] = (uint32_t)((size_t)trow*W + x);
 	}
-	if (x < W) L.depth[(size_t)y*W + x] = depth;
+	if (listed_on && x < W) L.depth[(size_t)y*W + x] = depth;
+	if (LISTED || !cnt) return;                        // (the pixels were counted by the certified scan)
 	// the workgroup is one wave: its counts are summed by lane shuffles, one atomic each
-	n_eval = wave_sum_u32(n_eval); n_pix = wave_sum_u32(n_pix); bad = wave_sum_u32(bad);
+	n_eval = wave_sum_u32(n_eval); n_pix = wave_sum_u32(n_pix); bad = wave_sum_u32(bad); n_flag = wave_sum_u32(n_flag);
 	if (tid == 0) {
 		if (n_eval) atomicAdd(&cnt->n_eval, (unsigned long long)n_eval);
 		if (n_pix) atomicAdd(&cnt->n_pixels, (unsigned long long)n_pix);
 		if (bad) atomicAdd(&cnt->not_row_aligned, (unsigned long long)bad);
+		if (CERT && n_pix) atomicAdd(&cnt->n_certified, (unsigned long long)n_pix);
+		if (CERT && n_flag) atomicAdd(&cnt->n_flagged, (unsigned long long)n_flag);
 	}
 }
 
+// cflag == nullptr: the exact scan.  cflag, nlist < 0: the certified scan (flags into cflag).  cflag, nlist >= 0: the
+// exact scan of the nlist pixels listed in cflag[1..].
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         Counters *cnt, const PixRange *prange)
+                         Counters *cnt, const PixRange *prange, uint32_t *cflag, int nlist)
 {
 	const int tiles = (width + SC_TW - 1)/SC_TW;
-	hipLaunchKernelGGL(twoview_scan_kernel, dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-	                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange);
+	const CertBound cb = cert_bound(P);
+	if (!cflag)
+		hipLaunchKernelGGL((twoview_scan_kernel<false, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, nullptr, 0, cb);
+	else if (nlist < 0)
+		hipLaunchKernelGGL((twoview_scan_kernel<true, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, 0, cb);
+	else if (nlist > 0)
+		hipLaunchKernelGGL((twoview_scan_kernel<false, true>), dim3((unsigned)((nlist + SC_TW - 1)/SC_TW)), dim3(SC_TW), 0, st,
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb);
 }
 
 } // namespace srh

@@ -64,6 +64,53 @@ __host__ __device__ inline size_t padded_size(int w, int h) { return (size_t)pad
 // candidate column range of a reference pixel on its own row of the other view (empty: hi < lo)
 struct PixRange { int32_t lo, hi; };
 
+// ---- certified fused arithmetic (option "arith" = 3; derivation: DESIGN.md section 2b) ---------------------------
+// The dense cost loops run with fused multiply-adds (half the FP64 instructions); a depth map depends on costs only
+// through comparisons (cost + wta_margin < minCost, minCost > second_best_factor*secondBest, the max_color_diff clamp;
+// twoviewstereo.cpp:292-305, 976), so the fused costs may stand in for the reference's wherever no comparison's
+// margin is inside the error bound.  For a fast-form candidate (all T taps usable; weights in (0,1], grays in
+// [0,255]; meanL, totalWeight and sum2 are the SAME bits in both arithmetics), with u = 2^-53, gamma_k = k*u/(1-k*u),
+// G = 256, A = sqrt(sum2), B = sqrt(sum3):
+//     eps_b = gamma_(T+4)*G   (error of w*g_R - meanR: the mean's T-term sum and division, the product, the subtraction)
+//     eps_a = 2*u*G           (error of w*g_L - meanL: meanL is shared)
+//     |cost_fused - cost_exact| <= 2*255*1.01*(3*eps_b*sqrt(T)/B + eps_a*sqrt(T)/A + 2*gamma_T) + 2600*u
+//                                =  k1/B + k2/A + k3
+// (either arithmetic is within half of that of the real-number value of the formula; 1.01 covers every second-order
+// term once A > 0.3 and B > 60, which the thresholds below imply).  A candidate is CERTIFIED when that is <= e0, i.e.
+// when sum3 >= sigma3(sum2); the cost kernel stores NaN for the others, and the certified scan flags every pixel
+// that meets a NaN or a comparison whose two sides are closer than the sum of their bounds: flagged pixels are
+// re-evaluated in the reference's arithmetic (twoview_refill_kernel + the exact scan).
+struct CertBound {
+	double e0, m_hi, k1, k2, room;
+	int ok;                                 // 0: the parameters leave the bound no room / weights are not in (0,1]: exact arithmetic
+	__host__ __device__ inline double sigma3(double s2) const {
+		const double d = room - k2/sqrt(s2);                      // (NaN or zero sum2: d is NaN or -inf)
+		if (!(d > 0)) return __builtin_inf();
+		const double b = k1/d;
+		return b*b*(1.0 + 0x1p-20);                               // (+ the roundings of this very computation)
+	}
+};
+inline CertBound cert_bound(const srh_params &P) {
+	const double u = 0x1p-53, G = 256.0;
+	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+	auto gamma = [&](int k) { return k*u/(1.0 - k*u); };
+	const double eps_b = gamma(T + 4)*G, eps_a = 2*u*G, rt = sqrt((double)T);
+	CertBound c;
+	c.e0 = 0x1p-30;                                               // 9.3e-10: a comparison needs 1.9e-9 of margin
+	c.k1 = 2*255*1.01*3*eps_b*rt;
+	c.k2 = 2*255*1.01*eps_a*rt;
+	const double k3 = 2*255*1.01*2*gamma(T) + 2600*u;
+	c.room = c.e0 - k3;
+	c.m_hi = P.max_color_diff + c.e0;
+	// the clamp test needs max_color_diff + e0 > max_color_diff (so below 2^22); the duplicate rule of the scan needs
+	// wta_margin >= 0; weights are exp(-distance/sigma) <= 1
+	// (and magnitudes <= 1e5, so that the rounding of cost + margin stays below e0/2 in the scan's tolerance)
+	c.ok = c.room > 0 && c.m_hi > P.max_color_diff && P.max_color_diff <= 1e5 && fabs(P.bad_ret) <= 1e5 &&
+	       P.wta_margin >= 0 && P.wta_margin <= 1e5 && fabs(P.second_best_factor) <= 1e5 &&
+	       (P.weight_kind == SRH_WEIGHT_GEODESIC ? P.geodesic_sigma > 0 : P.adaptive_color_sigma > 0);
+	return c;
+}
+
 // Work counters accumulated by the kernels (device memory, zeroed per run).
 struct Counters {
 	unsigned long long n_pixels;
@@ -72,6 +119,7 @@ struct Counters {
 	unsigned long long not_row_aligned;   // pixels whose curve leaves their own row
 	unsigned long long n_listed, n_slots; // row-run lists: distinct candidates / cost slots (8-column blocks) they occupy
 	unsigned long long strip_overflow;    // strip kernel: tiles whose candidate range does not fit one LDS chunk
+	unsigned long long n_certified, n_flagged;   // certified scan: reference pixels scanned on fused costs / flagged for the exact redo
 	unsigned int strip_ticket, strip_pad; // strip kernel: work-item counter of the current launch
 	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
 	unsigned long long dbg_phase[8];
@@ -123,9 +171,14 @@ bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
                                const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
+// cflag == nullptr: the exact scan (cnt == nullptr: without counting).  cflag, nlist < 0: the certified scan on fused
+// costs, flagged pixels into cflag = [count | band pixel indices].  cflag, nlist >= 0: the exact scan of the listed pixels
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         Counters *cnt, const PixRange *prange);
+                         Counters *cnt, const PixRange *prange, uint32_t *cflag = nullptr, int nlist = -1);
+// the cost rows of the listed pixels in the reference's arithmetic (strip path's buffers)
+bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int nlist,
+                           const double *wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt);
 // columns the cost kernel leaves out (dense_cover_hi with `lanes` block lanes per pixel), filled in before the scan
 void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,

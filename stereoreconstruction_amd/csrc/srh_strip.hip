@@ -124,6 +124,7 @@ struct StripArgs {
 	int n1, n2;                             // rows [0,n1) in 16-row items, [n1,n2) in 8-row items, the rest in 4-row items
 	int nitems;
 	double weight_cutoff, bad_ret, max_color_diff;
+	CertBound cb;                           // certified arithmetic (AR == 3): the constants of the error bound, srh_internal.hpp
 };
 
 template <int R, int NBUF>
@@ -307,10 +308,15 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 }
 
 // NWV waves: 4 (block lanes per pixel G = 8, NBUF = 1) or 8 (G = 16, NBUF = 2)
-template <int R, int NWV, int NBUF, bool FMA>
+// AR: 0 = the reference's arithmetic (no contraction), 1 = fused multiply-adds, 3 = fused AND certified: a candidate
+// whose error bound (srh_internal.hpp, CertBound) is not below cb.e0 is stored as NaN, a value above max_color_diff + e0
+// as max_color_diff itself (the exact cost is then max_color_diff too), anything else unclamped -- the certified scan
+// does the rest.  Candidates of the select forms are evaluated in the reference's arithmetic in every mode.
+template <int R, int NWV, int NBUF, int AR>
 __global__ __launch_bounds__(NWV*64, 2)
 void twoview_strip_cost_kernel(const StripArgs A)
 {
+	constexpr bool FMA = AR != 0, CERT = AR == 3;
 	typedef StripSmem<R, NBUF> Smem;
 	constexpr int WS = Smem::WS, WP = Smem::WP, WPIX = Smem::WPIX, RW = Smem::RW, LW = Smem::LW, NS = Smem::NS;
 	constexpr int NCB = ST_NCB, CHUNK = ST_CHUNK;
@@ -524,6 +530,8 @@ void twoview_strip_cost_kernel(const StripArgs A)
 				if (e_max >= e_min) e_max = dense_cover_hi(e_min, e_max, NCB, G, PAD);
 			}
 			const bool lall = CS.pc[cur][i][3] != 0.0;
+			// certified arithmetic: the smallest sum3 of a candidate of this pixel for which the bound holds (from its sum2)
+			const double sig3 = CERT ? A.cb.sigma3(CS.pc[cur][i][2]) : 0.0;
 			const size_t tile = (size_t)r*tiles_per_row + tx;
 			ST_STAMP(3);                               // ranges, (re)staging, requests for the next tile, form of the tile
 			if (e_max >= e_min) {
@@ -659,7 +667,8 @@ void twoview_strip_cost_kernel(const StripArgs A)
 							const int c = c0 + j;
 							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
 								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-								crow[(size_t)(c - e_min)*ST_TP] = (v < A.max_color_diff) ? v : A.max_color_diff;
+								if (CERT) crow[(size_t)(c - e_min)*ST_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
+								else crow[(size_t)(c - e_min)*ST_TP] = (v < A.max_color_diff) ? v : A.max_color_diff;
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
@@ -776,17 +785,25 @@ void twoview_strip_cost_kernel(const StripArgs A)
 #undef ST_STAMP
 }
 
-template <int R, int NWV, int NBUF, bool FMA>
+template <int R, int NWV, int NBUF, int AR>
 static void launch_strip_variant(hipStream_t st, const StripArgs &a, int num_cus)
 {
 	typedef StripSmem<R, NBUF> Smem;
 	size_t lds = sizeof(Smem);
-	(void)hipFuncSetAttribute((const void *)twoview_strip_cost_kernel<R, NWV, NBUF, FMA>,
+	(void)hipFuncSetAttribute((const void *)twoview_strip_cost_kernel<R, NWV, NBUF, AR>,
 	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	int grid = num_cus*(NBUF == 2 ? 1 : 2);
 	if (grid > a.nitems) grid = a.nitems;
 	if (grid < 1) grid = 1;
-	hipLaunchKernelGGL((twoview_strip_cost_kernel<R, NWV, NBUF, FMA>), dim3((unsigned)grid), dim3(NWV*64), lds, st, a);
+	hipLaunchKernelGGL((twoview_strip_cost_kernel<R, NWV, NBUF, AR>), dim3((unsigned)grid), dim3(NWV*64), lds, st, a);
+}
+
+template <int R, int NWV, int NBUF>
+static void launch_strip_arith(hipStream_t st, const StripArgs &a, int num_cus, int arith)
+{
+	if (arith == 3) launch_strip_variant<R, NWV, NBUF, 3>(st, a, num_cus);
+	else if (arith == 1) launch_strip_variant<R, NWV, NBUF, 1>(st, a, num_cus);
+	else launch_strip_variant<R, NWV, NBUF, 0>(st, a, num_cus);
 }
 
 // form: 0 = by the candidate range (16 block lanes only pay when a pixel has at least 17 blocks), 4 / 8 = forced
@@ -814,16 +831,14 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
 	const int nseg = a.n1/16 + (a.n2 - a.n1)/8 + (nrows - a.n2 + 3)/4;
 	a.nitems = nseg*((width + ST_TP - 1)/ST_TP);
 	a.weight_cutoff = P.weight_cutoff; a.bad_ret = P.bad_ret; a.max_color_diff = P.max_color_diff;
-	const bool fma = arith == 1;
+	a.cb = cert_bound(P);
 	const bool wide = lanes == 16;
 	switch (P.window_radius) {
 	case 5:
-		if (wide) { if (fma) launch_strip_variant<5, 8, 2, true>(st, a, num_cus); else launch_strip_variant<5, 8, 2, false>(st, a, num_cus); }
-		else      { if (fma) launch_strip_variant<5, 4, 1, true>(st, a, num_cus); else launch_strip_variant<5, 4, 1, false>(st, a, num_cus); }
+		if (wide) launch_strip_arith<5, 8, 2>(st, a, num_cus, arith); else launch_strip_arith<5, 4, 1>(st, a, num_cus, arith);
 		return true;
 	case 2:
-		if (wide) { if (fma) launch_strip_variant<2, 8, 2, true>(st, a, num_cus); else launch_strip_variant<2, 8, 2, false>(st, a, num_cus); }
-		else      { if (fma) launch_strip_variant<2, 4, 1, true>(st, a, num_cus); else launch_strip_variant<2, 4, 1, false>(st, a, num_cus); }
+		if (wide) launch_strip_arith<2, 8, 2>(st, a, num_cus, arith); else launch_strip_arith<2, 4, 1>(st, a, num_cus, arith);
 		return true;
 	default: return false;
 	}

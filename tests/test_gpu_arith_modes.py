@@ -1,8 +1,9 @@
-"""Opt-in arithmetic modes of the dense TwoView path (option "arith").  The default (0) is the reference's arithmetic,
-bit for bit.  Mode 1 ("fma") fuses the multiply-adds of the cost loops: costs move in their last bits, so a depth
-can change only where two candidates were (nearly) tied.  The winner-mismatch rate against the exact mode is measured
-here on C2 at full size and must stay tiny; where the winner is the same the depth is identical (the depth of a
-winner comes from geometry, not from the cost)."""
+"""Arithmetic modes of the dense TwoView path (option "arith").  Mode 0 is the reference's arithmetic, operation by
+operation.  Mode 3 (the default, "certified") runs the strip kernel's cost loops with fused multiply-adds, checks every
+decision of the WTA scan against an error bound and redoes the uncovered pixels in the reference's arithmetic: it must
+equal mode 0 BIT FOR BIT, always (the tests at the end of this file).  Mode 1 ("fma") is the
+unchecked fused arithmetic: costs move in their last bits, so a depth can change only where two candidates were
+(nearly) tied; its winner-mismatch rate against the exact mode is measured here.  Mode 2 is single precision."""
 import numpy as np
 import pytest
 
@@ -36,6 +37,7 @@ def test_fma_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed):
     finally:
         hip_ctx.set_option("arith", 0)
     hip_ctx.twoview_wta(0, 1, p)
+    hip_ctx.set_option("arith", capi.ARITH_DEFAULT)
     again = hip_ctx.download_depth(0)
     assert np.array_equal(exact.view(np.uint64), again.view(np.uint64))          # the default is untouched
     differ = exact.view(np.uint64) != fma.view(np.uint64)
@@ -70,7 +72,7 @@ def test_f32_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed, radius):
         f32 = hip_ctx.download_depth(0)
         st2 = hip_ctx.stats()
     finally:
-        hip_ctx.set_option("arith", 0)
+        hip_ctx.set_option("arith", capi.ARITH_DEFAULT)
     assert st2["used_dense_path"] and st2["n_eval"] == st0["n_eval"] and st2["n_pixels"] == st0["n_pixels"]
     differ = exact.view(np.uint64) != f32.view(np.uint64)
     rate = differ.mean()
@@ -90,6 +92,7 @@ def test_f32_mode_on_masked_views_bands_and_row_ranges(hip_ctx):
     case = cases.get_twoview("geodesic_masks", w=96, h=60, D=24)
     cams, p = cases.hip_inputs(case)
     cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.set_option("arith", 0)
     hip_ctx.twoview_wta(0, 1, p)
     exact = hip_ctx.download_depth(0)
     hip_ctx.set_option("arith", 2)
@@ -104,7 +107,7 @@ def test_f32_mode_on_masked_views_bands_and_row_ranges(hip_ctx):
         hip_ctx.twoview_wta(0, 1, p, 7, 41)
         part = hip_ctx.download_depth(0)
     finally:
-        hip_ctx.set_option("arith", 0)
+        hip_ctx.set_option("arith", capi.ARITH_DEFAULT)
         hip_ctx.set_option("band_budget_mb", 32768)
     assert np.array_equal(whole.view(np.uint64), banded.view(np.uint64))          # deterministic, band-independent
     assert np.array_equal(part[7:41].view(np.uint64), whole[7:41].view(np.uint64))
@@ -115,4 +118,150 @@ def test_f32_mode_on_masked_views_bands_and_row_ranges(hip_ctx):
 
 def test_arith_option_validation(hip_ctx):
     with pytest.raises(capi.StereoHipError):
-        hip_ctx.set_option("arith", 3)
+        hip_ctx.set_option("arith", 4)
+    with pytest.raises(capi.StereoHipError):
+        hip_ctx.set_option("arith", -1)
+
+
+# ---------------------------------------------------------------------------------------------- certified arithmetic
+def _both_ways(ctx, p, arith, strip):
+    """(left map, right map, stats of each pass) of WTA both ways under one arithmetic; strip = 8 / 4 forces the strip
+    kernel on images too small for it by default (the certified arithmetic lives in the strip kernel)."""
+    ctx.set_option("arith", arith)
+    ctx.set_option("strip", strip)
+    try:
+        out = []
+        for a, b in ((0, 1), (1, 0)):
+            ctx.twoview_wta(a, b, p)
+            out.append((ctx.download_depth(a), ctx.stats()))
+        return out
+    finally:
+        ctx.set_option("arith", capi.ARITH_DEFAULT)
+        ctx.set_option("strip", 1)
+
+
+def _assert_certified_equals_exact(ctx, p, strip, tag):
+    exact = _both_ways(ctx, p, capi.ARITH_EXACT, strip)
+    cert = _both_ways(ctx, p, capi.ARITH_CERTIFIED, strip)
+    flagged = 0
+    for d in range(2):
+        assert exact[d][1]["used_strip_kernel"] and cert[d][1]["used_strip_kernel"], tag
+        assert exact[d][1]["n_certified"] == 0
+        assert cert[d][1]["n_certified"] == cert[d][1]["n_pixels"] > 0, (tag, cert[d][1])
+        assert np.array_equal(exact[d][0].view(np.uint64), cert[d][0].view(np.uint64)), \
+            "%s direction %d: the certified arithmetic changed %d depths" % (
+                tag, d, (exact[d][0].view(np.uint64) != cert[d][0].view(np.uint64)).sum())
+        assert exact[d][1]["n_eval"] == cert[d][1]["n_eval"] and exact[d][1]["n_pixels"] == cert[d][1]["n_pixels"]
+        flagged += cert[d][1]["n_flagged"]
+    return flagged, sum(cert[d][1]["n_certified"] for d in range(2))
+
+
+CERT_CASES = [("geodesic_rect", dict()), ("adaptive_rect", dict()), ("geodesic_masks", dict()),
+              ("adaptive_masks", dict(w=97, h=53, D=24)), ("geodesic_r2", dict()),
+              ("geodesic_rect", dict(w=200, h=70, D=48)), ("adaptive_rect", dict(w=161, h=37, D=130)),
+              ("geodesic_scaled", dict())]
+
+
+@pytest.mark.parametrize("name,over", CERT_CASES)
+@pytest.mark.parametrize("strip", [4, 8])
+def test_certified_equals_exact_on_the_parity_cases(hip_ctx, name, over, strip):
+    import cases
+    case = cases.get_twoview(name, **over)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    _assert_certified_equals_exact(hip_ctx, p, strip, "%s %s strip=%d" % (name, over, strip))
+
+
+def _adversarial_pair(kind, W=192, H=96, D=40, seed=7):
+    """Rectified pairs built to sit ON the decisions: exact ties between different candidates (periodic texture: the
+    +1e-10 rule decides), near-flat windows (sum2, sum3 tiny: the costs are rounding noise), saturated / black regions
+    (every cost undefined or clamped), two-level images (a handful of distinct costs), and a ratio test on its
+    threshold (two equally good matches)."""
+    rng = np.random.default_rng(seed)
+    L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, 0x5EED0A00 + seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    if kind == "periodic":
+        per = 6
+        base = rng.integers(0, 256, (H, per, 3), dtype=np.uint8)
+        L[..., :3] = base[:, xx[0] % per]
+        R[..., :3] = base[:, (xx[0] + 2) % per]
+    elif kind == "periodic_rows_differ":
+        per = 5
+        base = rng.integers(0, 256, (1, per, 3), dtype=np.uint8)
+        L[..., :3] = base[:, xx[0] % per] // 2 + (yy[..., None] % 7).astype(np.uint8) * 9
+        R[..., :3] = L[..., :3]
+    elif kind == "flat":
+        L[..., :3] = 128
+        R[..., :3] = 128
+    elif kind == "near_flat":
+        L[..., :3] = 128
+        R[..., :3] = 128
+        L[::9, ::7, 0] = 129
+        R[::5, ::11, 1] = 127
+    elif kind == "saturated_half":
+        L[:, W // 2:, :3] = 255
+        R[:, W // 3:, :3] = 255
+        L[: H // 4, :, :3] = 0
+    elif kind == "two_level":
+        L[..., :3] = np.where(rng.random((H, W, 1)) < 0.5, 40, 200).astype(np.uint8)
+        R[..., :3] = np.roll(L[..., :3], -12, axis=1)
+    elif kind == "two_matches":
+        # the right image holds the left texture twice, 16 columns apart: two candidates with (almost) the same cost
+        tex = rng.integers(0, 256, (H, 16, 3), dtype=np.uint8)
+        L[..., :3] = tex[:, xx[0] % 16]
+        R[..., :3] = L[..., :3]
+        R[::2, ::3, 2] ^= 1
+    elif kind == "ramp":
+        L[..., :3] = (xx[..., None] % 256).astype(np.uint8)
+        R[..., :3] = ((xx[..., None] + 9) % 256).astype(np.uint8)
+    else:
+        raise KeyError(kind)
+    return L, R, ml, mr
+
+
+@pytest.mark.parametrize("wkind", [capi.WEIGHT_GEODESIC, capi.WEIGHT_ADAPTIVE], ids=["geodesic", "adaptive"])
+@pytest.mark.parametrize("kind", ["periodic", "periodic_rows_differ", "flat", "near_flat", "saturated_half", "two_level",
+                                  "two_matches", "ramp"])
+def test_certified_equals_exact_on_adversarial_images(hip_ctx, kind, wkind):
+    W, H, D = 192, 96, 40
+    L, R, ml, mr = _adversarial_pair(kind, W, H, D)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl))
+    hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr))
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
+    flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, 8, kind)
+    print("certified scan, %s / %s: %d of %d pixels flagged and redone" % (kind, "geodesic" if wkind else "adaptive", flagged, scanned))
+    if kind in ("flat", "periodic"):
+        assert flagged > 0, "an image made of exact ties must trip the bound somewhere"
+
+
+def test_certified_equals_exact_when_the_parameters_move_the_decisions(hip_ctx):
+    """Other clamps, margins and ratio factors: a clamp inside the cost range (many candidates exactly on it), a zero
+    margin, a ratio factor of 1; a negative margin switches the certified arithmetic off (the duplicate rule needs >= 0)."""
+    import cases
+    case = cases.get_twoview("geodesic_rect", w=160, h=64, D=40)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    for over in (dict(max_color_diff=3.0), dict(max_color_diff=0.5, second_best_factor=1.0), dict(wta_margin=0.0),
+                 dict(bad_ret=2.0, max_color_diff=40.0), dict(second_best_factor=0.5, max_color_diff=1e4)):
+        for k, v in over.items():
+            setattr(p, k, v)
+        _assert_certified_equals_exact(hip_ctx, p, 8, str(over))
+    p.wta_margin = -1e-3
+    exact = _both_ways(hip_ctx, p, capi.ARITH_EXACT, 8)
+    cert = _both_ways(hip_ctx, p, capi.ARITH_CERTIFIED, 8)
+    assert cert[0][1]["n_certified"] == 0                                         # ran in the reference's arithmetic
+    assert np.array_equal(exact[0][0].view(np.uint64), cert[0][0].view(np.uint64))
+
+
+@pytest.mark.parametrize("W,H,D,wkind,seed", [(1920, 1080, 256, capi.WEIGHT_GEODESIC, 0x5EED0003),
+                                              (640, 480, 64, capi.WEIGHT_ADAPTIVE, 0x5EED0002)], ids=["C3", "C2"])
+def test_certified_equals_exact_at_full_size(hip_ctx, W, H, D, wkind, seed):
+    """C3 and C2 at BASELINE size, both directions: the default (certified) arithmetic gives the reference arithmetic's
+    bits; the flagged fraction is what the bench line reports."""
+    p = _pair(hip_ctx, W, H, D, seed, wkind)
+    strip = 1 if W >= 1920 else 8
+    flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, strip, "%dx%dx%d" % (W, H, D))
+    print("certified scan at %dx%dx%d: %d of %d pixels flagged and redone (%.3g)" % (W, H, D, flagged, scanned, flagged / scanned))
+    assert flagged < 0.02 * scanned
