@@ -1008,9 +1008,11 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				const size_t px64 = (lrows*W + 63) & ~(size_t)63, px32 = lrows*(size_t)((W + 31)/32)*32;
 				if ((rc = ensure(c->cost, c->cost_cap, (rows_mode ? px32 : lrows*W)*(size_t)ccap))) return rc;
 				if ((rc = ensure(c->lcand, c->lcand_cap, (rows_mode ? px64 : lrows*W)*(size_t)cmax))) return rc;
+				const bool rows_cert = rows_mode && cert_ok;
 				if (rows_mode) {
 					if ((rc = ensure(c->lrowinfo, c->lrowinfo_cap, px64*(size_t)SRH_ROWS_NR))) return rc;
 					if ((rc = ensure(c->lmeta, c->lmeta_cap, lrows*W))) return rc;
+					if (rows_cert && (rc = ensure(c->cflag, c->cflag_cap, lrows*W + 1))) return rc;
 				}
 				for (int by = y0; by < y1; by += (int)lrows) {
 					if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
@@ -1035,12 +1037,35 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						std::swap(c->stream, c->side_stream);
 						HIP_TRY(hipEventRecord(c->side_done, c->side_stream));
 						HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
+						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
-						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
+						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? 3 : 0); }
 						{ Scope s(c, "twoview_rows_scan_kernel");
 						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
-						                           c->lrowinfo, c->lmeta, c->cost, smax); }
+						                           c->lrowinfo, c->lmeta, c->cost, smax, rows_cert ? c->cflag : nullptr, -1, c->d_cnt); }
+						if (rows_cert) {
+							// certified arithmetic: the flagged pixels once more in the reference's arithmetic (a list cut by a too
+							// small capacity is harmless here: the pass is repeated anyway); more than 1 pixel in 32: the whole band
+							uint32_t nflag = 0;
+							HIP_TRY(hipMemcpyAsync(&nflag, c->cflag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+							HIP_TRY(hipStreamSynchronize(c->stream));
+							if ((size_t)nflag*32 > (size_t)nr*W) {
+								{ Scope s(c, "twoview_rows_cost_kernel");
+								  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
+								                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, 0); }
+								Scope s(c, "twoview_rows_scan_kernel");
+								launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
+								                         c->lrowinfo, c->lmeta, c->cost, smax);
+							} else if (nflag) {
+								{ Scope s(c, "twoview_rows_refill_kernel");
+								  launch_twoview_rows_refill(c->stream, c->d_views, ref, oth, *p, by, c->cflag, (int)nflag, c->wbuf,
+								                             c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
+								Scope s(c, "twoview_rows_rescan_kernel");
+								launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
+								                         c->lrowinfo, c->lmeta, c->cost, smax, c->cflag, (int)nflag, c->d_cnt);
+							}
+						}
 						continue;
 					}
 					run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
@@ -1075,6 +1100,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
 						HIP_TRY(hipStreamSynchronize(c->stream));
 						c->views[ref].list_mode[oth] = (hc.n_slots > 2.2*(double)hc.n_listed) ? 2 : 1;
+						if (rows_cert) { c->stats.n_certified = (int64_t)hc.n_pixels; c->stats.n_flagged = (int64_t)hc.n_flagged; }
 						break;
 					}
 					if (maxc > cmax) { cmax = (maxc + 7) & ~7; if (need <= smax) smax = std::max(smax, cmax + 64); }

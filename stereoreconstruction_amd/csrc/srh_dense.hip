@@ -1043,9 +1043,6 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 	return v;
 }
 
-// certified scan: is this stored cost the very number the reference's arithmetic gives?  (+inf: the initial minCost / secondBest)
-__device__ __forceinline__ bool cert_sure(double x, double clamp, double m_hi) { return x == clamp || x > m_hi; }
-
 struct TwoViewScanState {
 	double minCost, secondBest;
 	int wcol;                 // winning column relative to lo, -1 = none

@@ -90,6 +90,8 @@ struct CertBound {
 		return b*b*(1.0 + 0x1p-20);                               // (+ the roundings of this very computation)
 	}
 };
+// certified scan: is this stored cost the very number the reference's arithmetic gives?  (+inf: the initial minCost / secondBest)
+__host__ __device__ inline bool cert_sure(double x, double clamp, double m_hi) { return x == clamp || x > m_hi; }
 inline CertBound cert_bound(const srh_params &P) {
 	const double u = 0x1p-53, G = 256.0;
 	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
@@ -272,12 +274,19 @@ void launch_epipolar_curves(hipStream_t st, const ViewDev *views, int ref, int o
 void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, uint32_t *rowinfo,
                               int32_t *meta, int smax, Counters *cnt, int *maxes, const double *tdist);
+// arith: 0 = the reference's arithmetic, 3 = certified fused sweeps (values stored for the certified scan)
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
-                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt);
+                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith = 0);
+// cflag == nullptr: exact scan.  cflag, nlist < 0: certified scan (flags into cflag = [count | band pixel indices]).
+// cflag, nlist >= 0: the exact scan of the listed pixels (after launch_twoview_rows_refill)
 void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, int cmax,
-                              const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax);
+                              const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax,
+                              uint32_t *cflag = nullptr, int nlist = -1, Counters *cnt = nullptr);
+void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
+                                const uint32_t *cflag, int nlist, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
+                                double *cost, int smax, Counters *cnt);
 // RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
 const char *rccl_unique_id_get(void *out128);
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);

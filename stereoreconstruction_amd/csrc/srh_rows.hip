@@ -142,14 +142,19 @@ struct RowsSmem {
 	int glist_n;
 };
 
-template <int R>
+// AR: 0 = the reference's arithmetic; 3 = certified: the two sweeps of the fast form run with fused multiply-adds and
+// every value is stored by the rule of the certified scan (srh_internal.hpp, CertBound; twoview_strip_cost_kernel): NaN
+// for a candidate whose error bound is not below e0, the clamp itself above clamp + e0, anything else unclamped.  The
+// per-pixel constants (meanL, totalWeight, sum2) and the select form stay in the reference's arithmetic.
+template <int R, int AR>
 __global__ __launch_bounds__(RC_THREADS, 2)
 void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                               int y0, int nrows, const double *__restrict__ wbuf,
                               const uint8_t *__restrict__ full_oth,
                               const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
-                              double *__restrict__ cost, int smax, Counters *__restrict__ cnt)
+                              double *__restrict__ cost, int smax, Counters *__restrict__ cnt, const CertBound cb)
 {
+	constexpr bool FMA = AR != 0, CERT = AR == 3;
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
 	typedef RowsSmem<R> Smem;
@@ -365,6 +370,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		double *crow = cost + (size_t)blockIdx.x*smax*RC_TP + i;      // tile-transposed: slot s at crow[s*32]
 		const bool lall = CS.lall[i] != 0;
 		const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
+		const double sig3 = CERT ? cb.sigma3(s2) : 0.0;                // certified: smallest sum3 the bound covers for this pixel
 		// task t = the t-th 8-column block of the pixel's spans (rows in order); lane g takes t = g, g+8, ...
 		// its costs live in slots [8t, 8t+8)
 		const int ntask = CS.blk0[i][nr];
@@ -427,12 +433,17 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
-							double pr[RC_NCB];
+							if (FMA) {
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) pr[j] = wv[col]*r[col + j];
-							__builtin_amdgcn_sched_barrier(0);
+								for (int j = 0; j < RC_NCB; ++j) acc[j] = __builtin_fma(wv[col], r[col + j], acc[j]);
+							} else {
+								double pr[RC_NCB];
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) acc[j] += pr[j];            // meanR += weight*gray
+								for (int j = 0; j < RC_NCB; ++j) pr[j] = wv[col]*r[col + j];
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int j = 0; j < RC_NCB; ++j) acc[j] += pr[j];            // meanR += weight*gray
+							}
 							__builtin_amdgcn_sched_barrier(0);                  // keep each refill where it is written
 							if (col & 1) {                                      // r[col-1], r[col], wv[col-1], wv[col] are dead
 								r[col - 1] = rp[col - 1]; r[col] = rp[col];
@@ -458,20 +469,30 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
 							const double wt = wv[col];
-							double bb[RC_NCB], u1[RC_NCB], u3[RC_NCB];
-							const double pa = wt*av[col];
+							if (FMA) {
+								const double a = __builtin_fma(wt, av[col], -mL);
+								double bb[RC_NCB];
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) bb[j] = wt*r[col + j];
-							__builtin_amdgcn_sched_barrier(0);
-							const double a = pa - mL;                           // pixel_gray_l - meanL
+								for (int j = 0; j < RC_NCB; ++j) bb[j] = __builtin_fma(wt, r[col + j], -mR[j]);
+								__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
-							__builtin_amdgcn_sched_barrier(0);
+								for (int j = 0; j < RC_NCB; ++j) { s1[j] = __builtin_fma(a, bb[j], s1[j]); s3[j] = __builtin_fma(bb[j], bb[j], s3[j]); }
+							} else {
+								double bb[RC_NCB], u1[RC_NCB], u3[RC_NCB];
+								const double pa = wt*av[col];
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
-							__builtin_amdgcn_sched_barrier(0);
+								for (int j = 0; j < RC_NCB; ++j) bb[j] = wt*r[col + j];
+								__builtin_amdgcn_sched_barrier(0);
+								const double a = pa - mL;                           // pixel_gray_l - meanL
 #pragma unroll
-							for (int j = 0; j < RC_NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+								for (int j = 0; j < RC_NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int j = 0; j < RC_NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int j = 0; j < RC_NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+							}
 							__builtin_amdgcn_sched_barrier(0);
 							av[col] = lp[col];
 							if (col & 1) {
@@ -488,7 +509,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					for (int j = 0; j < RC_NCB; ++j) {
 						if (j >= sh) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							dst[(j - sh)*RC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							if (CERT) dst[(j - sh)*RC_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
+							else dst[(j - sh)*RC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 					}
 				} else {
@@ -519,19 +541,21 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
-                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt)
+                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith)
 {
 	const int tiles = (width + RC_TP - 1)/RC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
-#define SRH_RC_LAUNCH(RR)                                                                                   \
+	const CertBound cb = cert_bound(P);
+#define SRH_RC_LAUNCH2(RR, AA)                                                                              \
 	{                                                                                                       \
 		/* per device, hence on every launch */                                                             \
-		(void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR>,                                                \
-		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>));                  \
-		hipLaunchKernelGGL(twoview_rows_cost_kernel<RR>, grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
-		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt);  \
+		(void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR, AA>,                           \
+		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>));            \
+		hipLaunchKernelGGL((twoview_rows_cost_kernel<RR, AA>), grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
+		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb);  \
 		return true;                                                                                        \
 	}
+#define SRH_RC_LAUNCH(RR) { if (arith == 3) SRH_RC_LAUNCH2(RR, 3) else SRH_RC_LAUNCH2(RR, 0) }
 	switch (P.window_radius) {
 	case 1: SRH_RC_LAUNCH(1)
 	case 2: SRH_RC_LAUNCH(2)
@@ -541,24 +565,74 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 	default: return false;
 	}
 #undef SRH_RC_LAUNCH
+#undef SRH_RC_LAUNCH2
+}
+
+// Certified arithmetic: every cost slot of the flagged pixels (cflag[1 .. 1 + nlist)) once more, in the reference's
+// arithmetic (tv_cost: any validity pattern) -- one 64-lane workgroup per pixel, a lane per slot.
+__global__ __launch_bounds__(64)
+void twoview_rows_refill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
+                                const uint32_t *__restrict__ cflag, const double *__restrict__ wbuf,
+                                const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
+                                double *__restrict__ cost, int smax, Counters *__restrict__ cnt)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w;
+	const size_t q = cflag[1 + blockIdx.x];
+	const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
+	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+	const double *wq = wbuf + wbuf_offset(W, T, trow, x);
+	const int tiles_per_row = (W + 31) >> 5;
+	double *crow = cost + ((size_t)trow*tiles_per_row + (x >> 5))*(size_t)smax*32 + (x & 31);
+	const int m = meta[q];
+	const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
+	unsigned n = 0;
+	int base = 0;
+	for (int r = 0; r < nr; ++r) {
+		const uint32_t info = rowinfo[((q >> 6)*RW_NR + r)*64 + (q & 63)];
+		const int xlo = (int)(short)(info & 0xffff), wdt = (int)(info >> 16);
+		for (int k = (int)threadIdx.x; k < wdt; k += 64) {
+			crow[(size_t)(base + k)*32] = tv_cost(L, Rv, wq, SRH_WTILE, P, x, y, xlo + k, ymin + r);
+			++n;
+		}
+		base += (wdt + 7) & ~7;
+	}
+	block_count_add(&cnt->n_eval_device, n);
+}
+
+void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
+                                const uint32_t *cflag, int nlist, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
+                                double *cost, int smax, Counters *cnt)
+{
+	if (nlist <= 0) return;
+	hipLaunchKernelGGL(twoview_rows_refill_kernel, dim3((unsigned)nlist), dim3(64), 0, st,
+	                   views, ref, oth, P, y0, cflag, wbuf, rowinfo, meta, cost, smax, cnt);
 }
 
 // ------------------------------------------------------------------ scan with slot look-ups
 #define RS_QN 16
 
+// CERT / LISTED: as twoview_scan_kernel (srh_dense.hip): the certified scan on fused costs flags the pixels with a decision
+// the error bound does not cover; the listed scan is the exact scan of those pixels after twoview_rows_refill_kernel.
+template <bool CERT, bool LISTED>
 __global__ __launch_bounds__(RW_LT)
 void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                               int y0, int nrows, const int32_t *__restrict__ count,
                               const uint32_t *__restrict__ cand, int cmax,
                               const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
-                              const double *__restrict__ cost, int smax)
+                              const double *__restrict__ cost, int smax, uint32_t *__restrict__ cflag, int nlist,
+                              Counters *__restrict__ cnt, const CertBound cb)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
 	const int W = L.w;
-	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+	size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
 	__shared__ uint32_t s_row[RW_NR][RW_LT];                     // xlo | slot base << 16
-	if (q >= (size_t)nrows*W) return;
+	if (LISTED) {
+		if (q >= (size_t)nlist) return;
+		q = cflag[1 + q];
+	} else if (q >= (size_t)nrows*W) return;
 	const int x = (int)(q % W), y = y0 + (int)(q / W);
 	const size_t pv = (size_t)y*W + x;
 	double depth = __builtin_nan("");
@@ -578,6 +652,7 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		const double *crow = cost + ((size_t)(q / W)*tiles_per_row + (x >> 5))*(size_t)smax*32 + (x & 31);
 		double minCost = __builtin_inf(), secondBest = __builtin_inf();
 		uint32_t win = 0xffffffffu;
+		bool flag = false;
 		for (int k0 = 0; k0 < n; k0 += RS_QN) {
 			uint32_t e[RS_QN];
 			double c[RS_QN];
@@ -593,6 +668,12 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			}
 #pragma unroll
 			for (int j = 0; j < RS_QN; ++j) {
+				if (CERT && k0 + j < n) {
+					// (srh_dense.hip, twoview_scan_kernel: tolerance, "sure" values, the winner seen again)
+					const double t = c[j] + P.wta_margin;
+					if (!(fabs(t - minCost) > 2.5*cb.e0) && e[j] != win &&
+					    !(cert_sure(c[j], P.max_color_diff, cb.m_hi) && cert_sure(minCost, P.max_color_diff, cb.m_hi))) flag = true;
+				}
 				if (k0 + j < n && c[j] + P.wta_margin < minCost) {     // twoviewstereo.cpp:293-301
 					secondBest = minCost;
 					minCost = c[j];
@@ -606,17 +687,36 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		}
 		if (minCost > P.second_best_factor*secondBest)                 // twoviewstereo.cpp:304-305
 			depth = __builtin_inf();
+		if (CERT) {
+			if (win != 0xffffffffu) {
+				const double rhs = P.second_best_factor*secondBest;
+				const double tol = __builtin_fma(fmin(fabs(rhs), 1e300), 1e-15, (1.0 + fabs(P.second_best_factor))*cb.e0);
+				if (!(fabs(minCost - rhs) > tol) &&
+				    !(cert_sure(minCost, P.max_color_diff, cb.m_hi) && cert_sure(secondBest, P.max_color_diff, cb.m_hi))) flag = true;
+			}
+			if (flag) { cflag[1 + atomicAdd(&cflag[0], 1u)] = (uint32_t)q; atomicAdd(&cnt->n_flagged, 1ull); }
+		}
 	}
 	L.depth[pv] = depth;
 }
 
+// cflag == nullptr: exact scan.  cflag, nlist < 0: certified scan.  cflag, nlist >= 0: exact scan of the listed pixels.
 void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, int cmax,
-                              const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax)
+                              const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax,
+                              uint32_t *cflag, int nlist, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
-	hipLaunchKernelGGL(twoview_rows_scan_kernel, dim3((unsigned)((n + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
-	                   views, ref, oth, P, y0, nrows, count, cand, cmax, rowinfo, meta, cost, smax);
+	const CertBound cb = cert_bound(P);
+	if (!cflag)
+		hipLaunchKernelGGL((twoview_rows_scan_kernel<false, false>), dim3((unsigned)((n + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
+		                   views, ref, oth, P, y0, nrows, count, cand, cmax, rowinfo, meta, cost, smax, nullptr, 0, cnt, cb);
+	else if (nlist < 0)
+		hipLaunchKernelGGL((twoview_rows_scan_kernel<true, false>), dim3((unsigned)((n + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
+		                   views, ref, oth, P, y0, nrows, count, cand, cmax, rowinfo, meta, cost, smax, cflag, 0, cnt, cb);
+	else if (nlist > 0)
+		hipLaunchKernelGGL((twoview_rows_scan_kernel<false, true>), dim3((unsigned)((nlist + RW_LT - 1)/RW_LT)), dim3(RW_LT), 0, st,
+		                   views, ref, oth, P, y0, nrows, count, cand, cmax, rowinfo, meta, cost, smax, cflag, nlist, cnt, cb);
 }
 
 } // namespace srh

@@ -265,3 +265,61 @@ def test_certified_equals_exact_at_full_size(hip_ctx, W, H, D, wkind, seed):
     flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, strip, "%dx%dx%d" % (W, H, D))
     print("certified scan at %dx%dx%d: %d of %d pixels flagged and redone (%.3g)" % (W, H, D, flagged, scanned, flagged / scanned))
     assert flagged < 0.02 * scanned
+
+
+# ------------------------------------------------------------------- certified arithmetic on the row-run list path
+ROWS_CASES = [("geodesic_distorted", dict()), ("adaptive_verged", dict()), ("geodesic_verged_dist_masks", dict()),
+              ("adaptive_refractive", dict()), ("geodesic_distorted", dict(radius=5, w=120, h=72, D=30)),
+              ("adaptive_refractive", dict(radius=5, w=150, h=64, D=36, weight_kind=1)),
+              ("geodesic_verged_dist_masks", dict(radius=5, w=96, h=80, D=24))]
+
+
+def _rows_both_ways(ctx, p, arith):
+    ctx.set_option("arith", arith)
+    try:
+        out = []
+        for a, b in ((0, 1), (1, 0)):
+            ctx.twoview_wta(a, b, p)
+            out.append((ctx.download_depth(a), ctx.stats()))
+        return out
+    finally:
+        ctx.set_option("arith", capi.ARITH_DEFAULT)
+
+
+@pytest.mark.parametrize("name,over", ROWS_CASES)
+def test_certified_equals_exact_on_general_geometry(hip_ctx, name, over):
+    """Verged, distorted and refractive rigs take the row-run candidate lists (srh_rows.hip): its cost kernel has the same
+    certified fused form as the strip kernel, its scan the same checks."""
+    import cases
+    case = cases.get_twoview(name, **over)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    exact = _rows_both_ways(hip_ctx, p, capi.ARITH_EXACT)
+    cert = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+    for d in range(2):
+        assert not cert[d][1]["used_dense_path"] and exact[d][1]["n_certified"] == 0
+        assert cert[d][1]["n_certified"] == cert[d][1]["n_pixels"] > 0
+        assert np.array_equal(exact[d][0].view(np.uint64), cert[d][0].view(np.uint64)), (name, over, d)
+        assert exact[d][1]["n_eval"] == cert[d][1]["n_eval"]
+
+
+@pytest.mark.parametrize("kind", ["periodic", "flat", "near_flat", "saturated_half", "two_matches"])
+def test_certified_equals_exact_on_adversarial_images_general_geometry(hip_ctx, kind):
+    """The adversarial images once more under a slightly verged, distorted rig: row-run lists, curves crossing rows."""
+    W, H, D = 160, 80, 32
+    L, R, ml, mr = _adversarial_pair(kind, W, H, D)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    a = 0.01
+    Rr = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]]) @ Rr
+    tr = -Rr @ np.array([1.0, 0.02, 0.0])
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    dist = np.array([-0.05, 0.02, 0.001, 0.0, 0.0])
+    hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl, dist))
+    hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr, dist))
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
+    exact = _rows_both_ways(hip_ctx, p, capi.ARITH_EXACT)
+    cert = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+    for d in range(2):
+        assert not cert[d][1]["used_dense_path"] and cert[d][1]["n_certified"] > 0
+        assert np.array_equal(exact[d][0].view(np.uint64), cert[d][0].view(np.uint64)), (kind, d)
+    print("certified row-run scan, %s: %d of %d pixels flagged" % (kind, sum(c[1]["n_flagged"] for c in cert), sum(c[1]["n_certified"] for c in cert)))
