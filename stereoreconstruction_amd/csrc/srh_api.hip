@@ -1136,7 +1136,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*4))) return rc;
 		int lanes = 8;
 		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
-		const bool cert = strip && cert_ok;
+		const bool cert = dense && cert_ok;
 		const int cost_arith = c->arith == 3 ? (cert ? 3 : 0) : c->arith;
 		if (cert && (rc = ensure(c->cflag, c->cflag_cap, rows*(size_t)W + 1))) return rc;
 		if (strip) {
@@ -1168,16 +1168,30 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				Scope s(c, "pixel_range_kernel");
 				launch_pixel_range(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, cstride, c->prange);
 			}
-			if (dense && strip) {
+			if (dense) {
+				// the band's cost rows under one arithmetic: strip kernel or one workgroup per tile, then the left-out columns
 				auto cost_pass = [&](int arith) -> int {
-					HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));
-					{ Scope s(c, "twoview_strip_cost_kernel");
-					  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
-					                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
-					                            c->d_cnt, arith, c->num_cus, lanes); }
-					{ Scope s(c, "twoview_lazy_fill_kernel");
-					  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
-					                           c->views[ref].tvp, c->views[oth].tvp, lanes, c->cost, cstride, c->d_cnt); }
+					if (strip) {
+						HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));
+						{ Scope s(c, "twoview_strip_cost_kernel");
+						  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
+						                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
+						                            c->d_cnt, arith, c->num_cus, lanes); }
+						Scope s(c, "twoview_lazy_fill_kernel");
+						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
+						                         c->views[ref].tvp, c->views[oth].tvp, lanes, c->cost, cstride, c->d_cnt);
+					} else {
+						{ Scope s(c, "twoview_dense_cost_kernel");
+						  if (arith == 2)
+							launch_twoview_dense_cost_f32(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
+							                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst);
+						  else
+							launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
+							                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, arith); }
+						Scope s(c, "twoview_lazy_fill_kernel");
+						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
+						                         nullptr, nullptr, 8, c->cost, cstride, c->d_cnt);
+					}
 					return SRH_OK;
 				};
 				if (cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
@@ -1197,26 +1211,17 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, nullptr, c->prange);
 					} else if (nflag) {
 						{ Scope s(c, "twoview_refill_kernel");
-						  launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, (int)nflag, c->wbuf, c->views[ref].tvp,
-						                        c->views[oth].tvp, c->cost, cstride, c->d_cnt); }
+						  if (strip)
+							launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, (int)nflag, c->wbuf, c->views[ref].tvp,
+							                      c->views[oth].tvp, c->cost, cstride, c->d_cnt);
+						  else
+							launch_twoview_refill_tiles(c->stream, c->d_views, ref, oth, *p, by, c->prange, c->cflag, (int)nflag, c->wbuf,
+							                            wstride, c->cost, cstride, c->d_cnt); }
 						Scope s(c, "twoview_rescan_kernel");
 						launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
 						                    c->cflag, (int)nflag);
 					}
 				}
-			} else if (dense) {
-				{ Scope s(c, "twoview_dense_cost_kernel");
-				  if (c->arith == 2)
-					launch_twoview_dense_cost_f32(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-					                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst);
-				  else
-					launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-					                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->arith == 3 ? 0 : c->arith); }
-				{ Scope s(c, "twoview_lazy_fill_kernel");
-				  launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
-				                           nullptr, nullptr, 8, c->cost, cstride, c->d_cnt); }
-				{ Scope s(c, "twoview_scan_kernel");
-				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange); }
 			} else {
 				Scope s(c, "twoview_generic_kernel");
 				launch_twoview_generic(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride, c->d_cnt);

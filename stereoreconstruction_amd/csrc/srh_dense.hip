@@ -440,13 +440,17 @@ void exp_set(int repeat, int lds_pad) {
 // fused (one rounding instead of two): half the FP64 instructions, costs differ from the reference's in the last
 // bits (|delta cost| ~ 1e-13), which can flip a winner only between near-tied candidates -- the mismatch rate is
 // measured, not assumed (bench.py --arith fma, tests/test_gpu_arith_modes.py).
-template <int R, int DC_NCB, int DC_CHUNK, int MINW, bool FMA>
+// AR = 3: the certified mode (srh_internal.hpp, CertBound): fused loops, and every fast-form value stored
+// by the rule of the certified scan -- NaN for a candidate the bound does not cover, the clamp itself above clamp + e0,
+// anything else unclamped.
+template <int R, int DC_NCB, int DC_CHUNK, int MINW, int AR>
 __global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                                const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
-                               Counters *__restrict__ cnt, const double *__restrict__ pconst)
+                               Counters *__restrict__ cnt, const double *__restrict__ pconst, const CertBound cb)
 {
+	constexpr bool FMA = AR != 0, CERT = AR == 3;
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
 	typedef DenseSmem<R, DC_NCB, DC_CHUNK> Smem;
@@ -655,6 +659,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #endif
 				if (fast) {
 					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
+					const double sig3 = CERT ? cb.sigma3(s2) : 0.0;
 					// Both passes are modulo-scheduled by hand: r[] / wv[] / av[] hold the current
 					// window row; as soon as a value has had its last use, the same register is
 					// refilled with the next row's value, so the LDS latency is always a row ahead.
@@ -761,7 +766,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 						const int c = c0 + j;
 						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							crow[(size_t)(c - e.xmin)*DC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							if (CERT) crow[(size_t)(c - e.xmin)*DC_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
+							else crow[(size_t)(c - e.xmin)*DC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
@@ -812,7 +818,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #undef SRH_STAMP
 }
 
-template <int R, int NCB, int CHUNK, int MINW, bool FMA>
+template <int R, int NCB, int CHUNK, int MINW, int AR>
 static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
                                  int y0, int nrows, const double *wbuf, size_t wstride,
                                  const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst)
@@ -824,10 +830,10 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
 #ifdef SRH_EXPERIMENT
 	lds += (size_t)g_exp_lds_pad;
 #endif
-	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>,
+	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, AR>,
 	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, FMA>), grid, dim3(DC_THREADS), lds, st,
-	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst);
+	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, AR>), grid, dim3(DC_THREADS), lds, st,
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst, cert_bound(P));
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -839,10 +845,14 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 #define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst
 	switch (P.window_radius) {
 	case 5:
-		if (arith == 1) launch_dense_variant<5, 8, 320, 2, true>(SRH_ARGS); else launch_dense_variant<5, 8, 320, 2, false>(SRH_ARGS);
+		if (arith == 3) launch_dense_variant<5, 8, 320, 2, 3>(SRH_ARGS);
+		else if (arith == 1) launch_dense_variant<5, 8, 320, 2, 1>(SRH_ARGS);
+		else launch_dense_variant<5, 8, 320, 2, 0>(SRH_ARGS);
 		return true;
 	case 2:
-		if (arith == 1) launch_dense_variant<2, 8, 320, 2, true>(SRH_ARGS); else launch_dense_variant<2, 8, 320, 2, false>(SRH_ARGS);
+		if (arith == 3) launch_dense_variant<2, 8, 320, 2, 3>(SRH_ARGS);
+		else if (arith == 1) launch_dense_variant<2, 8, 320, 2, 1>(SRH_ARGS);
+		else launch_dense_variant<2, 8, 320, 2, 0>(SRH_ARGS);
 		return true;
 	default: return false;
 	}
@@ -997,6 +1007,40 @@ void twoview_refill_kernel(int W, srh_params P, int y0, const PixRange *__restri
 		++n;
 	}
 	block_count_add(&cnt->n_eval_device, n);
+}
+
+// the same for the per-tile path: windows tile-major, taps through the views (tv_cost: any validity pattern)
+__global__ __launch_bounds__(64)
+void twoview_refill_tiles_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
+                                 const PixRange *__restrict__ prange, const uint32_t *__restrict__ cflag,
+                                 const double *__restrict__ wbuf, size_t wstride, double *__restrict__ cost, int cstride,
+                                 Counters *__restrict__ cnt)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w;
+	const uint32_t q = cflag[1 + blockIdx.x];
+	const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
+	const PixRange pr = prange[q];
+	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
+	const double *wq = wbuf + wbuf_offset(W, T, trow, x);
+	double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+	unsigned n = 0;
+	for (int c = pr.lo + (int)threadIdx.x; c <= pr.hi; c += 64) {
+		crow[(size_t)(c - pr.lo)*DC_TP] = tv_cost(L, Rv, wq, wstride, P, x, y, c, y);
+		++n;
+	}
+	block_count_add(&cnt->n_eval_device, n);
+}
+
+bool launch_twoview_refill_tiles(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
+                                 const PixRange *prange, const uint32_t *cflag, int nlist, const double *wbuf, size_t wstride,
+                                 double *cost, int cstride, Counters *cnt)
+{
+	if (nlist <= 0) return true;
+	hipLaunchKernelGGL(twoview_refill_tiles_kernel, dim3((unsigned)nlist), dim3(64), 0, st,
+	                   views, ref, oth, P, y0, prange, cflag, wbuf, wstride, cost, cstride, cnt);
+	return true;
 }
 
 bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int nlist,

@@ -178,6 +178,10 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          Counters *cnt, const PixRange *prange, uint32_t *cflag = nullptr, int nlist = -1);
+// (per-tile path's buffers: tile-major windows)
+bool launch_twoview_refill_tiles(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
+                                 const PixRange *prange, const uint32_t *cflag, int nlist, const double *wbuf, size_t wstride,
+                                 double *cost, int cstride, Counters *cnt);
 // the cost rows of the listed pixels in the reference's arithmetic (strip path's buffers)
 bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int nlist,
                            const double *wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt);

@@ -569,8 +569,8 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 }
 
 // Certified arithmetic: every cost slot of the flagged pixels (cflag[1 .. 1 + nlist)) once more, in the reference's
-// arithmetic (tv_cost: any validity pattern) -- one 64-lane workgroup per pixel, a lane per slot.
-__global__ __launch_bounds__(64)
+// arithmetic (tv_cost: any validity pattern) -- one 256-lane workgroup per pixel, a lane per slot.
+__global__ __launch_bounds__(256)
 void twoview_rows_refill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
                                 const uint32_t *__restrict__ cflag, const double *__restrict__ wbuf,
                                 const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
@@ -592,7 +592,7 @@ void twoview_rows_refill_kernel(const ViewDev *__restrict__ views, int ref, int 
 	for (int r = 0; r < nr; ++r) {
 		const uint32_t info = rowinfo[((q >> 6)*RW_NR + r)*64 + (q & 63)];
 		const int xlo = (int)(short)(info & 0xffff), wdt = (int)(info >> 16);
-		for (int k = (int)threadIdx.x; k < wdt; k += 64) {
+		for (int k = (int)threadIdx.x; k < wdt; k += 256) {
 			crow[(size_t)(base + k)*32] = tv_cost(L, Rv, wq, SRH_WTILE, P, x, y, xlo + k, ymin + r);
 			++n;
 		}
@@ -606,7 +606,7 @@ void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, i
                                 double *cost, int smax, Counters *cnt)
 {
 	if (nlist <= 0) return;
-	hipLaunchKernelGGL(twoview_rows_refill_kernel, dim3((unsigned)nlist), dim3(64), 0, st,
+	hipLaunchKernelGGL(twoview_rows_refill_kernel, dim3((unsigned)nlist), dim3(256), 0, st,
 	                   views, ref, oth, P, y0, cflag, wbuf, rowinfo, meta, cost, smax, cnt);
 }
 

@@ -126,7 +126,7 @@ def test_arith_option_validation(hip_ctx):
 # ---------------------------------------------------------------------------------------------- certified arithmetic
 def _both_ways(ctx, p, arith, strip):
     """(left map, right map, stats of each pass) of WTA both ways under one arithmetic; strip = 8 / 4 forces the strip
-    kernel on images too small for it by default (the certified arithmetic lives in the strip kernel)."""
+    kernel on images too small for it by default, strip = 0 the one-workgroup-per-tile kernel (both have the certified form)."""
     ctx.set_option("arith", arith)
     ctx.set_option("strip", strip)
     try:
@@ -145,7 +145,8 @@ def _assert_certified_equals_exact(ctx, p, strip, tag):
     cert = _both_ways(ctx, p, capi.ARITH_CERTIFIED, strip)
     flagged = 0
     for d in range(2):
-        assert exact[d][1]["used_strip_kernel"] and cert[d][1]["used_strip_kernel"], tag
+        assert exact[d][1]["used_dense_path"] and cert[d][1]["used_dense_path"], tag
+        assert bool(exact[d][1]["used_strip_kernel"]) == bool(cert[d][1]["used_strip_kernel"]) == (strip != 0), tag
         assert exact[d][1]["n_certified"] == 0
         assert cert[d][1]["n_certified"] == cert[d][1]["n_pixels"] > 0, (tag, cert[d][1])
         assert np.array_equal(exact[d][0].view(np.uint64), cert[d][0].view(np.uint64)), \
@@ -163,7 +164,7 @@ CERT_CASES = [("geodesic_rect", dict()), ("adaptive_rect", dict()), ("geodesic_m
 
 
 @pytest.mark.parametrize("name,over", CERT_CASES)
-@pytest.mark.parametrize("strip", [4, 8])
+@pytest.mark.parametrize("strip", [0, 4, 8])
 def test_certified_equals_exact_on_the_parity_cases(hip_ctx, name, over, strip):
     import cases
     case = cases.get_twoview(name, **over)
@@ -219,10 +220,11 @@ def _adversarial_pair(kind, W=192, H=96, D=40, seed=7):
     return L, R, ml, mr
 
 
+@pytest.mark.parametrize("strip", [8, 0], ids=["strip", "per-tile"])
 @pytest.mark.parametrize("wkind", [capi.WEIGHT_GEODESIC, capi.WEIGHT_ADAPTIVE], ids=["geodesic", "adaptive"])
 @pytest.mark.parametrize("kind", ["periodic", "periodic_rows_differ", "flat", "near_flat", "saturated_half", "two_level",
                                   "two_matches", "ramp"])
-def test_certified_equals_exact_on_adversarial_images(hip_ctx, kind, wkind):
+def test_certified_equals_exact_on_adversarial_images(hip_ctx, kind, wkind, strip):
     W, H, D = 192, 96, 40
     L, R, ml, mr = _adversarial_pair(kind, W, H, D)
     (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
@@ -230,7 +232,7 @@ def test_certified_equals_exact_on_adversarial_images(hip_ctx, kind, wkind):
     hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl))
     hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr))
     p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
-    flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, 8, kind)
+    flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, strip, kind)
     print("certified scan, %s / %s: %d of %d pixels flagged and redone" % (kind, "geodesic" if wkind else "adaptive", flagged, scanned))
     if kind in ("flat", "periodic"):
         assert flagged > 0, "an image made of exact ties must trip the bound somewhere"
@@ -261,8 +263,10 @@ def test_certified_equals_exact_at_full_size(hip_ctx, W, H, D, wkind, seed):
     """C3 and C2 at BASELINE size, both directions: the default (certified) arithmetic gives the reference arithmetic's
     bits; the flagged fraction is what the bench line reports."""
     p = _pair(hip_ctx, W, H, D, seed, wkind)
-    strip = 1 if W >= 1920 else 8
-    flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, strip, "%dx%dx%d" % (W, H, D))
+    strip = 1 if W >= 1920 else 0                             # (what each size takes by default)
+    hip_ctx.twoview_wta(0, 1, p)
+    assert bool(hip_ctx.stats()["used_strip_kernel"]) == (strip == 1)
+    flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, strip if strip == 0 else 8, "%dx%dx%d" % (W, H, D))
     print("certified scan at %dx%dx%d: %d of %d pixels flagged and redone (%.3g)" % (W, H, D, flagged, scanned, flagged / scanned))
     assert flagged < 0.02 * scanned
 
