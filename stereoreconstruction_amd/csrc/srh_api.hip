@@ -961,9 +961,12 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 	bool strip = dense && c->strip != 0 && c->arith != 2 && cstride + SRH_WTILE <= strip_chunk_columns();
 	// certified arithmetic (arith = 3, the default): fused cost loops in the strip kernel + the certified scan; where the
 	// strip kernel does not run, or the parameters leave the bound no room, the reference's arithmetic
-	const bool cert_ok = c->arith == 3 && cert_bound(*p).ok != 0;
+	bool cert_ok = c->arith == 3 && cert_bound(*p).ok != 0;
 	c->stats.n_certified = c->stats.n_flagged = 0;
-	for (int attempt = 0; attempt < 3; ++attempt) {
+	// the exact redo of flagged pixels is launched for a fixed capacity (the host does not wait for the count): a band
+	// that flags more (adversarial images: exact ties everywhere) makes the whole pass run again in mode 0
+	auto redo_capacity = [](size_t band_pixels) { return (int)std::min<size_t>(std::max<size_t>(band_pixels/32, 256), 16384); };
+	for (int attempt = 0; attempt < 4; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		// ---- arbitrary geometry: candidate lists (the one-thread-per-pixel walk kernel is the last resort)
 		if (!dense && !c->force_walk && R <= 5 && W < 65536 && H < 65536) {
@@ -994,7 +997,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 			bool rows_mode = c->list_rows && W < 32768 && H < 32768;       // spans and row origins are stored as 16-bit signed
 			if (c->views[ref].list_mode[oth] == 2) rows_mode = false;      // learnt: steep curves, list order is cheaper
 			int smax = c->list_smax_hint > 0 ? c->list_smax_hint : cmax + 64;
-			for (int pass = 0; pass < 5; ++pass) {
+			for (int pass = 0; pass < 6; ++pass) {
 				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 				HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
 				const int ccap = rows_mode ? smax : cmax;             // cost values per pixel
@@ -1045,26 +1048,15 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, rows_cert ? c->cflag : nullptr, -1, c->d_cnt); }
 						if (rows_cert) {
-							// certified arithmetic: the flagged pixels once more in the reference's arithmetic (a list cut by a too
-							// small capacity is harmless here: the pass is repeated anyway); more than 1 pixel in 32: the whole band
-							uint32_t nflag = 0;
-							HIP_TRY(hipMemcpyAsync(&nflag, c->cflag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-							HIP_TRY(hipStreamSynchronize(c->stream));
-							if ((size_t)nflag*32 > (size_t)nr*W) {
-								{ Scope s(c, "twoview_rows_cost_kernel");
-								  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
-								                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, 0); }
-								Scope s(c, "twoview_rows_scan_kernel");
-								launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
-								                         c->lrowinfo, c->lmeta, c->cost, smax);
-							} else if (nflag) {
-								{ Scope s(c, "twoview_rows_refill_kernel");
-								  launch_twoview_rows_refill(c->stream, c->d_views, ref, oth, *p, by, c->cflag, (int)nflag, c->wbuf,
-								                             c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
-								Scope s(c, "twoview_rows_rescan_kernel");
-								launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
-								                         c->lrowinfo, c->lmeta, c->cost, smax, c->cflag, (int)nflag, c->d_cnt);
-							}
+							// certified arithmetic: the flagged pixels once more in the reference's arithmetic, launched for a capacity
+							// (a list cut by a too small capacity is harmless here: the pass is repeated anyway)
+							const int cap = redo_capacity((size_t)nr*W);
+							{ Scope s(c, "twoview_rows_refill_kernel");
+							  launch_twoview_rows_refill(c->stream, c->d_views, ref, oth, *p, by, c->cflag, cap, c->wbuf,
+							                             c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
+							Scope s(c, "twoview_rows_rescan_kernel");
+							launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
+							                         c->lrowinfo, c->lmeta, c->cost, smax, c->cflag, cap, c->d_cnt);
 						}
 						continue;
 					}
@@ -1100,6 +1092,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
 						HIP_TRY(hipStreamSynchronize(c->stream));
 						c->views[ref].list_mode[oth] = (hc.n_slots > 2.2*(double)hc.n_listed) ? 2 : 1;
+						if (hc.cert_overflow != 0) { cert_ok = false; continue; }   // more flagged pixels than the redo covers: mode 0
 						if (rows_cert) { c->stats.n_certified = (int64_t)hc.n_pixels; c->stats.n_flagged = (int64_t)hc.n_flagged; }
 						break;
 					}
@@ -1139,9 +1132,11 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		const bool cert = dense && cert_ok;
 		const int cost_arith = c->arith == 3 ? (cert ? 3 : 0) : c->arith;
 		if (cert && (rc = ensure(c->cflag, c->cflag_cap, rows*(size_t)W + 1))) return rc;
-		if (strip) {
-			lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);
-			// NaN-bordered gray_tv planes of both views, zero-bordered "window fully usable" plane of the other view
+		const bool planes = dense && (R == 5 || R == 2);
+		if (strip) lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);
+		if (planes) {
+			// NaN-bordered gray_tv planes of both views (strip kernel; the general cost of the left-out columns and of the
+			// certified redo on either dense path)
 			for (int k = 0; k < 2; ++k) {
 				ViewHost &v = c->views[k == 0 ? ref : oth];
 				if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
@@ -1151,6 +1146,9 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					v.tvp_valid = true;
 				}
 			}
+		}
+		if (strip) {
+			// zero-bordered "window fully usable" plane of the other view
 			ViewHost &O = c->views[oth];
 			if (!O.fullp) HIP_TRY(hipMalloc((void **)&O.fullp, padded_size(O.w, O.h)));
 			if (O.fullp_r != R) {
@@ -1179,7 +1177,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						                            c->d_cnt, arith, c->num_cus, lanes); }
 						Scope s(c, "twoview_lazy_fill_kernel");
 						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
-						                         c->views[ref].tvp, c->views[oth].tvp, lanes, c->cost, cstride, c->d_cnt);
+						                         c->views[ref].tvp, c->views[oth].tvp, true, lanes, c->cost, cstride, c->d_cnt);
 					} else {
 						{ Scope s(c, "twoview_dense_cost_kernel");
 						  if (arith == 2)
@@ -1190,7 +1188,8 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 							                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, arith); }
 						Scope s(c, "twoview_lazy_fill_kernel");
 						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
-						                         nullptr, nullptr, 8, c->cost, cstride, c->d_cnt);
+						                         planes ? c->views[ref].tvp : nullptr, planes ? c->views[oth].tvp : nullptr, false, 8,
+						                         c->cost, cstride, c->d_cnt);
 					}
 					return SRH_OK;
 				};
@@ -1201,26 +1200,14 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				                      cert ? c->cflag : nullptr, -1); }
 				if (cert) {
 					// the pixels whose decisions the bound does not cover, in the reference's arithmetic: their cost rows are
-					// refilled and scanned again; a band with more than 1 in 32 of them is redone as a whole
-					uint32_t nflag = 0;
-					HIP_TRY(hipMemcpyAsync(&nflag, c->cflag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-					HIP_TRY(hipStreamSynchronize(c->stream));
-					if ((size_t)nflag*32 > (size_t)nr*W) {
-						if ((rc = cost_pass(0))) return rc;
-						Scope s(c, "twoview_scan_kernel");
-						launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, nullptr, c->prange);
-					} else if (nflag) {
-						{ Scope s(c, "twoview_refill_kernel");
-						  if (strip)
-							launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, (int)nflag, c->wbuf, c->views[ref].tvp,
-							                      c->views[oth].tvp, c->cost, cstride, c->d_cnt);
-						  else
-							launch_twoview_refill_tiles(c->stream, c->d_views, ref, oth, *p, by, c->prange, c->cflag, (int)nflag, c->wbuf,
-							                            wstride, c->cost, cstride, c->d_cnt); }
-						Scope s(c, "twoview_rescan_kernel");
-						launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
-						                    c->cflag, (int)nflag);
-					}
+					// refilled and they are scanned again -- launched for a capacity, the count stays on the device
+					const int cap = redo_capacity((size_t)nr*W);
+					{ Scope s(c, "twoview_refill_kernel");
+					  launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, cap, c->wbuf, strip, c->views[ref].tvp,
+					                        c->views[oth].tvp, c->cost, cstride, c->d_cnt); }
+					Scope s(c, "twoview_rescan_kernel");
+					launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
+					                    c->cflag, cap);
 				}
 			} else {
 				Scope s(c, "twoview_generic_kernel");
@@ -1234,6 +1221,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (strip && hc.strip_overflow != 0) { strip = false; continue; }   // a tile's ranges did not fit one chunk: per-tile kernel
+		if (hc.cert_overflow != 0) { cert_ok = false; continue; }           // more flagged pixels than the redo covers: mode 0
 		c->stats.n_certified = (int64_t)hc.n_certified; c->stats.n_flagged = (int64_t)hc.n_flagged;
 		if (hc.not_row_aligned == 0) break;
 		dense = false;                                              // redo with the general kernel

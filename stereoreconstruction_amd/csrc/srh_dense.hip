@@ -878,7 +878,7 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 // The columns the cost kernel leaves out (dense_cover_hi: a last block that would cost its lanes a whole extra round
 // for one or two columns) are evaluated here, one thread per pixel, with the general cost -- so that the scan kernel
 // only ever looks costs up.  (Inlined at every slot of the scan's flushes, that general cost made the scan kernel
-// 27 000 instructions long, far beyond the instruction cache.)
+// 27 000 instructions long, far beyond the instruction cache.)  Radii without a template instance: tv_cost through the views.
 __global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0, int nrows,
                                          const PixRange *__restrict__ prange, const double *__restrict__ wbuf, size_t wstride,
                                          int ncb, int lanes, double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
@@ -907,14 +907,13 @@ __global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int 
 	block_count_add(&cnt->n_eval_device, n_lazy);
 }
 
-// The same for the strip path: windows in the LDS-image layout (a window row = 11 contiguous doubles), image rows from
-// the NaN-bordered planes (no bound tests), loops unrolled by window row so that a row's 33 loads travel together.
-// Same sums, same order as tv_cost (twoviewstereo.cpp:909-977): a skipped tap adds +0.0.
-// cost_ncc in the reference's arithmetic for ANY validity pattern, from the LDS-image windows and the NaN-bordered planes:
-// wq = the pixel's window, lp / rp = top-left tap of the two windows in the padded planes (stride SP)
+// cost_ncc in the reference's arithmetic for ANY validity pattern (a skipped tap adds +0.0: the same sums, same order as
+// tv_cost, twoviewstereo.cpp:909-977), from a window in either band layout and the NaN-bordered planes (no bound tests,
+// loops unrolled by window row so that a row's 33 loads travel together):
+// tap (row, col) of the window at wq[row*wrow + col*wcol]; lp / rp = top-left tap of the two windows in the padded planes (stride SP)
 template <int R>
-__device__ __forceinline__ double wimg_exact_cost(const double *__restrict__ wq, int wrow, const double *__restrict__ lp,
-                                                  const double *__restrict__ rp, int SP, const srh_params &P)
+__device__ __forceinline__ double window_exact_cost(const double *__restrict__ wq, int wrow, int wcol, const double *__restrict__ lp,
+                                                    const double *__restrict__ rp, int SP, const srh_params &P)
 {
 	constexpr int WS = 2*R + 1;
 	double meanL = 0, meanR = 0, totalWeight = 0.0;
@@ -922,7 +921,7 @@ __device__ __forceinline__ double wimg_exact_cost(const double *__restrict__ wq,
 	for (int row = 0; row < WS; ++row) {
 		double gl[WS], gr[WS], wt[WS];
 #pragma unroll
-		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
+		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col*wcol]; }
 #pragma unroll
 		for (int col = 0; col < WS; ++col) {
 			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
@@ -940,7 +939,7 @@ __device__ __forceinline__ double wimg_exact_cost(const double *__restrict__ wq,
 	for (int row = 0; row < WS; ++row) {
 		double gl[WS], gr[WS], wt[WS];
 #pragma unroll
-		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col]; }
+		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col*wcol]; }
 #pragma unroll
 		for (int col = 0; col < WS; ++col) {
 			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
@@ -955,12 +954,23 @@ __device__ __forceinline__ double wimg_exact_cost(const double *__restrict__ wq,
 	return (v < P.max_color_diff) ? v : P.max_color_diff;
 }
 
+// where a pixel's window lies in the band buffer: wimg != 0 the strip path's LDS-image layout, else tile-major
+struct WindowAt { const double *wq; int wrow, wcol; };
+template <int R>
+__device__ __forceinline__ WindowAt window_at(const double *wbuf, int wimg, int W, int trow, int x) {
+	constexpr int WS = 2*R + 1;
+	WindowAt a;
+	if (wimg) { a.wq = wbuf + wimg_offset(W, R, trow, x); a.wrow = wimg_row_stride(R); a.wcol = 1; }
+	else      { a.wq = wbuf + wbuf_offset(W, WS*WS, trow, x); a.wrow = WS*SRH_WTILE; a.wcol = SRH_WTILE; }
+	return a;
+}
+
 template <int R>
 __global__ __launch_bounds__(256)
-void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const PixRange *__restrict__ prange,
-                                   const double *__restrict__ wimg, const double *__restrict__ ref_tvp,
-                                   const double *__restrict__ oth_tvp, int ncb, int lanes, int pad,
-                                   double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
+void twoview_lazy_fill_planes_kernel(int W, srh_params P, int y0, int nrows, const PixRange *__restrict__ prange,
+                                     const double *__restrict__ wbuf, int wimg, const double *__restrict__ ref_tvp,
+                                     const double *__restrict__ oth_tvp, int ncb, int lanes, int pad,
+                                     double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
 {
 	const size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
 	unsigned n_lazy = 0;
@@ -970,13 +980,12 @@ void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const
 		const int cover = pr.hi >= pr.lo ? dense_cover_hi(pr.lo, pr.hi, ncb, lanes, pad != 0) : pr.hi;
 		if (cover < pr.hi) {
 			const int SP = padded_stride(W);
-			const double *wq = wimg + wimg_offset(W, R, trow, x);
-			const int wrow = wimg_row_stride(R);
+			const WindowAt wa = window_at<R>(wbuf, wimg, W, trow, x);
 			const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SP + (x + SRH_PADL - R);
 			double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 			for (int c = cover + 1; c <= pr.hi; ++c) {
 				const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
-				crow[(size_t)(c - pr.lo)*DC_TP] = wimg_exact_cost<R>(wq, wrow, lp, rp, SP, P);
+				crow[(size_t)(c - pr.lo)*DC_TP] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SP, P);
 				++n_lazy;
 			}
 		}
@@ -984,88 +993,61 @@ void twoview_lazy_fill_wimg_kernel(int W, srh_params P, int y0, int nrows, const
 	block_count_add(&cnt->n_eval_device, n_lazy);
 }
 
-// Certified arithmetic: the cost rows of the flagged pixels (cflag[1 .. 1 + nlist)) once more, every column of the pixel's
-// range in the reference's arithmetic -- one 64-lane workgroup per pixel, a lane per column.
+// Certified arithmetic: the cost rows of the flagged pixels (cflag[1 .. 1 + cflag[0])) once more, every column of the pixel's
+// range in the reference's arithmetic -- one 64-lane workgroup per pixel, a lane per column.  The grid is sized by the
+// CAPACITY of the redo (`cap` workgroups: the host does not wait for the count); workgroups beyond the count leave at
+// once, and a count above the capacity is reported in cnt->cert_overflow: the host then repeats the pass in mode 0.
 template <int R>
 __global__ __launch_bounds__(64)
-void twoview_refill_kernel(int W, srh_params P, int y0, const PixRange *__restrict__ prange, const uint32_t *__restrict__ cflag,
-                           const double *__restrict__ wimg, const double *__restrict__ ref_tvp, const double *__restrict__ oth_tvp,
+void twoview_refill_kernel(int W, srh_params P, int y0, const PixRange *__restrict__ prange, const uint32_t *__restrict__ cflag, int cap,
+                           const double *__restrict__ wbuf, int wimg, const double *__restrict__ ref_tvp, const double *__restrict__ oth_tvp,
                            double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
 {
+	const uint32_t nflag = cflag[0];
+	if (blockIdx.x == 0 && threadIdx.x == 0 && nflag > (uint32_t)cap) atomicAdd(&cnt->cert_overflow, 1ull);
+	if (blockIdx.x >= nflag) return;
 	const uint32_t q = cflag[1 + blockIdx.x];
 	const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
 	const PixRange pr = prange[q];
 	const int SP = padded_stride(W);
-	const double *wq = wimg + wimg_offset(W, R, trow, x);
-	const int wrow = wimg_row_stride(R);
+	const WindowAt wa = window_at<R>(wbuf, wimg, W, trow, x);
 	const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SP + (x + SRH_PADL - R);
 	double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 	unsigned n = 0;
 	for (int c = pr.lo + (int)threadIdx.x; c <= pr.hi; c += 64) {
 		const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
-		crow[(size_t)(c - pr.lo)*DC_TP] = wimg_exact_cost<R>(wq, wrow, lp, rp, SP, P);
+		crow[(size_t)(c - pr.lo)*DC_TP] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SP, P);
 		++n;
 	}
 	block_count_add(&cnt->n_eval_device, n);
 }
 
-// the same for the per-tile path: windows tile-major, taps through the views (tv_cost: any validity pattern)
-__global__ __launch_bounds__(64)
-void twoview_refill_tiles_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
-                                 const PixRange *__restrict__ prange, const uint32_t *__restrict__ cflag,
-                                 const double *__restrict__ wbuf, size_t wstride, double *__restrict__ cost, int cstride,
-                                 Counters *__restrict__ cnt)
+bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int cap,
+                           const double *wbuf, bool wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt)
 {
-	const ViewDev &L = views[ref];
-	const ViewDev &Rv = views[oth];
-	const int W = L.w;
-	const uint32_t q = cflag[1 + blockIdx.x];
-	const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
-	const PixRange pr = prange[q];
-	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
-	const double *wq = wbuf + wbuf_offset(W, T, trow, x);
-	double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
-	unsigned n = 0;
-	for (int c = pr.lo + (int)threadIdx.x; c <= pr.hi; c += 64) {
-		crow[(size_t)(c - pr.lo)*DC_TP] = tv_cost(L, Rv, wq, wstride, P, x, y, c, y);
-		++n;
-	}
-	block_count_add(&cnt->n_eval_device, n);
-}
-
-bool launch_twoview_refill_tiles(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
-                                 const PixRange *prange, const uint32_t *cflag, int nlist, const double *wbuf, size_t wstride,
-                                 double *cost, int cstride, Counters *cnt)
-{
-	if (nlist <= 0) return true;
-	hipLaunchKernelGGL(twoview_refill_tiles_kernel, dim3((unsigned)nlist), dim3(64), 0, st,
-	                   views, ref, oth, P, y0, prange, cflag, wbuf, wstride, cost, cstride, cnt);
-	return true;
-}
-
-bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int nlist,
-                           const double *wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt)
-{
-	if (nlist <= 0) return true;
+	if (cap <= 0) return true;
 	if (P.window_radius == 5)
-		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)nlist), dim3(64), 0, st, width, P, y0, prange, cflag, wimg, ref_tvp, oth_tvp, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)cap), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
 	else if (P.window_radius == 2)
-		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)nlist), dim3(64), 0, st, width, P, y0, prange, cflag, wimg, ref_tvp, oth_tvp, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)cap), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
 	else return false;
 	return true;
 }
 
+// ref_tvp / oth_tvp: the NaN-bordered planes (radius 5 or 2: the fast general cost); null: tv_cost through the views.
+// wimg: the band buffer holds the strip path's LDS-image windows (lanes / pad as that kernel's form), else tile-major.
 void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,
-                              const double *ref_tvp, const double *oth_tvp,
+                              const double *ref_tvp, const double *oth_tvp, bool wimg,
                               int lanes, double *cost, int cstride, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + 255)/256)), block(256);
+	const int pad = (!wimg || lanes == 8) ? 1 : 0;
 	if (ref_tvp && P.window_radius == 5)
-		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<5>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, lanes == 8 ? 1 : 0, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_lazy_fill_planes_kernel<5>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, 8, lanes, pad, cost, cstride, cnt);
 	else if (ref_tvp && P.window_radius == 2)
-		hipLaunchKernelGGL(twoview_lazy_fill_wimg_kernel<2>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, ref_tvp, oth_tvp, 8, lanes, lanes == 8 ? 1 : 0, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_lazy_fill_planes_kernel<2>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, 8, lanes, pad, cost, cstride, cnt);
 	else
 		hipLaunchKernelGGL(twoview_lazy_fill_kernel, grid, block, 0, st, views, ref, oth, P, y0, nrows, prange, wbuf, wstride, 8, lanes, cost, cstride, cnt);
 }
@@ -1125,8 +1107,10 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	int trow, x;
 	bool listed_on = true;
 	if (LISTED) {
+		// (grid sized by the capacity `nlist`: the count is on the device, twoview_refill_kernel)
+		const uint32_t nflag = cflag[0];
 		const int k = blockIdx.x*SC_TW + tid;
-		listed_on = k < nlist;
+		listed_on = k < nlist && (uint32_t)k < nflag;
 		const uint32_t q = listed_on ? cflag[1 + k] : 0u;
 		trow = (int)(q / (uint32_t)W); x = (int)(q % (uint32_t)W);
 	} else {

@@ -122,6 +122,7 @@ struct Counters {
 	unsigned long long n_listed, n_slots; // row-run lists: distinct candidates / cost slots (8-column blocks) they occupy
 	unsigned long long strip_overflow;    // strip kernel: tiles whose candidate range does not fit one LDS chunk
 	unsigned long long n_certified, n_flagged;   // certified scan: reference pixels scanned on fused costs / flagged for the exact redo
+	unsigned long long cert_overflow;     // certified redo: a band flagged more pixels than the redo's launch covers
 	unsigned int strip_ticket, strip_pad; // strip kernel: work-item counter of the current launch
 	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
 	unsigned long long dbg_phase[8];
@@ -175,20 +176,19 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
 // cflag == nullptr: the exact scan (cnt == nullptr: without counting).  cflag, nlist < 0: the certified scan on fused
 // costs, flagged pixels into cflag = [count | band pixel indices].  cflag, nlist >= 0: the exact scan of the listed pixels
+// (launch sized for nlist pixels, the count itself is read on the device)
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          Counters *cnt, const PixRange *prange, uint32_t *cflag = nullptr, int nlist = -1);
-// (per-tile path's buffers: tile-major windows)
-bool launch_twoview_refill_tiles(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
-                                 const PixRange *prange, const uint32_t *cflag, int nlist, const double *wbuf, size_t wstride,
-                                 double *cost, int cstride, Counters *cnt);
-// the cost rows of the listed pixels in the reference's arithmetic (strip path's buffers)
-bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int nlist,
-                           const double *wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt);
+// the cost rows of the flagged pixels in the reference's arithmetic; `cap` workgroups (the count is read on the device;
+// a count above cap is reported in Counters::cert_overflow); wimg: LDS-image windows, else tile-major
+bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int cap,
+                           const double *wbuf, bool wimg, const double *ref_tvp, const double *oth_tvp, double *cost, int cstride, Counters *cnt);
 // columns the cost kernel leaves out (dense_cover_hi with `lanes` block lanes per pixel), filled in before the scan
 void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,
-                              const double *ref_tvp, const double *oth_tvp,      // strip path: LDS-image windows + padded planes; else null
+                              const double *ref_tvp, const double *oth_tvp,      // NaN-bordered planes (radius 5 / 2), else null
+                              bool wimg,                                         // LDS-image windows (strip path), else tile-major
                               int lanes, double *cost, int cstride, Counters *cnt);
 
 // Persistent strip form of the dense cost kernel, srh_strip.hip
@@ -289,7 +289,7 @@ void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int
                               const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax,
                               uint32_t *cflag = nullptr, int nlist = -1, Counters *cnt = nullptr);
 void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
-                                const uint32_t *cflag, int nlist, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
+                                const uint32_t *cflag, int cap, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
                                 double *cost, int smax, Counters *cnt);
 // RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
 const char *rccl_unique_id_get(void *out128);

@@ -572,13 +572,17 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 // arithmetic (tv_cost: any validity pattern) -- one 256-lane workgroup per pixel, a lane per slot.
 __global__ __launch_bounds__(256)
 void twoview_rows_refill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
-                                const uint32_t *__restrict__ cflag, const double *__restrict__ wbuf,
+                                const uint32_t *__restrict__ cflag, int cap, const double *__restrict__ wbuf,
                                 const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
                                 double *__restrict__ cost, int smax, Counters *__restrict__ cnt)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
 	const int W = L.w;
+	// (grid sized by the capacity of the redo: the count stays on the device, as in twoview_refill_kernel)
+	const uint32_t nflag = cflag[0];
+	if (blockIdx.x == 0 && threadIdx.x == 0 && nflag > (uint32_t)cap) atomicAdd(&cnt->cert_overflow, 1ull);
+	if (blockIdx.x >= nflag) return;
 	const size_t q = cflag[1 + blockIdx.x];
 	const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
 	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
@@ -602,12 +606,12 @@ void twoview_rows_refill_kernel(const ViewDev *__restrict__ views, int ref, int 
 }
 
 void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
-                                const uint32_t *cflag, int nlist, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
+                                const uint32_t *cflag, int cap, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
                                 double *cost, int smax, Counters *cnt)
 {
-	if (nlist <= 0) return;
-	hipLaunchKernelGGL(twoview_rows_refill_kernel, dim3((unsigned)nlist), dim3(256), 0, st,
-	                   views, ref, oth, P, y0, cflag, wbuf, rowinfo, meta, cost, smax, cnt);
+	if (cap <= 0) return;
+	hipLaunchKernelGGL(twoview_rows_refill_kernel, dim3((unsigned)cap), dim3(256), 0, st,
+	                   views, ref, oth, P, y0, cflag, cap, wbuf, rowinfo, meta, cost, smax, cnt);
 }
 
 // ------------------------------------------------------------------ scan with slot look-ups
@@ -630,7 +634,7 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
 	__shared__ uint32_t s_row[RW_NR][RW_LT];                     // xlo | slot base << 16
 	if (LISTED) {
-		if (q >= (size_t)nlist) return;
+		if (q >= (size_t)nlist || q >= (size_t)cflag[0]) return;     // (launched for a capacity; the count is on the device)
 		q = cflag[1 + q];
 	} else if (q >= (size_t)nrows*W) return;
 	const int x = (int)(q % W), y = y0 + (int)(q / W);
