@@ -57,13 +57,20 @@ bool ingestViewFile(const QString &file, double imageScale, Raster &image, std::
 } // namespace srq
 
 // ------------------------------------------------------------------ TwoViewStereo
-TwoViewStereo::TwoViewStereo(const srh_camera &leftView_, QImage left_, QImage leftMask_,
-                             const srh_camera &rightView_, QImage right_, QImage rightMask_,
-                             double minDepth_, double maxDepth_, int numDepthLevels_, double imageScale_,
-                             int deviceOrdinal)
+static int g_device = 0;
+void TwoViewStereo::setDevice(int ordinal) { g_device = ordinal; }
+void MultiViewStereo::setDevice(int ordinal) { g_device = ordinal; }
+
+TwoViewStereo::TwoViewStereo(CameraPtr leftView_, QImage left_, QImage leftMask_,
+                             CameraPtr rightView_, QImage right_, QImage rightMask_,
+                             double minDepth_, double maxDepth_, int numDepthLevels_, double imageScale_)
 	: leftView(leftView_), rightView(rightView_)
 	, minDepth(minDepth_), maxDepth(maxDepth_), numDepthLevels(numDepthLevels_), imageScale(imageScale_), ctx_(nullptr)
 {
+	const int deviceOrdinal = g_device;
+	memset(&leftCam, 0, sizeof(leftCam)); memset(&rightCam, 0, sizeof(rightCam));
+	if (leftView) leftCam = srq::cameraInfo(*leftView).camera;         // the host application's glue (stereo_qt.hpp)
+	if (rightView) rightCam = srq::cameraInfo(*rightView).camera;
 	// twoviewstereo.cpp:89-124: images and masks are smooth-scaled to width*imageScale; a null mask is all WHITE
 	left = srq::rasterFromQImage(left_.scaledToWidth(static_cast<int>(left_.width() * imageScale), Qt::SmoothTransformation));
 	right = srq::rasterFromQImage(right_.scaledToWidth(static_cast<int>(right_.width() * imageScale), Qt::SmoothTransformation));
@@ -103,15 +110,15 @@ QImage TwoViewStereo::colorize(const DepthMap &d, int w, int h) const {
 
 bool TwoViewStereo::uploadViews() const {
 	if (uploaded_) return true;
-	if (srh_view_upload(ctx_, 0, left.w, left.h, left.rgba.data(), leftMask.data(), &leftView) != SRH_OK ||
-	    srh_view_upload(ctx_, 1, right.w, right.h, right.rgba.data(), rightMask.data(), &rightView) != SRH_OK) {
+	if (srh_view_upload(ctx_, 0, left.w, left.h, left.rgba.data(), leftMask.data(), &leftCam) != SRH_OK ||
+	    srh_view_upload(ctx_, 1, right.w, right.h, right.rgba.data(), rightMask.data(), &rightCam) != SRH_OK) {
 		error_ = srh_last_error(); return false;
 	}
 	uploaded_ = true;
 	return true;
 }
 
-std::vector<std::array<double, 3> > TwoViewStereo::epipolarCurve(int x, int y, bool fromLeft) const {
+std::vector<std::array<double, 3> > TwoViewStereo::curveOfPixel(int x, int y, bool fromLeft) const {
 	std::vector<std::array<double, 3> > curve;
 	if (!ctx_ || left.w <= 0 || right.w <= 0 || !uploadViews()) return curve;
 	srh_params p = params_;
@@ -159,9 +166,10 @@ void TwoViewStereo::computeDepthMaps() {
 }
 
 // ------------------------------------------------------------------ MultiViewStereo
-MultiViewStereo::MultiViewStereo(int deviceOrdinal)
+MultiViewStereo::MultiViewStereo()
 	: minDepth(0), maxDepth(0), crossCheckThreshold(0), imageScale(1), numDepthLevels(0), ctx_(nullptr)
 {
+	const int deviceOrdinal = g_device;
 	srh_params_mvs_defaults(&params_);
 	srh_mrf_params_defaults(&mrfParams_);
 	if (srh_create(deviceOrdinal, &ctx_) != SRH_OK) { error_ = srh_last_error(); ctx_ = nullptr; }
@@ -169,9 +177,27 @@ MultiViewStereo::MultiViewStereo(int deviceOrdinal)
 
 MultiViewStereo::~MultiViewStereo() { if (ctx_) srh_destroy(ctx_); }
 
+void MultiViewStereo::initialize(ProjectPtr project_, ImageSetPtr imageSet, const std::vector<CameraPtr> &views,
+                                 double minDepth_, double maxDepth_, int numDepthLevels_, double crossCheckThreshold_, double imageScale_)
+{
+	// multiviewstereo.cpp:193-247: every non-null view with a default image in the set becomes a record
+	std::vector<View> records;
+	for (size_t index = 0; index < views.size(); ++index) if (views[index] && imageSet) {
+		const srq::CameraInfo info = srq::cameraInfo(*views[index]);
+		View v;
+		v.id = info.id; v.name = info.name; v.camera = info.camera; v.ptr = views[index];
+		v.file = srq::defaultImageFile(*imageSet, views[index]);
+		if (!v.file.isEmpty()) records.push_back(v);
+	}
+	initialize(records, minDepth_, maxDepth_, numDepthLevels_, crossCheckThreshold_, imageScale_);
+	project = project_;
+	imageSet_ = imageSet;
+}
+
 void MultiViewStereo::initialize(const std::vector<View> &views, double minDepth_, double maxDepth_, int numDepthLevels_,
                                  double crossCheckThreshold_, double imageScale_)
 {
+	project.reset(); imageSet_.reset();
 	minDepth = minDepth_; maxDepth = maxDepth_; numDepthLevels = numDepthLevels_;
 	crossCheckThreshold = crossCheckThreshold_; imageScale = imageScale_;
 	views_.clear(); images.clear(); masks.clear(); results.clear(); computedDepths.clear();
@@ -253,6 +279,12 @@ void MultiViewStereo::runTask() {
 		if (srh_view_depth_download(ctx_, v, computedDepths[v].data()) != SRH_OK) { error_ = srh_last_error(); return; }
 	emit stageUpdate(tr("Constructing depth maps"));
 	for (int v = 0; v < V; ++v) colorize(v);
+}
+
+QImage MultiViewStereo::depthMap(CameraPtr view) const {
+	for (size_t v = 0; v < views_.size(); ++v)
+		if (views_[v].ptr && views_[v].ptr == view) return results[v];
+	return QImage();
 }
 
 QImage MultiViewStereo::depthMap(const QString &viewId) const {

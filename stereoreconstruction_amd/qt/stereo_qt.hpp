@@ -1,12 +1,20 @@
-// stereo_qt.hpp -- the Qt binding of libstereo_recon_hip: TwoViewStereo and MultiViewStereo as the reference's GUI
-// sees them (stereo/twoviewstereo.hpp:39-126, stereo/multiviewstereo.hpp:44-113), derived from the reference's own
-// Task (gui/task.hpp:57-105; compiled from /root/reference where it lies, with its moc output), QImage in and out,
-// the reference's signals, everything between "scaled images + cameras" and "depth maps" behind the C-ABI.
+// stereo_qt.hpp -- the Qt binding of libstereo_recon_hip: TwoViewStereo and MultiViewStereo with the reference's OWN
+// public signatures (stereo/twoviewstereo.hpp:39-70, stereo/multiviewstereo.hpp:44-63), derived from the reference's own
+// Task (gui/task.hpp:57-105; compiled from /root/reference where it lies, with its moc output), QImage in and out, the
+// reference's signals, everything between "scaled images + cameras" and "depth maps" behind the C-ABI.
 //
-// What differs from the reference's signatures, and why: cameras arrive as srh_camera snapshots instead of
-// CameraPtr, and the project as the loader's plain records (host/project.hpp) instead of ProjectPtr / ImageSetPtr --
-// project/camera.hpp and project/project.hpp need Eigen and OpenCV, which this image does not have.  A maintainer
-// with those headers replaces `const srh_camera &` by `CameraPtr` + the snapshot() helper of INTEGRATION.md.
+// Camera / Project / ImageSet / Ray3d / VectorImage / Eigen::Vector3d appear here as FORWARD DECLARATIONS only, exactly
+// as stereo/*.hpp forward-declare the first three (FORWARD_DECLARE, util/precompiled.hpp:60-63): the binding never looks
+// inside them.  What it needs from them -- a POD snapshot of a camera, its id and name, the image file an image set holds
+// for a camera, the pixel a curve query is about -- comes through the glue declared below (srq::cameraInfo,
+// srq::defaultImageFile, and the definition of the five-argument TwoViewStereo::epipolarCurve), defined in ONE translation
+// unit of the host application:
+//   qt/glue_reference.cpp   for the reference itself (includes project/camera.hpp, project/imageset.hpp, util/ray.hpp:
+//                           needs Eigen and OpenCV, which this image lacks, so it is compiled where they exist;
+//                           INTEGRATION.md shows it in full),
+//   tests/qt_glue_test.hpp  the test driver's own small Camera / ImageSet / ... classes.
+// gui/widgets/stereowidget.cpp's call sites (:160, 263, 274, 321-322, 964-966, 990-994) compile against this header
+// unchanged; tests/qt_adapter_test.cpp holds them as a type-check.
 #pragma once
 
 #include <QtCore/QString>
@@ -16,8 +24,20 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "gui/task.hpp"                 // the reference's Task (QObject with run/cancel slots and progress signals)
 #include "stereo_recon_hip.h"
+
+FORWARD_DECLARE(Project);               // class Project; typedef std::shared_ptr<Project> ProjectPtr; ... (the reference's macro)
+FORWARD_DECLARE(Camera);
+FORWARD_DECLARE(ImageSet);
+class Ray3d;
+class VectorImage;
+namespace Eigen {
+template <typename Scalar, int Rows, int Cols, int Options, int MaxRows, int MaxCols> class Matrix;   // (Eigen's own forward declaration, minus its defaults)
+typedef Matrix<double, 3, 1, 0, 3, 1> Vector3d;
+}
 
 namespace srq {
 
@@ -32,31 +52,50 @@ std::vector<unsigned char> whiteMask(const Raster &mask);
 // mask = alpha == 255 on a FAST-scaled copy when the file has an alpha channel, all WHITE otherwise
 bool ingestViewFile(const QString &file, double imageScale, Raster &image, std::vector<unsigned char> &mask);
 
+// ---- the glue: DECLARED here, DEFINED by the host application (see the header comment) ----
+struct CameraInfo { srh_camera camera; QString id, name; };
+// K, R, t, distortion, refractive interface of a project camera as the POD the C-ABI takes (a copy, not a live pointer)
+CameraInfo cameraInfo(const Camera &cam);
+// imageSet->defaultImageForCamera(cam)->file(), empty when the set has no image for the camera (multiviewstereo.cpp:214)
+QString defaultImageFile(const ImageSet &set, const CameraPtr &cam);
+
 } // namespace srq
 
 class TwoViewStereo : public Task {
 public:
 	typedef std::vector<double> DepthMap;
 
-	TwoViewStereo(const srh_camera &leftView, QImage left, QImage leftMask,
-	              const srh_camera &rightView, QImage right, QImage rightMask,
-	              double minDepth, double maxDepth, int numDepthLevels, double imageScale = 1.0,
-	              int deviceOrdinal = 0);
+	// stereo/twoviewstereo.hpp:44-47, verbatim.  The GPU is chosen with setDevice() (default 0).
+	TwoViewStereo(CameraPtr leftView, QImage left, QImage leftMask,
+	              CameraPtr rightView, QImage right, QImage rightMask,
+	              double minDepth, double maxDepth, int numDepthLevels,
+	              double imageScale = 1.0);
 	~TwoViewStereo();
+	static void setDevice(int ordinal);
 
 	QString title() const { return "Two-View Stereo"; }
 	int numSteps() const { return 8; }
 
 	void computeDepthMaps();
-	// TwoViewStereo::epipolarCurve (public member of the reference, stereo/twoviewstereo.hpp:66-70, .cpp:999-1054; the
-	// GUI's curve preview is its user): the candidate pixels (tx, ty, 1) of reference pixel (x, y), in the order the
-	// reference visits them, joint duplicates included.  The reference takes (ray, cameraOffset, depthPlaneNormal,
-	// mask, view) -- Ray3d / Eigen types this image lacks -- and every caller builds them from a pixel the same way
-	// (twoviewstereo.cpp:275-283, 445-453: ray = unproject((x + 0.5)/scale, (y + 0.5)/scale), offset and normal from the
-	// same camera, mask and view of the other one), so the pixel and the direction are the arguments here.
-	std::vector<std::array<double, 3> > epipolarCurve(int x, int y, bool fromLeft = true) const;
 	QImage leftDepthMap() const { return resultLeft; }
 	QImage rightDepthMap() const { return resultRight; }
+	// stereo/twoviewstereo.hpp:66-70, verbatim (twoviewstereo.cpp:999-1054): the candidate pixels (tx, ty, 1) of the
+	// reference pixel whose `ray` this is, in the order the reference visits them, joint duplicates included.  Every
+	// caller builds (ray, cameraOffset, depthPlaneNormal, mask, view) from a pixel of one view the same way
+	// (twoviewstereo.cpp:275-283, 445-453: ray = unproject((x + 0.5)/scale, (y + 0.5)/scale), offset and normal of the same
+	// camera, mask and `view` of the other one), so the glue translation unit -- which knows Ray3d and Eigen -- recovers
+	// the pixel and the direction and calls curveOfPixel(); that is where this member is DEFINED.
+	std::vector<Eigen::Vector3d> epipolarCurve(const Ray3d &ray,
+	                                           const Eigen::Vector3d &cameraOffset,
+	                                           const Eigen::Vector3d &depthPlaneNormal,
+	                                           const VectorImage &mask,
+	                                           CameraPtr view) const;
+
+	// ---- beyond the reference's interface ----
+	std::vector<std::array<double, 3> > curveOfPixel(int x, int y, bool fromLeft = true) const;
+	CameraPtr leftCamera() const { return leftView; }
+	CameraPtr rightCamera() const { return rightView; }
+	double scale() const { return imageScale; }
 	const DepthMap &leftDepths() const { return computedDepthLeft; }
 	const DepthMap &rightDepths() const { return computedDepthRight; }
 	srh_params &params() { return params_; }
@@ -67,7 +106,8 @@ protected:
 
 private:
 	QImage colorize(const DepthMap &d, int w, int h) const;
-	srh_camera leftView, rightView;
+	CameraPtr leftView, rightView;
+	srh_camera leftCam, rightCam;                          // snapshots taken by the constructor (srq::cameraInfo)
 	srq::Raster left, right;
 	std::vector<unsigned char> leftMask, rightMask;
 	double minDepth, maxDepth;
@@ -84,20 +124,32 @@ private:
 
 class MultiViewStereo : public Task {
 public:
-	struct View { QString id, name; srh_camera camera; QString file; };   // a camera of the project and its image file
+	// a camera of the project, its snapshot and its image file: what initialize() resolves every CameraPtr into
+	struct View { QString id, name; srh_camera camera; QString file; CameraPtr ptr; };
 
-	explicit MultiViewStereo(int deviceOrdinal = 0);
+	MultiViewStereo();
 	~MultiViewStereo();
+	static void setDevice(int ordinal);
 
-	// MultiViewStereo::initialize (multiviewstereo.cpp:193-247): loads, scales and masks every view's image;
-	// views without an existing image file are skipped
+	// stereo/multiviewstereo.hpp:46-52, verbatim (multiviewstereo.cpp:193-247): loads, scales and masks the image the
+	// image set holds for every view; views without an existing image file are skipped
+	void initialize(ProjectPtr project,
+	                ImageSetPtr imageSet,
+	                const std::vector<CameraPtr> &views,
+	                double minDepth, double maxDepth,
+	                int numDepthLevels,
+	                double crossCheckThreshold,
+	                double imageScale = 1.0);
+	// the same from resolved records (hosts without the reference's project model)
 	void initialize(const std::vector<View> &views, double minDepth, double maxDepth, int numDepthLevels,
 	                double crossCheckThreshold, double imageScale = 1.0);
 
 	QString title() const { return "Multi-view Stereo"; }
 	int numSteps() const { return 2*static_cast<int>(views_.size()); }
 
-	QImage depthMap(const QString &viewId) const;                 // null image for an unknown view (:279-286)
+	QImage depthMap(CameraPtr view) const;                        // stereo/multiviewstereo.hpp:60; null image for an unknown view (:279-286)
+	ImageSetPtr imageSet() const { return imageSet_; }            // stereo/multiviewstereo.hpp:63
+	QImage depthMap(const QString &viewId) const;                 // (by id: record-based hosts)
 	const std::vector<double> &depths(int viewIndex) const { return computedDepths[viewIndex]; }
 	int numViews() const { return static_cast<int>(views_.size()); }
 	const srq::Raster &image(int viewIndex) const { return images[viewIndex]; }
@@ -113,6 +165,8 @@ protected:
 
 private:
 	void colorize(int viewIndex);
+	ProjectPtr project;
+	ImageSetPtr imageSet_;
 	std::vector<View> views_;
 	std::vector<srq::Raster> images;
 	std::vector<std::vector<unsigned char> > masks;

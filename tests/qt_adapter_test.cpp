@@ -17,7 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "stereo_qt.hpp"
+#include "qt_glue_test.hpp"          // the test's own Camera / ImageSet / ... and the glue over them (includes stereo_qt.hpp)
 
 static bool readRaw(const std::string &path, std::vector<unsigned char> &out, size_t n) {
 	std::ifstream f(path, std::ios::binary);
@@ -47,6 +47,25 @@ static QImage imageFromRaw(const std::vector<unsigned char> &rgba, int w, int h)
 		for (int x = 0; x < w; ++x) { const unsigned char *p = &rgba[(static_cast<size_t>(y)*w + x)*4]; s[x] = qRgba(p[0], p[1], p[2], p[3]); }
 	}
 	return img;
+}
+
+// The reference GUI's call sites of the two classes (gui/widgets/stereowidget.cpp:160, 263, 274, 321-322, 964-966, 990-994),
+// as expressions over the same names: this function exists to be TYPE-CHECKED against stereo_qt.hpp (it also runs, on
+// an uninitialised task: null maps, no image set).
+static bool stereoWidgetCallSites(ProjectPtr project, CameraPtr leftView, CameraPtr rightView, ImageSetPtr imageSet,
+                                  double mind, double maxd, int levels, double crossCheck, double scale)
+{
+	std::shared_ptr<MultiViewStereo> mvs(new MultiViewStereo);                      // :160  mvs(new MultiViewStereo)
+	QImage img = mvs->depthMap(leftView);                                           // :263
+	if (!img.isNull()) return false;
+	img = mvs->depthMap(rightView);                                                 // :274
+	const bool sameSet = mvs->imageSet() == imageSet;                               // :321-322
+	std::vector<CameraPtr> views;
+	views.push_back(leftView); views.push_back(rightView);
+	mvs->initialize(project, imageSet, views, mind, maxd, levels, crossCheck, scale);   // :990-994
+	QObject::connect(mvs.get(), SIGNAL(finished(const Task *)), mvs.get(), SLOT(cancel()));   // :996-998 (signal of the reference's Task)
+	const QImage l = mvs->depthMap(leftView), r = mvs->depthMap(rightView);         // :964-966
+	return !sameSet && mvs->imageSet() == imageSet && mvs->numSteps() == 2*mvs->numViews() && l.isNull() == r.isNull();
 }
 
 // run `task` on its own thread exactly as MainWindow::customEvent does; returns the progress steps seen
@@ -95,10 +114,14 @@ int main(int argc, char **argv) {
 		QImage qml, qmr;
 		if (lm != "-") { if (!readRaw(lm, ML, static_cast<size_t>(w)*h*4)) return 1; qml = imageFromRaw(ML, w, h); }
 		if (rm != "-") { if (!readRaw(rm, MR, static_cast<size_t>(w)*h*4)) return 1; qmr = imageFromRaw(MR, w, h); }
-		TwoViewStereo *tv = new TwoViewStereo(cl, imageFromRaw(L, w, h), qml, cr, imageFromRaw(R, w, h), qmr, zmin, zmax, levels, scale);
-		// the public epipolarCurve member (twoviewstereo.hpp:66-70), before and independent of computeDepthMaps
+		CameraPtr leftView(new Camera("left", cl)), rightView(new Camera("right", cr));
+		// the reference's constructor signature (stereo/twoviewstereo.hpp:44-47)
+		TwoViewStereo *tv = new TwoViewStereo(leftView, imageFromRaw(L, w, h), qml, rightView, imageFromRaw(R, w, h), qmr, zmin, zmax, levels, scale);
+		// the public epipolarCurve member with the reference's five arguments (twoviewstereo.hpp:66-70), before and
+		// independent of computeDepthMaps; `view` is the camera the curve is drawn in
 		for (int dir = 0; dir < 2; ++dir) {
-			const auto curve = tv->epipolarCurve(w/2, h/2, dir == 0);
+			const std::vector<Eigen::Vector3d> curve = tv->epipolarCurve(Ray3d(w/2, h/2), Eigen::Vector3d(), Eigen::Vector3d(), VectorImage(),
+			                                                            dir == 0 ? rightView : leftView);
 			printf("curve%d", dir);
 			for (const auto &pt : curve) printf(" %d,%d", static_cast<int>(pt[0]), static_cast<int>(pt[1]));
 			printf("\n");
@@ -122,24 +145,34 @@ int main(int argc, char **argv) {
 		std::ifstream in(argv[2]);
 		int n, levels; double zmin, zmax, cc, scale;
 		in >> n >> zmin >> zmax >> levels >> cc >> scale;
-		std::vector<MultiViewStereo::View> views(n);
+		// the project side as the reference hands it over: cameras, an image set with one default image per camera
+		ProjectPtr project(new Project);
+		ImageSetPtr imageSet(new ImageSet);
+		std::vector<CameraPtr> views;
+		std::vector<std::string> ids(n);
 		for (int v = 0; v < n; ++v) {
-			std::string id, file;
-			in >> id >> file;
-			views[v].id = QString::fromStdString(id); views[v].name = views[v].id; views[v].file = QString::fromStdString(file);
-			if (!readCamera(in, views[v].camera)) { fprintf(stderr, "bad spec\n"); return 1; }
+			std::string file;
+			in >> ids[v] >> file;
+			srh_camera cam;
+			if (!readCamera(in, cam)) { fprintf(stderr, "bad spec\n"); return 1; }
+			views.push_back(CameraPtr(new Camera(QString::fromStdString(ids[v]), cam)));
+			imageSet->setDefaultImage(views.back(), QString::fromStdString(file));
 		}
+		printf("callsites %d\n", stereoWidgetCallSites(project, views[0], views[n > 1 ? 1 : 0], imageSet, zmin, zmax, levels, cc, scale) ? 1 : 0);
 		MultiViewStereo *mvs = new MultiViewStereo();
-		mvs->initialize(views, zmin, zmax, levels, cc, scale);
+		mvs->initialize(project, imageSet, views, zmin, zmax, levels, cc, scale);     // stereo/multiviewstereo.hpp:46-52
+		printf("imageset %d\n", mvs->imageSet() == imageSet ? 1 : 0);
 		std::vector<std::string> stages;
 		const std::vector<int> steps = runOnThread(app, mvs, stages);
 		printf("title %s\nnumViews %d\nnumSteps %d\nsteps", mvs->title().toStdString().c_str(), mvs->numViews(), mvs->numSteps());
 		for (int s : steps) printf(" %d", s);
 		printf("\nerror %s\n", mvs->lastError().toStdString().c_str());
-		printf("unknown_view_null %d\n", mvs->depthMap("no such view").isNull() ? 1 : 0);
+		printf("unknown_view_null %d\n", (mvs->depthMap(CameraPtr(new Camera("stranger", srh_camera()))).isNull() && mvs->depthMap(CameraPtr()).isNull()) ? 1 : 0);
+		for (int v = 0; v < n; ++v) {                                                  // (a view without an image file: null map)
+			const QImage m = mvs->depthMap(views[v]);                                  // stereo/multiviewstereo.hpp:60
+			printf("map_%s %dx%d\n", ids[v].c_str(), m.width(), m.height());
+		}
 		for (int v = 0; v < mvs->numViews(); ++v) {
-			const QImage m = mvs->depthMap(views[v].id);
-			printf("map %s %dx%d\n", views[v].id.toStdString().c_str(), m.width(), m.height());
 			std::ostringstream o; o << argv[3] << "_" << v;
 			writeRaw(o.str() + ".f64", mvs->depths(v).data(), mvs->depths(v).size()*sizeof(double));
 			const int hdr[2] = { mvs->image(v).w, mvs->image(v).h };

@@ -1,0 +1,63 @@
+// qt_glue_test.hpp -- the test driver's side of the Qt binding's glue (stereo_qt.hpp): small classes with the NAMES the
+// binding forward-declares (Camera, Project, ImageSet, Ray3d, VectorImage, Eigen::Vector3d) and the definitions of the
+// glue functions over them.  In the reference those names are the project model (project/camera.hpp needs Eigen and
+// OpenCV, which this image lacks) and the glue is stereoreconstruction_amd/qt/glue_reference.cpp; the binding itself
+// is the same object code in both cases -- it only ever holds pointers and references to these types.
+#pragma once
+
+#include <map>
+
+#include "stereo_qt.hpp"
+
+class Camera {
+public:
+	Camera(const QString &id, const srh_camera &c) : id_(id), cam_(c) { }
+	const QString &id() const { return id_; }
+	const QString &name() const { return id_; }
+	const srh_camera &pod() const { return cam_; }
+private:
+	QString id_;
+	srh_camera cam_;
+};
+
+class Project { };
+
+class ImageSet {
+public:
+	void setDefaultImage(const CameraPtr &cam, const QString &file) { files_[cam.get()] = file; }
+	QString fileFor(const CameraPtr &cam) const {
+		const std::map<const Camera *, QString>::const_iterator it = files_.find(cam.get());
+		return it == files_.end() ? QString() : it->second;
+	}
+private:
+	std::map<const Camera *, QString> files_;
+};
+
+// the curve query's arguments: the test's ray simply remembers the pixel it was cast from
+class Ray3d { public: int x, y; Ray3d(int x_, int y_) : x(x_), y(y_) { } };
+class VectorImage { };
+namespace Eigen {
+template <typename Scalar, int Rows, int Cols, int Options, int MaxRows, int MaxCols> class Matrix {
+public:
+	Matrix() { for (int i = 0; i < Rows*Cols; ++i) v[i] = Scalar(); }
+	Matrix(Scalar a, Scalar b, Scalar c) { v[0] = a; v[1] = b; v[2] = c; }
+	Scalar operator[](int i) const { return v[i]; }
+private:
+	Scalar v[Rows*Cols];
+};
+}
+
+// (plain definitions, not inline: the binding's shared library resolves these symbols from the executable; one TU includes this file)
+namespace srq {
+CameraInfo cameraInfo(const Camera &cam) { CameraInfo i; i.camera = cam.pod(); i.id = cam.id(); i.name = cam.name(); return i; }
+QString defaultImageFile(const ImageSet &set, const CameraPtr &cam) { return set.fileFor(cam); }
+}
+
+std::vector<Eigen::Vector3d> TwoViewStereo::epipolarCurve(const Ray3d &ray, const Eigen::Vector3d &, const Eigen::Vector3d &,
+                                                                 const VectorImage &, CameraPtr view) const
+{
+	const std::vector<std::array<double, 3> > pts = curveOfPixel(ray.x, ray.y, view == rightCamera());
+	std::vector<Eigen::Vector3d> curve;
+	for (size_t k = 0; k < pts.size(); ++k) curve.push_back(Eigen::Vector3d(pts[k][0], pts[k][1], pts[k][2]));
+	return curve;
+}

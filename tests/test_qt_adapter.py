@@ -141,6 +141,11 @@ def test_multiview_through_the_qt_binding(hip_ctx):
         assert out["title"] == "Multi-view Stereo" and out["numViews"] == str(V) and out["numSteps"] == str(2 * V)
         assert out["steps"].split() == [str(s) for s in range(2 * V)] and out["error"].strip() == ""
         assert out["unknown_view_null"] == "1"
+        # the reference's signatures: initialize(ProjectPtr, ImageSetPtr, views, ...), imageSet(), depthMap(CameraPtr);
+        # gui/widgets/stereowidget.cpp's call sites, compiled against the binding's header and run
+        assert out["callsites"] == "1" and out["imageset"] == "1"
+        h0, w0 = case["views"][0][0].shape[:2]
+        assert out["map_cam0"] == "%dx%d" % (w0, h0) and out["map_ghost"] == "0x0"
         cams, p = cases.hip_inputs(case)
         for v in range(V):
             img, mask = _read_ingest(os.path.join(td, "out_%d.img" % v))
