@@ -130,6 +130,9 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     neigh = capi.mvs_neighbours(cams, p)
     links = sum(len(n) for n in neigh)
     ctx = capi.Context(dev_index)
+    if args.arith in ("fma", "f32"):
+        sys.exit("--arith fma / f32 apply to the dense row-aligned TwoView path (c2, c3, small)")
+    ctx.set_option("arith", capi.ARITH_EXACT if args.arith == "exact" else capi.ARITH_CERTIFIED)
     for v in range(C4_VIEWS):                                  # every rank holds all views (a few MB): any neighbour
         ctx.upload_view(v, rgba[v], masks[v], cams[v])
     eng = HipMultiViewEngine(ctx, list(range(C4_VIEWS)), neigh, p, dev if backend == "nccl" else "cpu")
@@ -192,6 +195,10 @@ def run_c4(args, rank, world, dev, dev_index, backend):
                        "window_radius": int(p.window_radius), "weights": "geodesic",
                        "parallelism": ("views sharded, %s all-gather" % ("RCCL" if backend == "nccl" else backend))
                        if world > 1 else "single GPU",
+                       "arithmetic": ("certified (default): fused sweeps in the staged cost kernel, every unit's winner certified against "
+                                      "a proven error bound, its score recomputed and ambiguous units redone in the reference's arithmetic "
+                                      "-- same bits as 'exact' (DESIGN.md 2b)" if args.arith == "certified"
+                                      else "exact: the reference's operation order, no contraction, everywhere"),
                        "masked_in_fraction": round(float(np.mean([m.mean() for m in masks])), 4),
                        "n_eval_reference_rank0_per_step": int(n_eval)},
             "roofline": {"bound": "valu_fp64", "kernel": name, "achieved": round(valu, 3), "peak": FP64_VALU_PEAK_TFLOPS,

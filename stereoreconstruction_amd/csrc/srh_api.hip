@@ -1372,7 +1372,8 @@ static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int n
 			if (staged) {
 				Scope s(c, "mvs_staged_cost_kernel");
 				launch_mvs_staged_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,
-				                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact, upk);
+				                       c->lcand, cmax, c->lcount, c->cost, c->mvs_wdesc, c->mvs_nwin, c->d_cnt, act, nact, upk,
+				                       c->arith == 3 && !peaks_dev);
 			}
 			{ Scope s(c, "mvs_list_cost_kernel");
 			  launch_mvs_list_cost(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, c->wbuf, wstride,

@@ -92,24 +92,28 @@ struct CertBound {
 };
 // certified scan: is this stored cost the very number the reference's arithmetic gives?  (+inf: the initial minCost / secondBest)
 __host__ __device__ inline bool cert_sure(double x, double clamp, double m_hi) { return x == clamp || x > m_hi; }
-inline CertBound cert_bound(const srh_params &P) {
+// mvs: the free cost_ncc of MultiViewStereo (multiviewstereo.cpp:113-189): the score sum1/sqrt(sum2*sum3) itself (no factor
+// 255, no clamp), 25 taps at the reference's radius; e0 = 2^-36 there (scores live in [-1, 1])
+inline CertBound cert_bound(const srh_params &P, bool mvs = false) {
 	const double u = 0x1p-53, G = 256.0;
 	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
 	auto gamma = [&](int k) { return k*u/(1.0 - k*u); };
 	const double eps_b = gamma(T + 4)*G, eps_a = 2*u*G, rt = sqrt((double)T);
+	const double scale = mvs ? 1.0 : 255.0;
 	CertBound c;
-	c.e0 = 0x1p-30;                                               // 9.3e-10: a comparison needs 1.9e-9 of margin
-	c.k1 = 2*255*1.01*3*eps_b*rt;
-	c.k2 = 2*255*1.01*eps_a*rt;
-	const double k3 = 2*255*1.01*2*gamma(T) + 2600*u;
+	c.e0 = mvs ? 0x1p-36 : 0x1p-30;                               // TwoView: 9.3e-10, a comparison needs 2.3e-9 of margin
+	c.k1 = 2*scale*1.01*3*eps_b*rt;
+	c.k2 = 2*scale*1.01*eps_a*rt;
+	const double k3 = 2*scale*1.01*2*gamma(T) + (mvs ? 40 : 2600)*u;
 	c.room = c.e0 - k3;
 	c.m_hi = P.max_color_diff + c.e0;
+	const bool weights_ok = P.weight_kind == SRH_WEIGHT_GEODESIC ? P.geodesic_sigma > 0 : P.adaptive_color_sigma > 0;   // exp(-distance/sigma) <= 1
+	if (mvs) { c.ok = c.room > 0 && weights_ok && fabs(P.peak_threshold) <= 1e5; return c; }
 	// the clamp test needs max_color_diff + e0 > max_color_diff (so below 2^22); the duplicate rule of the scan needs
-	// wta_margin >= 0; weights are exp(-distance/sigma) <= 1
+	// wta_margin >= 0
 	// (and magnitudes <= 1e5, so that the rounding of cost + margin stays below e0/2 in the scan's tolerance)
 	c.ok = c.room > 0 && c.m_hi > P.max_color_diff && P.max_color_diff <= 1e5 && fabs(P.bad_ret) <= 1e5 &&
-	       P.wta_margin >= 0 && P.wta_margin <= 1e5 && fabs(P.second_best_factor) <= 1e5 &&
-	       (P.weight_kind == SRH_WEIGHT_GEODESIC ? P.geodesic_sigma > 0 : P.adaptive_color_sigma > 0);
+	       P.wta_margin >= 0 && P.wta_margin <= 1e5 && fabs(P.second_best_factor) <= 1e5 && weights_ok;
 	return c;
 }
 
@@ -238,11 +242,13 @@ void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave);
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
                      Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact, bool peaks);
+// cert: the certified fused form (no top-K request): fused sweeps, the unit's winner certified against the bound, its
+// cost recomputed in the reference's arithmetic; ambiguous units redone exactly
 void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                             const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                             const uint32_t *cand, int cmax, const int32_t *count, double *best,
                             const uint32_t *wdesc, const int32_t *nwin, Counters *cnt, const uint32_t *act, int nact,
-                            double *unit_peaks);
+                            double *unit_peaks, bool cert = false);
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                           const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                           const uint32_t *cand, int cmax, const int32_t *count, double *best,

@@ -1085,17 +1085,29 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 #ifndef MS_NC
 #define MS_NC 1                       // slots evaluated side by side (2 was measured: slower)
 #endif
+#ifndef MS_CA
+#define MS_CA 2                       // certified form: partial sums per sum (independent dependency chains)
+#endif
 
 // PEAKS: the top-K request (every pair above the threshold into the unit's sorted K-list upk[unit][K][2], as in
 // mvs_list_cost_kernel<R, true>); its LDS share of the box is smaller by the queue of pairs waiting for their depth.
-template <int R, bool PEAKS>
+// CERT (not with PEAKS): the certified fused arithmetic (srh_internal.hpp, CertBound).  The two sweeps run
+// with fused multiply-adds; a unit's result depends on the scores only through "which candidate has the largest score
+// above the threshold" (multiviewstereo.cpp:589-604, 654-660), so the unit keeps, beside its fused maximum, whether any
+// OTHER candidate's fused score came within 2*e0 of it (or any score within e0 of the threshold, or a candidate the
+// bound does not cover): such a unit is redone in the reference's arithmetic (mvs_unit_general, as for exact ties);
+// for every other unit the winner is the reference's, and its score -- which the combine step compares across
+// neighbours -- is recomputed in the reference's arithmetic (mvs_cost_general: one evaluation per unit).
+template <int R, bool PEAKS, bool CERT>
 __global__ __launch_bounds__(MQ_T, 2)
 void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                             int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                             const uint32_t *__restrict__ cand, int cmax, const int32_t *__restrict__ count,
                             double *__restrict__ best, const uint4 *__restrict__ wdesc, const int32_t *__restrict__ nwin,
-                            Counters *__restrict__ cnt, const uint32_t *__restrict__ act, int nact, double *__restrict__ upk)
+                            Counters *__restrict__ cnt, const uint32_t *__restrict__ act, int nact, double *__restrict__ upk,
+                            const CertBound cb)
 {
+	static_assert(!(PEAKS && CERT), "the top-K request hands scores out: the reference's arithmetic");
 	constexpr int WS = 2*R + 1, T = WS*WS;
 #ifdef SRH_PROFILE_PHASES
 	// diagnostic build: wave clocks of the phases, summed in cnt->dbg_phase (0 set-up, 1 copies, 2 slots, 3 end; dbg_blocks = slots)
@@ -1166,6 +1178,8 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	bool redo = active && !all;                                     // this unit needs mvs_unit_general
 	const SharedDivisor twd = shared_divisor(tw);
 	const double thr0 = P.peak_threshold > 0.0 ? P.peak_threshold : 0.0;
+	const double sig3 = CERT ? cb.sigma3(s2) : 0.0;                 // certified: the smallest sum3 the bound covers for this unit
+	bool amb = false, amb_tie = false;                              // certified: the maximum is not certain (amb_tie: only as long as the maximum stays where it is)
 	int pqn = 0;
 	auto pflush = [&]() {                                           // (all lanes together)
 		const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
@@ -1238,24 +1252,51 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 			}
 			// p_t = weight*gray of the other view (multiviewstereo.cpp:150-151, 171); meanR is their sum / totalWeight
 			double g[MS_NC][T], mR[MS_NC], s1[MS_NC], s3[MS_NC];
+			double mRx[MS_NC][MS_CA > 1 ? MS_CA - 1 : 1], s3x[MS_NC][MS_CA > 1 ? MS_CA - 1 : 1];   // certified: the other partial sums (mRx: of meanR, then of sum1)
 #pragma unroll
-			for (int u = 0; u < MS_NC; ++u) mR[u] = 0;
+			for (int u = 0; u < MS_NC; ++u) { mR[u] = 0; for (int k = 0; k < MS_CA - 1; ++k) mRx[u][k] = 0; }
 #pragma unroll
 			for (int row = 0; row < WS; ++row)
 #pragma unroll
 				for (int col = 0; col < WS; ++col)
 #pragma unroll
-					for (int u = 0; u < MS_NC; ++u) { const int t = row*WS + col; g[u][t] = w[t]*gp[u][row*stride + col]; mR[u] += g[u][t]; }
+					for (int u = 0; u < MS_NC; ++u) {
+						const int t = row*WS + col;
+						if (CERT) {
+							// (g keeps the gray value; MS_CA partial sums: the exact kernel's sums are single dependent chains, one
+							// instruction per 12 cycles and wave -- the bound holds for any order of summation)
+							g[u][t] = gp[u][row*stride + col];
+							if (t % MS_CA == 0) mR[u] = __builtin_fma(w[t], g[u][t], mR[u]); else mRx[u][t % MS_CA - 1] = __builtin_fma(w[t], g[u][t], mRx[u][t % MS_CA - 1]);
+						} else { g[u][t] = w[t]*gp[u][row*stride + col]; mR[u] += g[u][t]; }
+					}
+			if (CERT) {
+#pragma unroll
+				for (int u = 0; u < MS_NC; ++u)
+#pragma unroll
+					for (int k = 0; k < MS_CA - 1; ++k) { mR[u] += mRx[u][k]; mRx[u][k] = 0; s3x[u][k] = 0; }
+			}
 #pragma unroll
 			for (int u = 0; u < MS_NC; ++u) { mR[u] = div_by(mR[u], twd); s1[u] = 0; s3[u] = 0; }   // mR / tw, the same bits (srh_walk.hpp)
 #pragma unroll
 			for (int t = 0; t < T; ++t)
 #pragma unroll
 				for (int u = 0; u < MS_NC; ++u) {
-					const double b = g[u][t] - mR[u];
-					s1[u] += a[t]*b;
-					s3[u] += b*b;
+					if (CERT) {
+						const double b = __builtin_fma(w[t], g[u][t], -mR[u]);
+						if (t % MS_CA == 0) { s1[u] = __builtin_fma(a[t], b, s1[u]); s3[u] = __builtin_fma(b, b, s3[u]); }
+						else { mRx[u][t % MS_CA - 1] = __builtin_fma(a[t], b, mRx[u][t % MS_CA - 1]); s3x[u][t % MS_CA - 1] = __builtin_fma(b, b, s3x[u][t % MS_CA - 1]); }
+					} else {
+						const double b = g[u][t] - mR[u];
+						s1[u] += a[t]*b;
+						s3[u] += b*b;
+					}
 				}
+			if (CERT) {
+#pragma unroll
+				for (int u = 0; u < MS_NC; ++u)
+#pragma unroll
+					for (int k = 0; k < MS_CA - 1; ++k) { s1[u] += mRx[u][k]; s3[u] += s3x[u][k]; }
+			}
 #pragma unroll
 			for (int u = 0; u < MS_NC; ++u) {
 				// A score has an effect only when it is > threshold and >= the best so far (>= 0), hence >= bound.  With
@@ -1267,12 +1308,25 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 				const double bound = bestCost > thr0 ? bestCost : thr0;
 				bool hopeless;
 				if (e[u] == MQ_PAD) hopeless = true;
+				else if (CERT && !(s3[u] >= sig3)) { hopeless = false; amb = true; }   // a candidate the bound does not cover: the unit is redone
 				else if (!(den >= 1e-10)) hopeless = P.peak_threshold >= 0.0;        // score 0 (or NaN)
 				else if (s1[u] < 0.0) hopeless = P.peak_threshold >= 0.0;
-				else hopeless = s1[u]*s1[u] < bound*bound*den*0.999999;
+				// (certified: the fused score is within e0 of the reference's; 5e-7*bound covers e0 once bound >= 1e-3)
+				else hopeless = (!CERT || bound >= 1e-3) && s1[u]*s1[u] < bound*bound*den*0.999999;
 				if (__all(hopeless)) continue;
 				const double c = (den < 1e-10) ? 0.0 : s1[u] / sqrt(den);
-				if (e[u] != MQ_PAD && c > P.peak_threshold) {                // multiviewstereo.cpp:589-594, 654-660
+				if (CERT) {
+					if (e[u] != MQ_PAD && !hopeless) {
+						// the reference keeps the largest (score, depth) pair among the scores above the threshold; bestCost / be
+						// follow the fused maximum, amb says it is not certainly the reference's
+						if (!(fabs(c - P.peak_threshold) > cb.e0)) amb = true;   // the threshold decision itself (NaN: ambiguous)
+						else if (c > P.peak_threshold) {
+							// bestCost is the largest fused score so far (initially 0 with no candidate: the reference's start)
+							if (c > bestCost + 2*cb.e0) { bestCost = c; be = e[u]; amb_tie = false; }   // every earlier score is out of reach
+							else if (c >= bestCost - 2*cb.e0 && e[u] != be) { amb_tie = true; if (c > bestCost) { bestCost = c; be = e[u]; } }
+						}
+					}
+				} else if (e[u] != MQ_PAD && c > P.peak_threshold) {        // multiviewstereo.cpp:589-594, 654-660
 					if (PEAKS) { if (all) { s_pc[pqn][tid] = c; s_pe[pqn][tid] = e[u]; ++pqn; } }
 					else if (c > bestCost) { bestCost = c; be = e[u]; }
 					else if (c == bestCost && e[u] != be) redo = true;       // exact tie of two candidates: depths decide
@@ -1284,6 +1338,7 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 	}
 	if (PEAKS) pflush();
 	if (active) {
+		if (CERT && (amb || amb_tie) && !redo) { redo = true; atomicAdd(&cnt->n_flagged, 1ull); }
 		if (redo) mvs_unit_general<R>(A, B, P, wq, wstride, x, y, cl, n, bout, pk);
 		else if (PEAKS) { bout[0] = pk[2*(P.top_k - 1)]; bout[1] = pk[2*(P.top_k - 1) + 1]; }
 		else {
@@ -1291,6 +1346,8 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 			if (be != 0xffffffffu) {
 				const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 				bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16));
+				// certified: the winner is the reference's; the score handed to the combine step is the reference's too
+				if (CERT) bestCost = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, (int)(be & 0xffffu), (int)(be >> 16));
 			}
 			bout[0] = bestCost; bout[1] = bestDepth;
 		}
@@ -1327,17 +1384,21 @@ void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const
                             const srh_params &P, int y0, int nrows, const double *wbuf, size_t wstride,
                             const uint32_t *cand, int cmax, const int32_t *count, double *best,
                             const uint32_t *wdesc, const int32_t *nwin, Counters *cnt, const uint32_t *act, int nact,
-                            double *unit_peaks)
+                            double *unit_peaks, bool cert)
 {
 	if (nact <= 0) return;
 	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
 	const NeighList nl = make_neigh_list(neigh, nneigh);
+	const CertBound cb = cert_bound(P, true);
 	if (unit_peaks)
-		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, unit_peaks);
+		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, true, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, unit_peaks, cb);
+	else if (cert && cb.ok)
+		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, false, true>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, (double *)nullptr, cb);
 	else
-		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
-		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, (double *)nullptr);
+		hipLaunchKernelGGL((mvs_staged_cost_kernel<2, false, false>), grid, dim3(MQ_T), 0, st, views, ref, nl, P, y0, nrows,
+		                   wbuf, wstride, cand, cmax, count, best, (const uint4 *)wdesc, nwin, cnt, act, nact, (double *)nullptr, cb);
 }
 
 void launch_mvs_list_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,

@@ -330,3 +330,64 @@ def test_certified_equals_exact_on_adversarial_images_general_geometry(hip_ctx, 
         assert not cert[d][1]["used_dense_path"]
         assert np.array_equal(exact[d][0].view(np.uint64), cert[d][0].view(np.uint64)), (kind, d)
     print("certified row-run scan, %s: %d of %d pixels flagged" % (kind, sum(c[1]["n_flagged"] for c in cert), sum(c[1]["n_certified"] for c in cert)))
+
+
+# ------------------------------------------------------------------------------ certified arithmetic, MultiViewStereo
+def _mvs_maps(ctx, case, arith):
+    import cases
+    cams, p = cases.hip_inputs(case)
+    neigh = [list(map(int, n)) for n in capi.mvs_neighbours(cams, p)]
+    cases.upload_case(ctx, case, cams)
+    ctx.set_option("arith", arith)
+    try:
+        for v in range(len(cams)):
+            ctx.mvs_initial_estimate(v, neigh[v], p)
+        return [ctx.download_depth(v) for v in range(len(cams))]
+    finally:
+        ctx.set_option("arith", capi.ARITH_DEFAULT)
+
+
+@pytest.mark.parametrize("name,over", [("mvs_geodesic", dict(w=160, h=120, D=32, nviews=4)),
+                                       ("mvs_adaptive", dict(w=200, h=90, D=40, nviews=3)),
+                                       ("mvs_distorted", dict(w=128, h=96, D=24, nviews=3)),
+                                       ("mvs_refractive", dict(w=128, h=96, D=24, nviews=3)),
+                                       ("mvs_scaled", dict(w=128, h=96, D=24, nviews=3))])
+def test_certified_equals_exact_multiview(hip_ctx, name, over):
+    """The staged MultiViewStereo cost kernel's certified fused form (mvs_staged_cost_kernel<.., CERT>): the depth maps of
+    every view are the reference arithmetic's bits."""
+    import cases
+    case = cases.get_mvs(name, **over)
+    exact = _mvs_maps(hip_ctx, case, capi.ARITH_EXACT)
+    cert = _mvs_maps(hip_ctx, case, capi.ARITH_CERTIFIED)
+    for v, (a, b) in enumerate(zip(exact, cert)):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (name, v, int((a.view(np.uint64) != b.view(np.uint64)).sum()))
+    assert any((m[np.isfinite(m)] > 0).any() for m in cert)
+
+
+@pytest.mark.parametrize("kind", ["flat", "two_level", "periodic", "saturated_half"])
+def test_certified_equals_exact_multiview_adversarial(hip_ctx, kind):
+    """Views made of ties and zero variances (every score 0, undefined or repeated): still the reference's bits."""
+    import cases
+    case = cases.get_mvs("mvs_geodesic", w=144, h=96, D=24, nviews=3)
+    rng = np.random.default_rng(11)
+    H, W = case["views"][0][0].shape[:2]
+    yy, xx = np.mgrid[0:H, 0:W]
+    views = []
+    for v, (rgba, mask, cam, dist, plane) in enumerate(case["views"]):
+        img = rgba.copy()
+        if kind == "flat":
+            img[..., :3] = 120
+        elif kind == "two_level":
+            img[..., :3] = np.where(((xx // 3 + yy // 2 + v) % 2)[..., None] == 0, 50, 190).astype(np.uint8)
+        elif kind == "periodic":
+            base = rng.integers(0, 256, (1, 7, 3), dtype=np.uint8)
+            img[..., :3] = base[:, (xx[0] + 2 * v) % 7]
+        elif kind == "saturated_half":
+            img[:, W // 2:, :3] = 255
+            img[: H // 3, :, :3] = 0
+        views.append((img, np.ones_like(mask), cam, dist, plane))
+    case = dict(case, views=views)
+    exact = _mvs_maps(hip_ctx, case, capi.ARITH_EXACT)
+    cert = _mvs_maps(hip_ctx, case, capi.ARITH_CERTIFIED)
+    for v, (a, b) in enumerate(zip(exact, cert)):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (kind, v)
