@@ -150,6 +150,7 @@ struct srh_context {
 	// kernel's cost loops, every decision checked against an error bound, uncovered pixels redone in the reference's
 	// arithmetic -- the reference's bits at the fused speed; 1 = fused multiply-adds unchecked; 2 = packed single precision
 	int arith = 3;
+	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
@@ -468,6 +469,7 @@ extern "C" int srh_create(int device, srh_context **out) {
 	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
 	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
 	if (const char *s = getenv("SRH_STRIP")) c->strip = atoi(s);
+	if (const char *s = getenv("SRH_CERT_FORM")) { const int a = atoi(s); if (a == 1 || a == 2) c->cert_form = a; }
 	if (const char *s = getenv("SRH_ARITH")) { const int a = atoi(s); if (a >= 0 && a <= 3) c->arith = a; }
 	if (const char *s = getenv("SRH_MVS_STAGED")) c->mvs_staged = atoi(s) != 0;
 	if (const char *s = getenv("SRH_MVS_ASYNC")) c->mvs_async = atoi(s) != 0;
@@ -588,6 +590,10 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		c->arith = (int)value; return SRH_OK;
 	}
 	if (!strcmp(name, "force_dense")) { c->force_dense = value != 0; return SRH_OK; }
+	if (!strcmp(name, "cert_form")) {
+		if (value != 1 && value != 2) return fail(SRH_E_INVALID, "cert_form must be 1 (one-pass) or 2 (two fused sweeps)");
+		c->cert_form = (int)value; return SRH_OK;
+	}
 	if (!strcmp(name, "strip")) {
 		if (value != 0 && value != 1 && value != 4 && value != 8) return fail(SRH_E_INVALID, "strip must be 0, 1, 4 or 8");
 		c->strip = (int)value; return SRH_OK;
@@ -1130,7 +1136,8 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		int lanes = 8;
 		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
 		const bool cert = dense && cert_ok;
-		const int cost_arith = c->arith == 3 ? (cert ? 3 : 0) : c->arith;
+		// (the strip kernel's certified form: 5 = one sweep over the window, 3 = the reference's two sweeps fused; option "cert_form")
+		const int cost_arith = c->arith == 3 ? (cert ? (strip && c->cert_form == 1 ? 5 : 3) : 0) : c->arith;
 		if (cert && (rc = ensure(c->cflag, c->cflag_cap, rows*(size_t)W + 1))) return rc;
 		const bool planes = dense && (R == 5 || R == 2);
 		if (strip) lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);

@@ -80,8 +80,18 @@ struct PixRange { int32_t lo, hi; };
 // when sum3 >= sigma3(sum2); the cost kernel stores NaN for the others, and the certified scan flags every pixel
 // that meets a NaN or a comparison whose two sides are closer than the sum of their bounds: flagged pixels are
 // re-evaluated in the reference's arithmetic (twoview_refill_kernel + the exact scan).
+// ONE-PASS form (strip kernel, AR = 5).  Nothing obliges the fused kernel to follow the reference's two sweeps: any
+// arithmetic within e0 of the reference's will do.  With c_t = (w_t*l_t - meanL)*w_t, d_t = w_t^2, q = r^2 it accumulates
+// P = sum w_t r_t, Q = sum c_t r_t, U = sum d_t q_t in ONE sweep over the window (3 fused multiply-adds per tap and
+// candidate instead of 4, and 40 instead of 69 LDS values per window row and block), and finishes with m = P/tw,
+// sum3 = U - m*(2P - T*m), sum1 = Q - m*SA (SA = sum of w_t*l_t - meanL).  The price is cancellation in sum3: with
+// Q3 = U + 2mP + T*m^2 (every term >= 0) and z^2 = Q3/sum3, the one-pass value is within
+//     255*1.01*(3*gamma_(T+4)*z + 2.002*gamma_(T+3)*z^2) + 1300u
+// of the real-number cost, the reference's arithmetic within half of k1/B + k2/A + k3: a candidate is
+// certified when sum3 >= sigma3(sum2) (the latter <= e0/2) and Q3 <= zmax2*sum3 (the former <= e0/2).
 struct CertBound {
 	double e0, m_hi, k1, k2, room;
+	double zmax2;
 	int ok;                                 // 0: the parameters leave the bound no room / weights are not in (0,1]: exact arithmetic
 	__host__ __device__ inline double sigma3(double s2) const {
 		const double d = room - k2/sqrt(s2);                      // (NaN or zero sum2: d is NaN or -inf)
@@ -107,6 +117,11 @@ inline CertBound cert_bound(const srh_params &P, bool mvs = false) {
 	const double k3 = 2*scale*1.01*2*gamma(T) + (mvs ? 40 : 2600)*u;
 	c.room = c.e0 - k3;
 	c.m_hi = P.max_color_diff + c.e0;
+	{	// one-pass form: 255*1.01*g*(3z + 2.002 z^2) + 1300u = e0/2
+		const double g = gamma(T + 4), rhs = (c.e0/2 - 1300*u)/(scale*1.01*g);
+		const double z = rhs > 0 ? (-3.0 + sqrt(9.0 + 4*2.002*rhs))/(2*2.002) : 0.0;
+		c.zmax2 = z*z*(1.0 - 0x1p-20);
+	}
 	const bool weights_ok = P.weight_kind == SRH_WEIGHT_GEODESIC ? P.geodesic_sigma > 0 : P.adaptive_color_sigma > 0;   // exp(-distance/sigma) <= 1
 	if (mvs) { c.ok = c.room > 0 && weights_ok && fabs(P.peak_threshold) <= 1e5; return c; }
 	// the clamp test needs max_color_diff + e0 > max_color_diff (so below 2^22); the duplicate rule of the scan needs

@@ -308,7 +308,8 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 }
 
 // NWV waves: 4 (block lanes per pixel G = 8, NBUF = 1) or 8 (G = 16, NBUF = 2)
-// AR: 0 = the reference's arithmetic (no contraction), 1 = fused multiply-adds, 3 = fused AND certified: a candidate
+// AR: 0 = the reference's arithmetic (no contraction), 1 = fused multiply-adds, 5 = certified ONE-PASS form (below),
+// 3 = fused two sweeps AND certified: a candidate
 // whose error bound (srh_internal.hpp, CertBound) is not below cb.e0 is stored as NaN, a value above max_color_diff + e0
 // as max_color_diff itself (the exact cost is then max_color_diff too), anything else unclamped -- the certified scan
 // does the rest.  Candidates of the select forms are evaluated in the reference's arithmetic in every mode.
@@ -316,7 +317,7 @@ template <int R, int NWV, int NBUF, int AR>
 __global__ __launch_bounds__(NWV*64, 2)
 void twoview_strip_cost_kernel(const StripArgs A)
 {
-	constexpr bool FMA = AR != 0, CERT = AR == 3;
+	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;
 	typedef StripSmem<R, NBUF> Smem;
 	constexpr int WS = Smem::WS, WP = Smem::WP, WPIX = Smem::WPIX, RW = Smem::RW, LW = Smem::LW, NS = Smem::NS;
 	constexpr int NCB = ST_NCB, CHUNK = ST_CHUNK;
@@ -557,7 +558,78 @@ void twoview_strip_cost_kernel(const StripArgs A)
 						const int c = c0 + j;
 						if (c >= lo && c <= hi && rfull[rc + j] != 0) { fast = true; ++n_dev; }
 					}
-					if (fast) {
+					if (fast && ONEPASS) {
+						// ---- certified ONE-PASS form (srh_internal.hpp, CertBound): P = sum w r, Q = sum ((w l - meanL) w) r,
+						// U = sum w^2 r^2 in one sweep over the window; registers are refilled in place a row ahead, as below
+						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
+						double r_[NR], q_[NR], w_[WS], l_[WS], P_[NCB], Q_[NCB], U_[NCB], SA = 0.0;
+						{
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + s0*RW + rc);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][0][i][0]);
+#pragma unroll
+							for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+#pragma unroll
+							for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; w_[2*m] = v.x; w_[2*m + 1] = v.y; }
+							w_[WS - 1] = CS.w[wcur][0][i][WS - 1];
+#pragma unroll
+							for (int col = 0; col < WS; ++col) l_[col] = CS.lt[s0][i + col];
+						}
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) { P_[j] = 0.0; Q_[j] = 0.0; U_[j] = 0.0; }
+						__builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll 1
+						for (int row = 0; row < WS; ++row) {
+							int seen = 0;
+							prog_step(4, seen);
+							const int nrow = row + 1 < WS ? row + 1 : 0;          // (the last refill is never used)
+							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
+							const double *lp = &CS.lt[nsl][i];
+#pragma unroll
+							for (int k = 0; k < NCB - 1; ++k) q_[k] = r_[k]*r_[k];
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								q_[col + NCB - 1] = r_[col + NCB - 1]*r_[col + NCB - 1];
+								const double a = __builtin_fma(w_[col], l_[col], -mL);
+								const double c = a*w_[col], d = w_[col]*w_[col];
+								SA += a;
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int j = 0; j < NCB; ++j) P_[j] = __builtin_fma(w_[col], r_[col + j], P_[j]);
+#pragma unroll
+								for (int j = 0; j < NCB; ++j) Q_[j] = __builtin_fma(c, r_[col + j], Q_[j]);
+#pragma unroll
+								for (int j = 0; j < NCB; ++j) U_[j] = __builtin_fma(d, q_[col + j], U_[j]);
+								__builtin_amdgcn_sched_barrier(0);
+								l_[col] = lp[col];
+								if (col & 1) {
+									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
+									const double2 u = wp[col >> 1]; w_[col - 1] = u.x; w_[col] = u.y;
+								}
+								__builtin_amdgcn_sched_barrier(0);
+							}
+#pragma unroll
+							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+							w_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
+							prog_yield(seen);
+						}
+						constexpr double TT = (double)(WS*WS);
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) {
+							const int c = c0 + j;
+							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
+								const double m = P_[j]/tw, p2 = P_[j] + P_[j];
+								const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U_[j]);    // U - m*(2P - T*m)
+								const double s1 = __builtin_fma(-m, SA, Q_[j]);
+								const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
+								const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
+								const bool okc = s3 >= sig3 && s3*A.cb.zmax2 >= q3;
+								crow[(size_t)(c - e_min)*ST_TP] = !okc ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
+							}
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					} else if (fast) {
 						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
 						// Both passes are modulo-scheduled by hand (see twoview_dense_cost_kernel): a register is refilled
 						// with the next row's value right after its last use, so the LDS latency is always a row ahead.
@@ -801,7 +873,8 @@ static void launch_strip_variant(hipStream_t st, const StripArgs &a, int num_cus
 template <int R, int NWV, int NBUF>
 static void launch_strip_arith(hipStream_t st, const StripArgs &a, int num_cus, int arith)
 {
-	if (arith == 3) launch_strip_variant<R, NWV, NBUF, 3>(st, a, num_cus);
+	if (arith == 5) launch_strip_variant<R, NWV, NBUF, 5>(st, a, num_cus);
+	else if (arith == 3) launch_strip_variant<R, NWV, NBUF, 3>(st, a, num_cus);
 	else if (arith == 1) launch_strip_variant<R, NWV, NBUF, 1>(st, a, num_cus);
 	else launch_strip_variant<R, NWV, NBUF, 0>(st, a, num_cus);
 }
