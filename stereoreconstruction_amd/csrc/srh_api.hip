@@ -1049,7 +1049,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
-						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? 3 : 0); }
+						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? (c->cert_form == 1 ? 5 : 3) : 0); }
 						{ Scope s(c, "twoview_rows_scan_kernel");
 						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, rows_cert ? c->cflag : nullptr, -1, c->d_cnt); }
@@ -1137,7 +1137,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
 		const bool cert = dense && cert_ok;
 		// (the strip kernel's certified form: 5 = one sweep over the window, 3 = the reference's two sweeps fused; option "cert_form")
-		const int cost_arith = c->arith == 3 ? (cert ? (strip && c->cert_form == 1 ? 5 : 3) : 0) : c->arith;
+		const int cost_arith = c->arith == 3 ? (cert ? (c->cert_form == 1 ? 5 : 3) : 0) : c->arith;
 		if (cert && (rc = ensure(c->cflag, c->cflag_cap, rows*(size_t)W + 1))) return rc;
 		const bool planes = dense && (R == 5 || R == 2);
 		if (strip) lanes = strip_block_lanes(cstride, c->strip == 1 ? 0 : c->strip);

@@ -450,7 +450,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
                                const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
                                Counters *__restrict__ cnt, const double *__restrict__ pconst, const CertBound cb)
 {
-	constexpr bool FMA = AR != 0, CERT = AR == 3;
+	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;   // 5: the certified one-pass form (srh_internal.hpp, CertBound)
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
 	typedef DenseSmem<R, DC_NCB, DC_CHUNK> Smem;
@@ -657,7 +657,74 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #ifdef SRH_PROFILE_PHASES
 				const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
-				if (fast) {
+				if (fast && ONEPASS) {
+					// certified one-pass form (twoview_strip_cost_kernel): P = sum w r, Q = sum ((w l - meanL) w) r, U = sum w^2 r^2
+					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
+					const double sig3 = cb.sigma3(s2);
+					double r[NR], q[NR], wv[WS], lv[WS], P_[DC_NCB], Q_[DC_NCB], U_[DC_NCB], SA = 0.0;
+					{
+						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[0][rc]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
+#pragma unroll
+						for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+#pragma unroll
+						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][WS - 1];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) lv[col] = CS.lt[0][i + col];
+					}
+#pragma unroll
+					for (int j = 0; j < DC_NCB; ++j) { P_[j] = 0.0; Q_[j] = 0.0; U_[j] = 0.0; }
+					__builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll 1
+					for (int row = 0; row < WS; ++row) {
+						const int nrow = row + 1 < WS ? row + 1 : 0;          // (the last refill is never used)
+						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nrow][rc]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const double *lp = &CS.lt[nrow][i];
+#pragma unroll
+						for (int k = 0; k < DC_NCB - 1; ++k) q[k] = r[k]*r[k];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) {
+							q[col + DC_NCB - 1] = r[col + DC_NCB - 1]*r[col + DC_NCB - 1];
+							const double a = __builtin_fma(wv[col], lv[col], -mL);
+							const double c = a*wv[col], d = wv[col]*wv[col];
+							SA += a;
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) P_[j] = __builtin_fma(wv[col], r[col + j], P_[j]);
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) Q_[j] = __builtin_fma(c, r[col + j], Q_[j]);
+#pragma unroll
+							for (int j = 0; j < DC_NCB; ++j) U_[j] = __builtin_fma(d, q[col + j], U_[j]);
+							__builtin_amdgcn_sched_barrier(0);
+							lv[col] = lp[col];
+							if (col & 1) {
+								const double2 v = rp[col >> 1]; r[col - 1] = v.x; r[col] = v.y;
+								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
+							}
+							__builtin_amdgcn_sched_barrier(0);
+						}
+#pragma unroll
+						for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
+					}
+					constexpr double TT = (double)T;
+#pragma unroll
+					for (int j = 0; j < DC_NCB; ++j) {
+						const int c = c0 + j;
+						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
+							const double m = P_[j]/tw, p2 = P_[j] + P_[j];
+							const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U_[j]);    // U - m*(2P - T*m)
+							const double s1 = __builtin_fma(-m, SA, Q_[j]);
+							const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
+							const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
+							const bool okc = s3 >= sig3 && s3*cb.zmax2 >= q3;
+							crow[(size_t)(c - e.xmin)*DC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				} else if (fast) {
 					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
 					const double sig3 = CERT ? cb.sigma3(s2) : 0.0;
 					// Both passes are modulo-scheduled by hand: r[] / wv[] / av[] hold the current
@@ -845,12 +912,14 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 #define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst
 	switch (P.window_radius) {
 	case 5:
-		if (arith == 3) launch_dense_variant<5, 8, 320, 2, 3>(SRH_ARGS);
+		if (arith == 5) launch_dense_variant<5, 8, 320, 2, 5>(SRH_ARGS);
+		else if (arith == 3) launch_dense_variant<5, 8, 320, 2, 3>(SRH_ARGS);
 		else if (arith == 1) launch_dense_variant<5, 8, 320, 2, 1>(SRH_ARGS);
 		else launch_dense_variant<5, 8, 320, 2, 0>(SRH_ARGS);
 		return true;
 	case 2:
-		if (arith == 3) launch_dense_variant<2, 8, 320, 2, 3>(SRH_ARGS);
+		if (arith == 5) launch_dense_variant<2, 8, 320, 2, 5>(SRH_ARGS);
+		else if (arith == 3) launch_dense_variant<2, 8, 320, 2, 3>(SRH_ARGS);
 		else if (arith == 1) launch_dense_variant<2, 8, 320, 2, 1>(SRH_ARGS);
 		else launch_dense_variant<2, 8, 320, 2, 0>(SRH_ARGS);
 		return true;

@@ -111,7 +111,7 @@ inline CertBound cert_bound(const srh_params &P, bool mvs = false) {
 	const double eps_b = gamma(T + 4)*G, eps_a = 2*u*G, rt = sqrt((double)T);
 	const double scale = mvs ? 1.0 : 255.0;
 	CertBound c;
-	c.e0 = mvs ? 0x1p-36 : 0x1p-30;                               // TwoView: 9.3e-10, a comparison needs 2.3e-9 of margin
+	c.e0 = mvs ? 0x1p-36 : 0x1p-26;                               // TwoView: 1.5e-8, a comparison needs 3.7e-8 of margin (costs live in [0, 120])
 	c.k1 = 2*scale*1.01*3*eps_b*rt;
 	c.k2 = 2*scale*1.01*eps_a*rt;
 	const double k3 = 2*scale*1.01*2*gamma(T) + (mvs ? 40 : 2600)*u;

@@ -131,7 +131,7 @@ struct RowsSmem {
 	static constexpr int LW = RC_TP + 2*R;
 	double w[RC_TP][WPIX];
 	double lt[WS][LW];
-	double meanL[RC_TP], totalW[RC_TP], sum2[RC_TP];
+	double meanL[RC_TP], totalW[RC_TP], sum2[RC_TP], sumA[RC_TP];   // sumA: sum of w_t*l_t - meanL, fused (one-pass form only)
 	int lall[RC_TP];
 	int meta[RC_TP];
 	uint32_t rowinfo[RC_TP][RW_NR];
@@ -154,7 +154,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
                               const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
                               double *__restrict__ cost, int smax, Counters *__restrict__ cnt, const CertBound cb)
 {
-	constexpr bool FMA = AR != 0, CERT = AR == 3;
+	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;   // 5: the certified ONE-PASS form (srh_internal.hpp, CertBound)
 	constexpr int WS = 2*R + 1;
 	constexpr int T = WS*WS;
 	typedef RowsSmem<R> Smem;
@@ -243,7 +243,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				mL += wt*gl;
 				tw += wt;
 			}
-		double s2 = 0;
+		double s2 = 0, sA = 0;
 		if (all && !(tw < 1e-10)) {
 			mL /= tw;
 #pragma unroll 1
@@ -252,9 +252,10 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				for (int col = 0; col < WS; ++col) {
 					const double a = S.w[i][row*WP + col]*S.lt[row][i + col] - mL;
 					s2 += a*a;
+					if (ONEPASS) sA += __builtin_fma(S.w[i][row*WP + col], S.lt[row][i + col], -mL);
 				}
 		} else all = false;
-		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
+		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0; S.sumA[i] = sA;
 		const int nr = S.meta[i] >> 16;
 		int nblk = 0;
 		for (int r = 0; r < nr; ++r) {
@@ -403,7 +404,71 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				if (lane == __ffsll((long long)__ballot(1)) - 1) { ++d_waveiter; }
 				if (__all(fast) && lane == __ffsll((long long)__ballot(1)) - 1) ++d_wavefast;
 #endif
-				if (fast) {
+				if (fast && ONEPASS) {
+					// certified one-pass form: P = sum w r, Q = sum ((w l - meanL) w) r, U = sum w^2 r^2 in ONE sweep over the window
+					// (twoview_strip_cost_kernel); the other view's row segments come from L1 / L2 once instead of twice
+					typedef const __attribute__((address_space(1))) double *gptr;
+					const gptr rbase = (gptr)(Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R));
+					const double SA = CS.sumA[i];
+					double r[NR_], q[NR_], wv[WS], lv[WS], P_[RC_NCB], Q_[RC_NCB], U_[RC_NCB];
+					{
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
+#pragma unroll
+						for (int k = 0; k < NR_; ++k) r[k] = rbase[k];
+#pragma unroll
+						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
+						wv[WS - 1] = CS.w[i][WS - 1];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) lv[col] = CS.lt[0][i + col];
+					}
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) { P_[j] = 0.0; Q_[j] = 0.0; U_[j] = 0.0; }
+#pragma unroll 1
+					for (int row = 0; row < WS; ++row) {
+						const int nrow = row + 1 < WS ? row + 1 : 0;          // (the last refill is never used)
+						const gptr rp = rbase + (size_t)nrow*OW;
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const double *lp = &CS.lt[nrow][i];
+#pragma unroll
+						for (int k = 0; k < RC_NCB - 1; ++k) q[k] = r[k]*r[k];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) {
+							q[col + RC_NCB - 1] = r[col + RC_NCB - 1]*r[col + RC_NCB - 1];
+							const double a = __builtin_fma(wv[col], lv[col], -mL);
+							const double c = a*wv[col], d = wv[col]*wv[col];
+							__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) P_[j] = __builtin_fma(wv[col], r[col + j], P_[j]);
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) Q_[j] = __builtin_fma(c, r[col + j], Q_[j]);
+#pragma unroll
+							for (int j = 0; j < RC_NCB; ++j) U_[j] = __builtin_fma(d, q[col + j], U_[j]);
+							__builtin_amdgcn_sched_barrier(0);
+							lv[col] = lp[col];
+							if (col & 1) {
+								r[col - 1] = rp[col - 1]; r[col] = rp[col];
+								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
+							}
+							__builtin_amdgcn_sched_barrier(0);
+						}
+#pragma unroll
+						for (int k = WS - 1; k < NR_; ++k) r[k] = rp[k];
+						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
+					}
+					constexpr double TT = (double)T;
+#pragma unroll
+					for (int j = 0; j < RC_NCB; ++j) {
+						if (j >= sh) {
+							const double m = P_[j]/tw, p2 = P_[j] + P_[j];
+							const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U_[j]);    // U - m*(2P - T*m)
+							const double s1 = __builtin_fma(-m, SA, Q_[j]);
+							const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
+							const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
+							const bool okc = s3 >= sig3 && s3*cb.zmax2 >= q3;
+							dst[(j - sh)*RC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
+						}
+					}
+				} else if (fast) {
 					// blocked fast form (srh_dense.hip): a row segment of NCB+2R values of the other view is
 					// read once per window row and shared by the NCB candidates and 2R+1 taps
 					// (a global pointer, not a generic one: flat loads would share the LDS counter, and every wait for a
@@ -555,7 +620,7 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb);  \
 		return true;                                                                                        \
 	}
-#define SRH_RC_LAUNCH(RR) { if (arith == 3) SRH_RC_LAUNCH2(RR, 3) else SRH_RC_LAUNCH2(RR, 0) }
+#define SRH_RC_LAUNCH(RR) { if (arith == 5) SRH_RC_LAUNCH2(RR, 5) else if (arith == 3) SRH_RC_LAUNCH2(RR, 3) else SRH_RC_LAUNCH2(RR, 0) }
 	switch (P.window_radius) {
 	case 1: SRH_RC_LAUNCH(1)
 	case 2: SRH_RC_LAUNCH(2)
