@@ -863,6 +863,10 @@ static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int
 		Scope s(c, "geodesic_reg_kernel");
 		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride, pconst, wimg)) return;
 	}
+	if (p.weight_kind == SRH_WEIGHT_ADAPTIVE && !c->force_generic) {
+		Scope s(c, "adaptive_reg_kernel");
+		if (launch_adaptive_reg(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride, pconst, wimg)) return;
+	}
 	Scope s(c, "weights_kernel");
 	launch_weights(c->stream, c->d_views, ref, W, p, by, nr, c->wbuf, wstride, pconst, wimg);
 }

@@ -285,6 +285,105 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 }
 #undef GEO_STAMP
 
+// ------------------------------------------------------------------ AdaptiveWeight windows (adaptiveweight.cpp:33-79)
+// One thread per pixel, one wave = 64 consecutive pixels of a row; the colour tile and the tap plane of the wave in
+// LDS; weights leave tile-major (wb[tap*32 + pixel]: 256-byte segments per wave store), the per-pixel constants of
+// the dense kernel's fast form follow on the way (pconst, as in geodesic_reg_kernel).  Same operations as weights_kernel's adaptive branch -- dw[|row|]*dw[|col|]
+// with dw[k] = exp(-k/radius) taken from a table of R+1 values instead of being recomputed per tap, the colour
+// distance, exp(-diff/sigma), NaN -> 0 -- so the same bits; that kernel issued ~130 instructions per tap (two exp,
+// a square root, a division) and then read its window back from memory twice for the constants.
+#define AW_TW 64
+template <int R>
+__global__ __launch_bounds__(AW_TW)
+void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params P, int y0, int nrows,
+                         double *__restrict__ wbuf, size_t wstride, double *__restrict__ pconst)
+{
+	constexpr int WS = 2*R + 1, TWD = AW_TW + 2*R;
+	const ViewDev &V = views[ref];
+	const int W = V.w, H = V.h;
+	const int tiles = (W + AW_TW - 1)/AW_TW;
+	const int trow = blockIdx.x / tiles, x0 = (blockIdx.x % tiles)*AW_TW;
+	const int cy = y0 + trow;
+	const int i = threadIdx.x, cx = x0 + i;
+	__shared__ uint32_t ct[WS][TWD];                             // rgba of the tile; pixels outside the image: never looked at (inb)
+	__shared__ double gt[WS][TWD];                               // TwoView tap values (NaN = unusable), for pconst
+	for (int k = i; k < WS*TWD; k += AW_TW) {
+		const int ty = k / TWD, tx = k % TWD;
+		const int gx = x0 - R + tx, gy = cy - R + ty;
+		const bool in = gx >= 0 && gy >= 0 && gx < W && gy < H;
+		ct[ty][tx] = in ? V.rgba[(size_t)gy*W + gx] : 0u;
+		gt[ty][tx] = (pconst && in) ? V.gray_tv[(size_t)gy*W + gx] : __builtin_nan("");
+	}
+	__syncthreads();
+	if (cx >= W || V.mask[(size_t)cy*W + cx] != 1) return;       // masked pixels never reach init_weights
+	double dw[R + 1];
+#pragma unroll
+	for (int k = 0; k <= R; ++k) dw[k] = exp(-k / (1.0*R));
+	const uint32_t crgb = ct[R][i + R];
+	double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
+	// the window is NOT kept in registers (121 doubles would leave one wave per SIMD alone with the exp / sqrt / division
+	// chains): weights stream out as they are computed, meanL / totalWeight accumulate on the way, and the second sweep of
+	// the constants reads the weights back (the wave's own 256-byte segments, just written)
+	bool all = true;
+	double mL = 0, tw = 0;
+#pragma unroll 1
+	for (int a = 0; a < WS; ++a) {
+		const int py = cy - R + a;
+		const double dwr = dw[a < R ? R - a : a - R];
+#pragma unroll
+		for (int b = 0; b < WS; ++b) {
+			const int px = cx - R + b;
+			double weight = 0.0;
+			if (!(px < 0 || py < 0 || px >= W || py >= H)) {
+				const uint32_t q = ct[a][i + b];
+				const double dr = (double)((int)(q & 255u) - (int)(crgb & 255u));
+				const double dg = (double)((int)((q >> 8) & 255u) - (int)((crgb >> 8) & 255u));
+				const double db = (double)((int)((q >> 16) & 255u) - (int)((crgb >> 16) & 255u));
+				const double diff = sqrt(dr*dr + dg*dg + db*db);           // (color_dist: exact small integers)
+				const double w1 = dwr*dw[b < R ? R - b : b - R];
+				const double w2 = exp(-diff / P.adaptive_color_sigma);
+				weight = w1*w2;
+				if (weight != weight) weight = 0.0;
+			}
+			wb[(size_t)(a*WS + b)*wstride] = weight;
+			if (pconst) {
+				const double gl = gt[a][i + b];
+				if (!(gl == gl && weight > P.weight_cutoff)) all = false;
+				mL += weight*gl;
+				tw += weight;
+			}
+		}
+	}
+	if (pconst) {
+		double s2 = 0;
+		if (all && !(tw < 1e-10)) {
+			mL /= tw;
+#pragma unroll 1
+			for (int a = 0; a < WS; ++a) {
+				double wr[WS];
+#pragma unroll
+				for (int b = 0; b < WS; ++b) wr[b] = wb[(size_t)(a*WS + b)*wstride];
+#pragma unroll
+				for (int b = 0; b < WS; ++b) { const double t = wr[b]*gt[a][i + b] - mL; s2 += t*t; }
+			}
+		} else all = false;
+		double *pc = pconst + ((size_t)trow*W + cx)*4;
+		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+	}
+}
+
+// tile-major windows only (the strip path's LDS-image layout and other radii stay on weights_kernel)
+bool launch_adaptive_reg(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P, int y0, int nrows,
+                         double *wbuf, size_t wstride, double *pconst, bool wimg)
+{
+	if (wimg || wstride != SRH_WTILE) return false;
+	const dim3 grid((unsigned)(((width + AW_TW - 1)/AW_TW)*nrows)), block(AW_TW);
+	if (P.window_radius == 5) hipLaunchKernelGGL(adaptive_reg_kernel<5>, grid, block, 0, st, views, ref, P, y0, nrows, wbuf, wstride, pconst);
+	else if (P.window_radius == 2) hipLaunchKernelGGL(adaptive_reg_kernel<2>, grid, block, 0, st, views, ref, P, y0, nrows, wbuf, wstride, pconst);
+	else return false;
+	return true;
+}
+
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst, bool wimg)
 {

@@ -185,6 +185,8 @@ void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, doub
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr,
                          bool wimg = false);
+bool launch_adaptive_reg(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P, int y0, int nrows,
+                         double *wbuf, size_t wstride, double *pconst = nullptr, bool wimg = false);
 void launch_label_plane_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tdist);
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
