@@ -1188,7 +1188,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						                            c->d_cnt, arith, c->num_cus, lanes); }
 						Scope s(c, "twoview_lazy_fill_kernel");
 						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
-						                         c->views[ref].tvp, c->views[oth].tvp, true, lanes, c->cost, cstride, c->d_cnt);
+						                         c->views[ref].tvp, c->views[oth].tvp, true, lanes, lanes == 8, c->cost, cstride, c->d_cnt);
 					} else {
 						{ Scope s(c, "twoview_dense_cost_kernel");
 						  if (arith == 2)
@@ -1200,7 +1200,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						Scope s(c, "twoview_lazy_fill_kernel");
 						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
 						                         planes ? c->views[ref].tvp : nullptr, planes ? c->views[oth].tvp : nullptr, false, 8,
-						                         c->cost, cstride, c->d_cnt);
+						                         arith != 5, c->cost, cstride, c->d_cnt);   // (the one-pass form leaves no column out)
 					}
 					return SRH_OK;
 				};

@@ -626,7 +626,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		if (x < W && L.mask[(size_t)y*W + x] == 1) {
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 			pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
-			if (hi >= lo) hi = dense_cover_hi(lo, hi, DC_NCB, DC_G);   // columns beyond: evaluated lazily by the scan
+			if (hi >= lo) hi = dense_cover_hi(lo, hi, DC_NCB, DC_G, !ONEPASS);   // columns beyond: evaluated by the fill kernel
 		}
 		S.pxmin[i] = lo; S.pxmax[i] = hi;
 		if (hi >= lo) { atomicMin(&s_cmin, lo); atomicMax(&s_cmax, hi); }
@@ -732,7 +732,10 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		if (x < W && e.xmax >= e.xmin) {
 			const int lo = e.xmin > cs ? e.xmin : cs;
 			const int hi = e.xmax < cs + DC_CHUNK - 1 ? e.xmax : cs + DC_CHUNK - 1;
-			const int lo_e = lo & ~1;                               // blocks start on even columns (>= cs)
+			// blocks start on even columns (>= cs): 16-byte LDS reads of the other view's rows.  The one-pass form reads them
+			// 8 bytes at a time in pairs (ds_read2_b64: no alignment beyond 8 bytes) and starts at the pixel's first column: a
+			// range of 8*k columns is k blocks whatever its parity, and no column is left to the fill kernel
+			const int lo_e = ONEPASS ? lo : (lo & ~1);
 			const int nblocks = hi >= lo ? (hi - lo_e + DC_NCB)/DC_NCB : 0;
 			// cost rows are tile-transposed: column k (relative to the pixel's xmin) of pixel i of this tile at
 			// ((tile*cstride) + k)*DC_TP + i -- the 32 pixels' k-th costs are contiguous for the scan's wave loads
@@ -762,10 +765,10 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 					const double sig3 = cb.sigma3(s2);
 					double r[NR], q[NR], wv[WS], lv[WS], P_[DC_NCB], Q_[DC_NCB], U_[DC_NCB], SA = 0.0;
 					{
-						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[0][rc]);
+						const double *rp = &CS.rt[0][rc];
 						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
 #pragma unroll
-						for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+						for (int k = 0; k < NR; ++k) r[k] = rp[k];
 #pragma unroll
 						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
 						wv[WS - 1] = CS.w[i][WS - 1];
@@ -778,7 +781,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
 						const int nrow = row + 1 < WS ? row + 1 : 0;          // (the last refill is never used)
-						const double2 *rp = reinterpret_cast<const double2 *>(&CS.rt[nrow][rc]);
+						const double *rp = &CS.rt[nrow][rc];
 						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
 						const double *lp = &CS.lt[nrow][i];
 #pragma unroll
@@ -799,13 +802,13 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 							__builtin_amdgcn_sched_barrier(0);
 							lv[col] = lp[col];
 							if (col & 1) {
-								const double2 v = rp[col >> 1]; r[col - 1] = v.x; r[col] = v.y;
+								r[col - 1] = rp[col - 1]; r[col] = rp[col];
 								const double2 u = wp[col >> 1]; wv[col - 1] = u.x; wv[col] = u.y;
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
 #pragma unroll
-						for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r[2*m] = v.x; r[2*m + 1] = v.y; }
+						for (int k = WS - 1; k < NR; ++k) r[k] = rp[k];
 						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
 					}
 					constexpr double TT = (double)T;
@@ -1049,7 +1052,7 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 // 27 000 instructions long, far beyond the instruction cache.)  Radii without a template instance: tv_cost through the views.
 __global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0, int nrows,
                                          const PixRange *__restrict__ prange, const double *__restrict__ wbuf, size_t wstride,
-                                         int ncb, int lanes, double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
+                                         int ncb, int lanes, int pad, double *__restrict__ cost, int cstride, Counters *__restrict__ cnt)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
@@ -1060,7 +1063,7 @@ __global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int 
 		const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
 		const PixRange pr = prange[q];
 		if (pr.hi >= pr.lo) {
-			const int cover = dense_cover_hi(pr.lo, pr.hi, ncb, lanes);
+			const int cover = dense_cover_hi(pr.lo, pr.hi, ncb, lanes, pad != 0);
 			if (cover < pr.hi) {
 				const int R = P.window_radius, T = (2*R + 1)*(2*R + 1);
 				const double *wq = wbuf + wbuf_offset(W, T, trow, x);
@@ -1207,17 +1210,17 @@ bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y
 void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,
                               const double *ref_tvp, const double *oth_tvp, bool wimg,
-                              int lanes, double *cost, int cstride, Counters *cnt)
+                              int lanes, bool padded, double *cost, int cstride, Counters *cnt)
 {
 	const size_t n = (size_t)nrows*width;
 	const dim3 grid((unsigned)((n + 255)/256)), block(256);
-	const int pad = (!wimg || lanes == 8) ? 1 : 0;
+	const int pad = padded ? 1 : 0;
 	if (ref_tvp && P.window_radius == 5)
 		hipLaunchKernelGGL(twoview_lazy_fill_planes_kernel<5>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, 8, lanes, pad, cost, cstride, cnt);
 	else if (ref_tvp && P.window_radius == 2)
 		hipLaunchKernelGGL(twoview_lazy_fill_planes_kernel<2>, grid, block, 0, st, width, P, y0, nrows, prange, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, 8, lanes, pad, cost, cstride, cnt);
 	else
-		hipLaunchKernelGGL(twoview_lazy_fill_kernel, grid, block, 0, st, views, ref, oth, P, y0, nrows, prange, wbuf, wstride, 8, lanes, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_lazy_fill_kernel, grid, block, 0, st, views, ref, oth, P, y0, nrows, prange, wbuf, wstride, 8, lanes, pad, cost, cstride, cnt);
 }
 
 // sums / minima over the 64 lanes of the scan kernel's one-wave workgroup (no LDS, no barrier)

@@ -210,7 +210,8 @@ void launch_twoview_lazy_fill(hipStream_t st, const ViewDev *views, int ref, int
                               int y0, int nrows, const PixRange *prange, const double *wbuf, size_t wstride,
                               const double *ref_tvp, const double *oth_tvp,      // NaN-bordered planes (radius 5 / 2), else null
                               bool wimg,                                         // LDS-image windows (strip path), else tile-major
-                              int lanes, double *cost, int cstride, Counters *cnt);
+                              int lanes, bool padded,                            // the cost kernel's form: block lanes per pixel, blocks on even columns
+                              double *cost, int cstride, Counters *cnt);
 
 // Persistent strip form of the dense cost kernel, srh_strip.hip
 void launch_padded_plane(hipStream_t st, const double *gray_tv, int w, int h, double *out);
