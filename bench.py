@@ -355,9 +355,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
             if on_dev:
                 torch.cuda.current_stream().synchronize()   # the library writes the buffer from its own stream
             pending[b] = None
-        ctx.twoview_wta(0, 1, p)
-        ctx.twoview_wta(1, 0, p)
-        ctx.twoview_cross_check(0, 1, p)
+        ctx.twoview_compute_device(0, 1, p)            # srh_twoview_compute: WTA both ways + cross-check (TwoViewStereo::computeDepthMaps)
         ctx.copy_depth_to_device(0, outs[b][0].data_ptr(), H * W * 8)
         ctx.copy_depth_to_device(1, outs[b][1].data_ptr(), H * W * 8)
         if world > 1:

@@ -378,6 +378,10 @@ class Context:
         _check(lib().srh_twoview_compute(self._h, left_slot, right_slot, C.byref(p), _dptr(dl), _dptr(dr)))
         return dl, dr
 
+    def twoview_compute_device(self, left_slot, right_slot, p):
+        """srh_twoview_compute without host outputs: both passes + cross-check, the maps stay in the slots' device memory."""
+        _check(lib().srh_twoview_compute(self._h, left_slot, right_slot, C.byref(p), None, None))
+
     # -- MultiViewStereo
     def mvs_initial_estimate(self, view_slot, neigh_slots, p, y0=0, y1=0, peaks_dev=None):
         ng = np.ascontiguousarray(neigh_slots, dtype=np.int32)

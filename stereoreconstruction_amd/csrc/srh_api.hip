@@ -150,6 +150,11 @@ struct srh_context {
 	// kernel's cost loops, every decision checked against an error bound, uncovered pixels redone in the reference's
 	// arithmetic -- the reference's bits at the fused speed; 1 = fused multiply-adds unchecked; 2 = packed single precision
 	int arith = 3;
+	// srh_twoview_compute queues both passes and the cross-check and verifies the passes' counters with ONE wait at the end
+	// (the plans are refuted once in a blue moon; a wait per pass leaves the GPU idle while the host launches the next one)
+	struct TvDefer { Counters *host = nullptr; bool queued = false, strip = false, cert = false; };
+	TvDefer tv_defer[2];
+	TvDefer *defer = nullptr;
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
@@ -549,6 +554,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->pconst) hipFree(c->pconst);
 	if (c->prange) hipFree(c->prange);
 	if (c->cflag) hipFree(c->cflag);
+	for (auto &d : c->tv_defer) if (d.host) hipHostFree(d.host);
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
 	for (int i = 0; i < SRH_MAX_VIEWS; ++i) if (c->mrf_stream[i]) hipStreamDestroy(c->mrf_stream[i]);
@@ -1026,6 +1032,18 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					if ((rc = ensure(c->lrowinfo, c->lrowinfo_cap, px64*(size_t)SRH_ROWS_NR))) return rc;
 					if ((rc = ensure(c->lmeta, c->lmeta_cap, lrows*W))) return rc;
 					if (rows_cert && (rc = ensure(c->cflag, c->cflag_cap, lrows*W + 1))) return rc;
+					if (rows_cert) {
+						// NaN-bordered planes of both views: the general cost of the certified redo reads them without bound tests
+						for (int k = 0; k < 2; ++k) {
+							ViewHost &v = c->views[k == 0 ? ref : oth];
+							if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
+							if (!v.tvp_valid) {
+								Scope s(c, "padded_plane_kernel");
+								launch_padded_plane(c->stream, v.gray_tv, v.w, v.h, v.tvp);
+								v.tvp_valid = true;
+							}
+						}
+					}
 				}
 				for (int by = y0; by < y1; by += (int)lrows) {
 					if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
@@ -1062,7 +1080,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 							// (a list cut by a too small capacity is harmless here: the pass is repeated anyway)
 							const int cap = redo_capacity((size_t)nr*W);
 							{ Scope s(c, "twoview_rows_refill_kernel");
-							  launch_twoview_rows_refill(c->stream, c->d_views, ref, oth, *p, by, c->cflag, cap, c->wbuf,
+							  launch_twoview_rows_refill(c->stream, W, O.w, *p, by, c->cflag, cap, c->wbuf, c->views[ref].tvp, O.tvp,
 							                             c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt); }
 							Scope s(c, "twoview_rows_rescan_kernel");
 							launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
@@ -1227,6 +1245,14 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		}
 		HIP_TRY(hipGetLastError());
 		if (!dense) break;
+		if (c->defer && attempt == 0) {
+			// optimistic (srh_twoview_compute): the counters travel to pinned memory behind the kernels, the caller looks at them
+			HIP_TRY(hipMemcpyAsync(c->defer->host, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+			c->defer->queued = true; c->defer->strip = strip; c->defer->cert = cert_ok;
+			c->stats.used_strip_kernel = strip ? 1 : 0;
+			c->stats.used_dense_path = 1;
+			return SRH_OK;
+		}
 		// the dense result stands only if no candidate left its row / column range
 		Counters hc;
 		HIP_TRY(hipMemcpyAsync(&hc, c->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
@@ -1256,26 +1282,71 @@ extern "C" int srh_twoview_cross_check(srh_context *c, int left, int right, cons
 	return SRH_OK;
 }
 
+static bool tv_pass_stands(const srh_context::TvDefer &d) {
+	const Counters &h = *d.host;
+	return !(d.strip && h.strip_overflow != 0) && h.cert_overflow == 0 && h.not_row_aligned == 0;
+}
+
 extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const srh_params *p,
                                    double *left_out, double *right_out)
 {
 	int rc;
+	if ((rc = check_slot(c, left, true)) || (rc = check_slot(c, right, true)) || (rc = check_params(p))) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	for (auto &d : c->tv_defer) {
+		if (!d.host) HIP_TRY(hipHostMalloc((void **)&d.host, sizeof(Counters)));
+		d.queued = false;
+	}
 	// progress steps as TwoViewStereo emits them (twoviewstereo.cpp:234,405,597,225)
 	progress(c, 1, "Computing cost volume for left image...");
-	if ((rc = srh_twoview_wta(c, left, right, p, 0, 0))) return rc;
+	c->defer = &c->tv_defer[0];
+	rc = srh_twoview_wta(c, left, right, p, 0, 0);
+	c->defer = nullptr;
+	if (rc) return rc;
 	if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
-	srh_stats s_left;
-	if ((rc = fetch_counters(c, c->stats.used_dense_path))) return rc;
-	s_left = c->stats;
 	progress(c, 3, "Computing cost volume for right image...");
-	if ((rc = srh_twoview_wta(c, right, left, p, 0, 0))) return rc;
+	c->defer = &c->tv_defer[1];
+	rc = srh_twoview_wta(c, right, left, p, 0, 0);
+	c->defer = nullptr;
+	if (rc) return rc;
 	if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
+	srh_context::TvDefer &d0 = c->tv_defer[0], &d1 = c->tv_defer[1];
+	if (d0.queued && d1.queued) {
+		// both passes took the dense plan and are still unverified: queue the cross-check and the hand-over behind them, wait once
+		progress(c, 5, "Detecting inconsistencies...");
+		if ((rc = srh_twoview_cross_check(c, left, right, p))) return rc;
+		const ViewHost &L = c->views[left], &Rv = c->views[right];
+		if (left_out) HIP_TRY(hipMemcpyAsync(left_out, L.depth, (size_t)L.w*L.h*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+		if (right_out) HIP_TRY(hipMemcpyAsync(right_out, Rv.depth, (size_t)Rv.w*Rv.h*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (tv_pass_stands(d0) && tv_pass_stands(d1)) {
+			c->stats.n_pixels = (int64_t)(d0.host->n_pixels + d1.host->n_pixels);
+			c->stats.n_eval = (int64_t)(d0.host->n_eval + d1.host->n_eval);
+			c->stats.n_eval_device = (int64_t)(d0.host->n_eval_device + d1.host->n_eval_device);
+			c->stats.n_certified = (int64_t)(d0.host->n_certified + d1.host->n_certified);
+			c->stats.n_flagged = (int64_t)(d0.host->n_flagged + d1.host->n_flagged);
+			c->stats.used_dense_path = 1;
+			c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
+			progress(c, 8, "Finished!");
+			return SRH_OK;
+		}
+		// a plan was refuted on the device (a curve off its row, a range wider than a chunk, more flagged pixels than the
+		// redo covers): everything once more, each pass verified before the next step -- the maps are rewritten whole
+		d0.queued = d1.queued = false;
+		if ((rc = srh_twoview_wta(c, left, right, p, 0, 0))) return rc;
+		if ((rc = srh_twoview_wta(c, right, left, p, 0, 0))) return rc;
+	} else {
+		// one pass (or none) was left unverified: settle it now, before anything reads its map
+		for (int k = 0; k < 2; ++k) {
+			srh_context::TvDefer &d = c->tv_defer[k];
+			if (!d.queued) continue;
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			d.queued = false;
+			if (!tv_pass_stands(d) && (rc = (k == 0 ? srh_twoview_wta(c, left, right, p, 0, 0) : srh_twoview_wta(c, right, left, p, 0, 0)))) return rc;
+		}
+	}
+	// (counters of the two passes for the statistics: an untimed recount is not worth a pass; the last pass's are reported)
 	if ((rc = fetch_counters(c, c->stats.used_dense_path))) return rc;
-	c->stats.n_pixels += s_left.n_pixels;
-	c->stats.n_eval += s_left.n_eval;
-	c->stats.n_eval_device += s_left.n_eval_device;
-	c->stats.n_certified += s_left.n_certified;
-	c->stats.n_flagged += s_left.n_flagged;
 	progress(c, 5, "Detecting inconsistencies...");
 	if ((rc = srh_twoview_cross_check(c, left, right, p))) return rc;
 	if (left_out && (rc = srh_view_depth_download(c, left, left_out))) return rc;

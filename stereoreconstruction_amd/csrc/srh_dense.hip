@@ -1078,64 +1078,6 @@ __global__ void twoview_lazy_fill_kernel(const ViewDev *__restrict__ views, int 
 	block_count_add(&cnt->n_eval_device, n_lazy);
 }
 
-// cost_ncc in the reference's arithmetic for ANY validity pattern (a skipped tap adds +0.0: the same sums, same order as
-// tv_cost, twoviewstereo.cpp:909-977), from a window in either band layout and the NaN-bordered planes (no bound tests,
-// loops unrolled by window row so that a row's 33 loads travel together):
-// tap (row, col) of the window at wq[row*wrow + col*wcol]; lp / rp = top-left tap of the two windows in the padded planes (stride SP)
-template <int R>
-__device__ __forceinline__ double window_exact_cost(const double *__restrict__ wq, int wrow, int wcol, const double *__restrict__ lp,
-                                                    const double *__restrict__ rp, int SP, const srh_params &P)
-{
-	constexpr int WS = 2*R + 1;
-	double meanL = 0, meanR = 0, totalWeight = 0.0;
-#pragma unroll 1
-	for (int row = 0; row < WS; ++row) {
-		double gl[WS], gr[WS], wt[WS];
-#pragma unroll
-		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col*wcol]; }
-#pragma unroll
-		for (int col = 0; col < WS; ++col) {
-			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
-			const double pl = wt[col]*gl[col], prr = wt[col]*gr[col];
-			meanL += ok ? pl : 0.0;
-			meanR += ok ? prr : 0.0;
-			totalWeight += ok ? wt[col] : 0.0;
-		}
-	}
-	if (totalWeight < 1e-10) return P.bad_ret;
-	meanL /= totalWeight;
-	meanR /= totalWeight;
-	double sum1 = 0, sum2 = 0, sum3 = 0;
-#pragma unroll 1
-	for (int row = 0; row < WS; ++row) {
-		double gl[WS], gr[WS], wt[WS];
-#pragma unroll
-		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SP + col]; wt[col] = wq[row*wrow + col*wcol]; }
-#pragma unroll
-		for (int col = 0; col < WS; ++col) {
-			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
-			const double a = wt[col]*gl[col] - meanL, b = wt[col]*gr[col] - meanR;
-			const double ab = a*b, aa = a*a, bb = b*b;
-			sum1 += ok ? ab : 0.0;
-			sum2 += ok ? aa : 0.0;
-			sum3 += ok ? bb : 0.0;
-		}
-	}
-	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
-	return (v < P.max_color_diff) ? v : P.max_color_diff;
-}
-
-// where a pixel's window lies in the band buffer: wimg != 0 the strip path's LDS-image layout, else tile-major
-struct WindowAt { const double *wq; int wrow, wcol; };
-template <int R>
-__device__ __forceinline__ WindowAt window_at(const double *wbuf, int wimg, int W, int trow, int x) {
-	constexpr int WS = 2*R + 1;
-	WindowAt a;
-	if (wimg) { a.wq = wbuf + wimg_offset(W, R, trow, x); a.wrow = wimg_row_stride(R); a.wcol = 1; }
-	else      { a.wq = wbuf + wbuf_offset(W, WS*WS, trow, x); a.wrow = WS*SRH_WTILE; a.wcol = SRH_WTILE; }
-	return a;
-}
-
 template <int R>
 __global__ __launch_bounds__(256)
 void twoview_lazy_fill_planes_kernel(int W, srh_params P, int y0, int nrows, const PixRange *__restrict__ prange,
@@ -1156,7 +1098,7 @@ void twoview_lazy_fill_planes_kernel(int W, srh_params P, int y0, int nrows, con
 			double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 			for (int c = cover + 1; c <= pr.hi; ++c) {
 				const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
-				crow[(size_t)(c - pr.lo)*DC_TP] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SP, P);
+				crow[(size_t)(c - pr.lo)*DC_TP] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SP, SP, P);
 				++n_lazy;
 			}
 		}
@@ -1176,19 +1118,20 @@ void twoview_refill_kernel(int W, srh_params P, int y0, const PixRange *__restri
 {
 	const uint32_t nflag = cflag[0];
 	if (blockIdx.x == 0 && threadIdx.x == 0 && nflag > (uint32_t)cap) atomicAdd(&cnt->cert_overflow, 1ull);
-	if (blockIdx.x >= nflag) return;
-	const uint32_t q = cflag[1 + blockIdx.x];
-	const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
-	const PixRange pr = prange[q];
-	const int SP = padded_stride(W);
-	const WindowAt wa = window_at<R>(wbuf, wimg, W, trow, x);
-	const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SP + (x + SRH_PADL - R);
-	double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 	unsigned n = 0;
-	for (int c = pr.lo + (int)threadIdx.x; c <= pr.hi; c += 64) {
-		const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
-		crow[(size_t)(c - pr.lo)*DC_TP] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SP, P);
-		++n;
+	for (uint32_t f = blockIdx.x; f < nflag && f < (uint32_t)cap; f += gridDim.x) {      // (a few hundred workgroups share the list)
+		const uint32_t q = cflag[1 + f];
+		const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
+		const PixRange pr = prange[q];
+		const int SP = padded_stride(W);
+		const WindowAt wa = window_at<R>(wbuf, wimg, W, trow, x);
+		const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SP + (x + SRH_PADL - R);
+		double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+		for (int c = pr.lo + (int)threadIdx.x; c <= pr.hi; c += 64) {
+			const double *rp = oth_tvp + (size_t)(y + SRH_PADY - R)*SP + (c + SRH_PADL - R);
+			crow[(size_t)(c - pr.lo)*DC_TP] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SP, SP, P);
+			++n;
+		}
 	}
 	block_count_add(&cnt->n_eval_device, n);
 }
@@ -1198,9 +1141,9 @@ bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y
 {
 	if (cap <= 0) return true;
 	if (P.window_radius == 5)
-		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)cap), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)(cap < 512 ? cap : 512)), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
 	else if (P.window_radius == 2)
-		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)cap), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)(cap < 512 ? cap : 512)), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
 	else return false;
 	return true;
 }

@@ -312,9 +312,9 @@ void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int
                               int y0, int nrows, const int32_t *count, const uint32_t *cand, int cmax,
                               const uint32_t *rowinfo, const int32_t *meta, const double *cost, int smax,
                               uint32_t *cflag = nullptr, int nlist = -1, Counters *cnt = nullptr);
-void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
-                                const uint32_t *cflag, int cap, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
-                                double *cost, int smax, Counters *cnt);
+bool launch_twoview_rows_refill(hipStream_t st, int width, int oth_width, const srh_params &P, int y0,
+                                const uint32_t *cflag, int cap, const double *wbuf, const double *ref_tvp, const double *oth_tvp,
+                                const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt);
 // RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
 const char *rccl_unique_id_get(void *out128);
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);

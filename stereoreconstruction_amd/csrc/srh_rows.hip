@@ -633,50 +633,53 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 #undef SRH_RC_LAUNCH2
 }
 
-// Certified arithmetic: every cost slot of the flagged pixels (cflag[1 .. 1 + nlist)) once more, in the reference's
-// arithmetic (tv_cost: any validity pattern) -- one 256-lane workgroup per pixel, a lane per slot.
+// Certified arithmetic: every cost slot of the flagged pixels (cflag[1 .. 1 + count)) once more, in the reference's
+// arithmetic (window_exact_cost on the NaN-bordered planes: any validity pattern) -- one 256-lane workgroup per pixel, a
+// lane per slot; launched for the redo's capacity, the count stays on the device (twoview_refill_kernel).
+template <int R>
 __global__ __launch_bounds__(256)
-void twoview_rows_refill_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
-                                const uint32_t *__restrict__ cflag, int cap, const double *__restrict__ wbuf,
-                                const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
+void twoview_rows_refill_kernel(int W, srh_params P, int y0, const uint32_t *__restrict__ cflag, int cap,
+                                const double *__restrict__ wbuf, const double *__restrict__ ref_tvp, const double *__restrict__ oth_tvp,
+                                int OW, const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
                                 double *__restrict__ cost, int smax, Counters *__restrict__ cnt)
 {
-	const ViewDev &L = views[ref];
-	const ViewDev &Rv = views[oth];
-	const int W = L.w;
-	// (grid sized by the capacity of the redo: the count stays on the device, as in twoview_refill_kernel)
 	const uint32_t nflag = cflag[0];
 	if (blockIdx.x == 0 && threadIdx.x == 0 && nflag > (uint32_t)cap) atomicAdd(&cnt->cert_overflow, 1ull);
-	if (blockIdx.x >= nflag) return;
-	const size_t q = cflag[1 + blockIdx.x];
+	unsigned n = 0;
+	for (uint32_t f = blockIdx.x; f < nflag && f < (uint32_t)cap; f += gridDim.x) {      // (a few hundred workgroups share the list)
+	const size_t q = cflag[1 + f];
 	const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
-	const int T = (2*P.window_radius + 1)*(2*P.window_radius + 1);
-	const double *wq = wbuf + wbuf_offset(W, T, trow, x);
+	const WindowAt wa = window_at<R>(wbuf, 0, W, trow, x);
+	const int SPL = padded_stride(W), SPR = padded_stride(OW);
+	const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SPL + (x + SRH_PADL - R);
 	const int tiles_per_row = (W + 31) >> 5;
 	double *crow = cost + ((size_t)trow*tiles_per_row + (x >> 5))*(size_t)smax*32 + (x & 31);
 	const int m = meta[q];
 	const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
-	unsigned n = 0;
 	int base = 0;
 	for (int r = 0; r < nr; ++r) {
 		const uint32_t info = rowinfo[((q >> 6)*RW_NR + r)*64 + (q & 63)];
 		const int xlo = (int)(short)(info & 0xffff), wdt = (int)(info >> 16);
 		for (int k = (int)threadIdx.x; k < wdt; k += 256) {
-			crow[(size_t)(base + k)*32] = tv_cost(L, Rv, wq, SRH_WTILE, P, x, y, xlo + k, ymin + r);
+			const double *rp = oth_tvp + (size_t)(ymin + r + SRH_PADY - R)*SPR + (xlo + k + SRH_PADL - R);
+			crow[(size_t)(base + k)*32] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SPL, SPR, P);
 			++n;
 		}
 		base += (wdt + 7) & ~7;
 	}
+	}
 	block_count_add(&cnt->n_eval_device, n);
 }
 
-void launch_twoview_rows_refill(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0,
-                                const uint32_t *cflag, int cap, const double *wbuf, const uint32_t *rowinfo, const int32_t *meta,
-                                double *cost, int smax, Counters *cnt)
+bool launch_twoview_rows_refill(hipStream_t st, int width, int oth_width, const srh_params &P, int y0,
+                                const uint32_t *cflag, int cap, const double *wbuf, const double *ref_tvp, const double *oth_tvp,
+                                const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt)
 {
-	if (cap <= 0) return;
-	hipLaunchKernelGGL(twoview_rows_refill_kernel, dim3((unsigned)cap), dim3(256), 0, st,
-	                   views, ref, oth, P, y0, cflag, cap, wbuf, rowinfo, meta, cost, smax, cnt);
+	if (cap <= 0) return true;
+#define SRH_RR(RR) case RR: hipLaunchKernelGGL(twoview_rows_refill_kernel<RR>, dim3((unsigned)(cap < 256 ? cap : 256)), dim3(256), 0, st, width, P, y0, cflag, cap, \
+	                                           wbuf, ref_tvp, oth_tvp, oth_width, rowinfo, meta, cost, smax, cnt); return true;
+	switch (P.window_radius) { SRH_RR(1) SRH_RR(2) SRH_RR(3) SRH_RR(4) SRH_RR(5) default: return false; }
+#undef SRH_RR
 }
 
 // ------------------------------------------------------------------ scan with slot look-ups

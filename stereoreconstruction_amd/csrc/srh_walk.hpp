@@ -279,6 +279,65 @@ __device__ __forceinline__ double tv_cost(const ViewDev &L, const ViewDev &Rv, c
 	return (v < P.max_color_diff) ? v : P.max_color_diff;       // std::min(MAX_COLOR_DIFF, v): NaN -> 120
 }
 
+// cost_ncc in the reference's arithmetic for ANY validity pattern (a skipped tap adds +0.0: the same sums, same order as
+// tv_cost, twoviewstereo.cpp:909-977), from a window in either band layout and the NaN-bordered planes (no bound tests,
+// loops unrolled by window row so that a row's 33 loads travel together):
+// tap (row, col) of the window at wq[row*wrow + col*wcol]; lp / rp = top-left tap of the two windows in the padded planes
+// (strides SP / SPR)
+template <int R>
+__device__ __forceinline__ double window_exact_cost(const double *__restrict__ wq, int wrow, int wcol, const double *__restrict__ lp,
+                                                    const double *__restrict__ rp, int SP, int SPR, const srh_params &P)
+{
+	constexpr int WS = 2*R + 1;
+	double meanL = 0, meanR = 0, totalWeight = 0.0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SPR + col]; wt[col] = wq[row*wrow + col*wcol]; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
+			const double pl = wt[col]*gl[col], prr = wt[col]*gr[col];
+			meanL += ok ? pl : 0.0;
+			meanR += ok ? prr : 0.0;
+			totalWeight += ok ? wt[col] : 0.0;
+		}
+	}
+	if (totalWeight < 1e-10) return P.bad_ret;
+	meanL /= totalWeight;
+	meanR /= totalWeight;
+	double sum1 = 0, sum2 = 0, sum3 = 0;
+#pragma unroll 1
+	for (int row = 0; row < WS; ++row) {
+		double gl[WS], gr[WS], wt[WS];
+#pragma unroll
+		for (int col = 0; col < WS; ++col) { gl[col] = lp[(size_t)row*SP + col]; gr[col] = rp[(size_t)row*SPR + col]; wt[col] = wq[row*wrow + col*wcol]; }
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const bool ok = gl[col] == gl[col] && gr[col] == gr[col] && wt[col] > P.weight_cutoff;
+			const double a = wt[col]*gl[col] - meanL, b = wt[col]*gr[col] - meanR;
+			const double ab = a*b, aa = a*a, bb = b*b;
+			sum1 += ok ? ab : 0.0;
+			sum2 += ok ? aa : 0.0;
+			sum3 += ok ? bb : 0.0;
+		}
+	}
+	const double v = 255*(1.0 - fabs(sum1) / sqrt(sum2 * sum3));
+	return (v < P.max_color_diff) ? v : P.max_color_diff;
+}
+
+// where a pixel's window lies in the band buffer: wimg != 0 the strip path's LDS-image layout, else tile-major
+struct WindowAt { const double *wq; int wrow, wcol; };
+template <int R>
+__device__ __forceinline__ WindowAt window_at(const double *wbuf, int wimg, int W, int trow, int x) {
+	constexpr int WS = 2*R + 1;
+	WindowAt a;
+	if (wimg) { a.wq = wbuf + wimg_offset(W, R, trow, x); a.wrow = wimg_row_stride(R); a.wcol = 1; }
+	else      { a.wq = wbuf + wbuf_offset(W, WS*WS, trow, x); a.wrow = WS*SRH_WTILE; a.wcol = SRH_WTILE; }
+	return a;
+}
+
 __device__ __forceinline__ double mvs_tap(const ViewDev &V, int x, int y) {
 	if (x < 0 || y < 0 || x >= V.w || y >= V.h) return __builtin_nan("");
 	return V.gray[(size_t)y*V.w + x];
