@@ -1396,6 +1396,117 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	}
 }
 
+// The exact scan of the FLAGGED pixels, one WAVE per pixel.  twoview_scan_kernel<false, true> gives a flagged pixel one lane:
+// a handful of pixels then cost a whole pixel's serial walk (256 dependent label projections, every cost a dependent
+// load: 0.25 ms on C3, whatever their number).  Here the wave splits the pixel's work: (1) the label projections, one
+// label per lane; (2) the other view's mask bytes of the pixel's column range; (3) ONE lane replays the reference's walk
+// over the projected points and writes the candidate columns in visiting order (twoviewstereo.cpp:999-1054: the cheap,
+// strictly sequential part); (4) all lanes fetch the candidates' costs; (5) one lane runs the running-min rule
+// (twoviewstereo.cpp:293-305) over them.  Same functions, same order, same bits as the one-lane form.
+#define RSW_MAXD 1024                  // labels (else: the one-lane form)
+#define RSW_MAXC 6144                  // candidates of a pixel (more: Counters::cert_overflow, the pass is repeated in mode 0)
+__global__ __launch_bounds__(64)
+void twoview_rescan_wave_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0,
+                                const double *__restrict__ tnum, const double *__restrict__ cost, int cstride,
+                                const PixRange *__restrict__ prange, const uint32_t *__restrict__ cflag, int cap,
+                                Counters *__restrict__ cnt)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w, OW = Rv.w, OH = Rv.h;
+	const int lane = threadIdx.x;
+	__shared__ double sx[RSW_MAXD], sy[RSW_MAXD];
+	__shared__ unsigned short scol[RSW_MAXC];
+	__shared__ double scost[RSW_MAXC];
+	__shared__ unsigned char smask[4096 + 64];
+	__shared__ int s_n;
+	const uint32_t nflag = cflag[0];
+	for (uint32_t f = blockIdx.x; f < nflag && f < (uint32_t)cap; f += gridDim.x) {
+		const uint32_t q = cflag[1 + f];
+		const int x = (int)(q % (uint32_t)W), trow = (int)(q / (uint32_t)W), y = y0 + trow;
+		const PixRange pr = prange[q];
+		const int lo = pr.lo, hi = pr.hi;
+		const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		const Vec3 nrm = normalized(load3(L.cam.pdir));
+		const double nd = dot(nrm, ray.dir);
+		const bool walk = !(fabs(nd) < 1e-10);
+		// (1) label projections
+		if (walk) {
+			const SharedDivisor nd_sd = shared_divisor(nd);
+			for (int d = lane; d < P.num_depth_levels; d += 64) {
+				double x2, y2;
+				const bool ok = pinhole_project_label_sd(ray, nd_sd, tnum[d], Rv.cam, P.image_scale, x2, y2);
+				sx[d] = ok ? x2 : __builtin_nan("");              // (a projection is never NaN when it succeeds: t >= 1e-10, finite cameras;
+				sy[d] = ok ? y2 : 0.0;                             //  a NaN x2 from a degenerate camera is skipped by the one-lane form's isnan test too)
+			}
+		}
+		// (2) mask bytes of row y of the other view over the pixel's column range
+		const int span = hi >= lo ? hi - lo + 1 : 0;
+		for (int k = lane; k < span && k < 4096; k += 64) smask[k] = (y >= 0 && y < OH) ? Rv.mask[(size_t)y*OW + lo + k] : 0;
+		__syncthreads();
+		// (3) the walk: candidate columns in visiting order
+		if (lane == 0) {
+			int n = 0;
+			bool over = false;
+			if (walk) {
+				double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+				for (int d = 0; d < P.num_depth_levels && !over; ++d) {
+					const double x2 = sx[d], y2 = sy[d];
+					if (isnan_d(x2)) continue;                       // pinhole_project_label_sd failed
+					if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
+					const double dx = x2 - x1, dy = y2 - y1;
+					if (!(dx*dx + dy*dy >= 1)) continue;
+					const int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+					const int a = ix0 < ix1 ? ix0 : ix1, b = ix0 < ix1 ? ix1 : ix0;
+					if (iy0 == y && iy1 == y && a >= lo && b <= hi) {
+						for (int tx = a; tx <= b; ++tx) {
+							const int k = tx - lo;
+							const bool white = k < 4096 ? (smask[k] == 1) : (Rv.mask[(size_t)y*OW + tx] == 1);
+							if (white) { if (n < RSW_MAXC) scol[n] = (unsigned short)k; else over = true; ++n; }
+						}
+					} else {
+						LineWalk lw;
+						lw.begin(ix0, iy0, ix1, iy1, OW, OH);
+						while (lw.has_next()) {
+							int tx, ty;
+							lw.current(tx, ty);
+							if (tx >= 0 && ty >= 0 && tx < OW && ty < OH && Rv.mask[(size_t)ty*OW + tx] == 1 &&
+							    ty == y && tx >= lo && tx <= hi) {           // (off-row candidates refute the dense plan: counted by the first scan)
+								if (n < RSW_MAXC) scol[n] = (unsigned short)(tx - lo); else over = true;
+								++n;
+							}
+							lw.next();
+						}
+					}
+					x1 = x2; y1 = y2;
+				}
+			}
+			if (over) { atomicAdd(&cnt->cert_overflow, 1ull); n = RSW_MAXC; }
+			s_n = n;
+		}
+		__syncthreads();
+		const int n = s_n;
+		// (4) the candidates' costs
+		const double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+		for (int k = lane; k < n; k += 64) scost[k] = crow[(size_t)scol[k]*DC_TP];
+		__syncthreads();
+		// (5) running minimum, ratio test, depth of the winner
+		if (lane == 0) {
+			double minCost = __builtin_inf(), secondBest = __builtin_inf();
+			int wcol = -1;
+			for (int k = 0; k < n; ++k) {
+				const double cv = scost[k];
+				if (cv + P.wta_margin < minCost) { secondBest = minCost; minCost = cv; wcol = scol[k]; }   // twoviewstereo.cpp:293-301
+			}
+			double depth = __builtin_nan("");
+			if (wcol >= 0) depth = candidate_depth(L.cam, Rv.cam, P, ray, lo + wcol, y);
+			if (minCost > P.second_best_factor*secondBest) depth = __builtin_inf();
+			L.depth[(size_t)y*W + x] = depth;
+		}
+		__syncthreads();
+	}
+}
+
 // cflag == nullptr: the exact scan.  cflag, nlist < 0: the certified scan (flags into cflag).  cflag, nlist >= 0: the
 // exact scan of the nlist pixels listed in cflag[1..].
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
@@ -1410,6 +1521,9 @@ void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth,
 	else if (nlist < 0)
 		hipLaunchKernelGGL((twoview_scan_kernel<true, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
 		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, 0, cb);
+	else if (nlist > 0 && P.num_depth_levels <= RSW_MAXD && cstride <= 4096)
+		hipLaunchKernelGGL(twoview_rescan_wave_kernel, dim3((unsigned)(nlist < 256 ? nlist : 256)), dim3(64), 0, st,
+		                   views, ref, oth, P, y0, tnum, cost, cstride, prange, cflag, nlist, cnt);
 	else if (nlist > 0)
 		hipLaunchKernelGGL((twoview_scan_kernel<false, true>), dim3((unsigned)((nlist + SC_TW - 1)/SC_TW)), dim3(SC_TW), 0, st,
 		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb);
