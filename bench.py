@@ -130,6 +130,8 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     neigh = capi.mvs_neighbours(cams, p)
     links = sum(len(n) for n in neigh)
     ctx = capi.Context(dev_index)
+    if os.environ.get("SRH_BENCH_EXP_WALK_MODE"):               # timing experiment build only
+        ctx.set_option("exp_walk_mode", int(os.environ["SRH_BENCH_EXP_WALK_MODE"]))
     if args.arith in ("fma", "f32"):
         sys.exit("--arith fma / f32 apply to the dense row-aligned TwoView path (c2, c3, small)")
     ctx.set_option("arith", capi.ARITH_EXACT if args.arith == "exact" else capi.ARITH_CERTIFIED)

@@ -627,6 +627,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
 	if (!strcmp(name, "exp_scan_mode")) { exp_set_scan((int)value); return SRH_OK; }
+	if (!strcmp(name, "exp_walk_mode")) { exp_set_walk((int)value); return SRH_OK; }
 #endif
 	return fail(SRH_E_INVALID, "unknown option '%s'", name);
 }
@@ -1403,6 +1404,8 @@ static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int n
 	// without a refractive interface every ray of the view starts at the camera centre: the per-label
 	// part of pointFromDepth is tabulated once (same operands and operations, see srh_walk.hpp)
 	const bool table = !A.cam.is_refractive;
+	bool neigh_pinhole = true;                                  // (certified label projections: plain pinhole neighbours only)
+	for (int i = 0; i < nneigh; ++i) { const srh_camera &nc = c->views[neigh[i]].cam; if (nc.is_refractive || nc.is_distorted) neigh_pinhole = false; }
 	if (table) {
 		if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
 		Scope s(c, "pinhole_label_table_kernel");
@@ -1449,7 +1452,7 @@ static int mvs_list_launch(srh_context *c, int view, const int32_t *neigh, int n
 			{ Scope s(c, "mvs_walk_kernel");
 			  launch_mvs_walk(c->stream, c->d_views, view, neigh, nneigh, W, *p, by, nr, table ? c->tnum : nullptr, c->lcand, cmax, c->lcount,
 			                  c->d_cnt, c->d_span, staged ? c->mvs_wdesc : nullptr, staged ? c->mvs_nwin : nullptr, act, nact,
-			                  peaks_dev != nullptr); }
+			                  peaks_dev != nullptr, neigh_pinhole && c->arith == 3); }
 			double *const upk = peaks_dev ? c->cost + units*2 : nullptr;
 			if (staged) {
 				Scope s(c, "mvs_staged_cost_kernel");

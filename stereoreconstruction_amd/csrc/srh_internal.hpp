@@ -232,6 +232,7 @@ void geodesic_phases_fetch(unsigned long long out[5]);
 #ifdef SRH_EXPERIMENT
 void exp_set(int repeat, int lds_pad);
 void exp_set_scan(int mode);
+void exp_set_walk(int mode);
 #endif
 
 // Fused row-aligned TwoView kernel (geometry + cost + WTA per 16-pixel tile), srh_fused.hip.
@@ -259,7 +260,8 @@ void launch_twoview_list_scan(hipStream_t st, const ViewDev *views, int ref, int
 void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave);
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
-                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact, bool peaks);
+                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact, bool peaks,
+                     bool fast_pinhole = false);   // every neighbour a plain pinhole camera: certified label projections (with tnum)
 // cert: the certified fused form (no top-K request): fused sweeps, the unit's winner certified against the bound, its
 // cost recomputed in the reference's arithmetic; ambiguous units redone exactly
 void launch_mvs_staged_cost(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,

@@ -692,7 +692,17 @@ __global__ void mvs_combine_kernel(const ViewDev *__restrict__ views, int ref, i
 #define MQ_FLUSH 24
 #define SRH_MVS_WAVES 2
 
-__global__ __launch_bounds__(MQ_T)
+#ifdef SRH_EXPERIMENT
+// timing experiments only (make exp): 1 = label projections only (no raster walk), 2 = raster walk but no flush work
+__device__ int g_exp_walk_mode = 0;
+void exp_set_walk(int mode) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_walk_mode), &mode, sizeof(int)); }
+#endif
+
+// FASTP: every neighbour of the launch is a plain pinhole camera and the reference view has the label table: the
+// certified label projections of srh_walk.hpp (the general projection path is then not even compiled into the kernel:
+// its live ranges cost a wave per SIMD)
+template <bool FASTP>
+__global__ __launch_bounds__(MQ_T, 4)
 void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, srh_params P,
                      int y0, int nrows, const double *__restrict__ tnum, uint32_t *__restrict__ cand, int cmax,
                      int32_t *__restrict__ count,
@@ -785,11 +795,50 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		const SharedDivisor ndd = shared_divisor(nd);                 // tnum[d] / nd with the divisor's half of the division done once
 		const bool b_pinhole = !B.cam.is_refractive && !B.cam.is_distorted;
 		double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+		// certified label projections (srh_walk.hpp): label table + plain pinhole neighbour
+		const bool fastp = FASTP;
+		FastProj fp = {};
+		double e1 = 0.0;                                            // bound of the kept point (0: it is the reference's own value)
+		int d1 = 0;                                                 // its label
+		if (fastp && active) {
+			const double ta = fabs(tnum[0]), tb = fabs(tnum[P.num_depth_levels - 1]);
+			fp = fast_proj_setup(ray, B.cam, ((ta > tb ? ta : tb)/fabs(nd))*1.000001);
+		}
 		for (int d = 0; d < P.num_depth_levels; ++d) {
 			bool seg = false;
 			LineWalk lw;
 			lw.x = 1; lw.xend = 0; lw.y = 0; lw.error = 0; lw.ystep = 0; lw.deltax = 0; lw.deltay = 0; lw.steep = false;
-			if (active) {
+			if (FASTP) { if (active) {
+				const double t = div_by(tnum[d], ndd);
+				if (!(fabs(nd) < 1e-10) && !(t < 1e-10)) {
+					double x2, y2, e;
+					fast_project(fp, t, P.image_scale, x2, y2, e);
+					if (!(trunc_certain(x2, e) && trunc_certain(y2, e))) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, t); x2 = p.x; y2 = p.y; e = 0.0; }
+					if (isnan_d(x1)) { x1 = x2; y1 = y2; e1 = e; d1 = d; }
+					else {
+						double dx = x2 - x1, dy = y2 - y1;
+						double dd = dx*dx + dy*dy;
+						const double se = e + e1;
+						// |dd_reference - dd| <= 2(|dx| + |dy|)se + 2se^2 + roundings
+						const double m = __builtin_fma(dd, 0x1p-48, 2.02*((fabs(dx) + fabs(dy))*se + se*se));
+						if (!(fabs(dd - 1.0) > m)) {
+							// the one-pixel test is not decided by the fast values: both points by the reference's operations
+							if (e != 0.0) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, t); x2 = p.x; y2 = p.y; e = 0.0; }
+							if (e1 != 0.0) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, div_by(tnum[d1], ndd)); x1 = p.x; y1 = p.y; e1 = 0.0; }
+							dx = x2 - x1; dy = y2 - y1;
+							dd = dx*dx + dy*dy;
+						}
+						if (dd >= 1) {
+							int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+							if (clip_line(ix0, iy0, ix1, iy1, OW, OH)) {  // 6-arg LineIterator, multiviewstereo.cpp:783
+								lw.begin(ix0, iy0, ix1, iy1, 0, 0);
+								seg = true;
+							}
+							x1 = x2; y1 = y2; e1 = e; d1 = d;
+						}
+					}
+				}
+			} } else if (active) {
 				Vec3 point = camC;
 				bool hit;
 				if (tnum) {
@@ -818,6 +867,10 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 								lw.begin(ix0, iy0, ix1, iy1, 0, 0);
 								seg = true;
 							}
+#ifdef SRH_EXPERIMENT
+							if (g_exp_walk_mode == 1) { seg = false; nreal += ix0 + iy1; }
+							if (g_exp_walk_mode == 3) { seg = false; nreal += trunc_sat(x1) + trunc_sat(y2); }
+#endif
 							x1 = x2; y1 = y2;
 						}
 					}
@@ -831,6 +884,9 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 					lw.next();
 				}
 				const bool more = seg && lw.has_next();
+#ifdef SRH_EXPERIMENT
+				if (g_exp_walk_mode == 2) { if (__any(more || qn >= MQ_FLUSH)) { nreal += qn; qn = 0; } if (!__any(more)) break; continue; }
+#endif
 				if (__any(more || qn >= MQ_FLUSH)) flush();
 				if (!__any(more)) break;
 			}
@@ -1370,13 +1426,19 @@ void mvs_staging_shape(int *maxw, size_t *desc_words_per_wave) { *maxw = MS_MAXW
 // wdesc / nwin: window descriptors (MS_MAXW uint4 per wave) and window counts of the launch's waves, or null (no staging)
 void launch_mvs_walk(hipStream_t st, const ViewDev *views, int ref, const int32_t *neigh, int nneigh, int width,
                      const srh_params &P, int y0, int nrows, const double *tnum, uint32_t *cand, int cmax, int32_t *count,
-                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact, bool peaks)
+                     Counters *cnt, int *max_count, uint32_t *wdesc, int32_t *nwin, const uint32_t *act, int nact, bool peaks,
+                     bool fast_pinhole)
 {
 	if (nact <= 0) return;
 	const dim3 grid((unsigned)((nact + MQ_T - 1)/MQ_T), (unsigned)nneigh);
-	hipLaunchKernelGGL(mvs_walk_kernel, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
-	                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW,
-	                   peaks ? MS_CAP_PEAKS : MS_CAP, act, nact);
+	if (fast_pinhole && tnum)
+		hipLaunchKernelGGL(mvs_walk_kernel<true>, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
+		                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW,
+		                   peaks ? MS_CAP_PEAKS : MS_CAP, act, nact);
+	else
+		hipLaunchKernelGGL(mvs_walk_kernel<false>, grid, dim3(MQ_T), 0, st, views, ref, make_neigh_list(neigh, nneigh),
+		                   P, y0, nrows, tnum, cand, cmax, count, cnt, max_count, (uint4 *)wdesc, nwin, MS_MAXW,
+		                   peaks ? MS_CAP_PEAKS : MS_CAP, act, nact);
 }
 
 // the three steps of the list path's second stage; nwin (or null): the waves with nwin >= 0 are the staged kernel's

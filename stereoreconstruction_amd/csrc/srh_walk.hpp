@@ -167,6 +167,66 @@ __device__ __forceinline__ bool pinhole_project_label_sd(const Ray &ray, const S
 	return true;
 }
 
+// ---- certified label projections (pinhole other camera) -------------------------------------------
+// The reference projects label d of a pixel's ray as  point = src + t*dir;  pl = R*point + tvec;  pk = K*pl;
+// (x, y) = (pk.x/pk.z, pk.y/pk.z)*scale  -- about 60 FP64 instructions per label -- and then only DECIDES with the
+// result: is the step from the last kept point at least one pixel long (dx^2 + dy^2 >= 1), and which pixel do the
+// coordinates truncate to.  k(t) = A + t*B with A = K*(R*src + tvec), B = K*R*dir (per pixel, once) gives the same point
+// in 3 fused multiply-adds and a reciprocal.  Both evaluations are within gamma_10*Km of the real-number pk, Km_i =
+// sum_j |K_ij| (sum_k |R_jk| (|src_k| + |t| |dir_k|) + |tvec_j|), hence within 2*gamma_10*Km of each other; divided by
+// pk.z that is a bound (ex, ey) on the coordinates.  A decision that (ex, ey) cannot change -- a coordinate further
+// than its bound from every integer, a squared step further from 1 than its propagated bound -- is the reference's; any
+// other label is projected once more by the reference's own operations (exact_label_point), so the candidate lists
+// are the reference's lists.
+struct FastProj { Vec3 A, B; double ek, ekz; };              // ek: the larger of the x and y bounds (one register pair less)
+__device__ __forceinline__ FastProj fast_proj_setup(const Ray &ray, const srh_camera &oth, double tmax) {
+	FastProj f;
+	f.A = matvec(oth.K, matvec(oth.R, ray.src) + load3(oth.t));
+	f.B = matvec(oth.K, matvec(oth.R, ray.dir));
+	const Vec3 pm = v3(fabs(ray.src.x) + tmax*fabs(ray.dir.x), fabs(ray.src.y) + tmax*fabs(ray.dir.y), fabs(ray.src.z) + tmax*fabs(ray.dir.z));
+	const double *R = oth.R, *K = oth.K;
+	const Vec3 lm = v3((fabs(R[0])*pm.x + fabs(R[1])*pm.y) + fabs(R[2])*pm.z + fabs(oth.t[0]),
+	                   (fabs(R[3])*pm.x + fabs(R[4])*pm.y) + fabs(R[5])*pm.z + fabs(oth.t[1]),
+	                   (fabs(R[6])*pm.x + fabs(R[7])*pm.y) + fabs(R[8])*pm.z + fabs(oth.t[2]));
+	const double g = 2.02*(10*0x1p-53)/(1.0 - 10*0x1p-53);      // 2*gamma_10, + 1 % for the roundings of these sums
+	const double ekx = g*((fabs(K[0])*lm.x + fabs(K[1])*lm.y) + fabs(K[2])*lm.z);
+	const double eky = g*((fabs(K[3])*lm.x + fabs(K[4])*lm.y) + fabs(K[5])*lm.z);
+	f.ek = ekx > eky ? ekx : eky;
+	f.ekz = g*((fabs(K[6])*lm.x + fabs(K[7])*lm.y) + fabs(K[8])*lm.z);
+	return f;
+}
+// the label's image point (scaled) with its bound; a degenerate pk.z gives NaN / huge bounds, which no decision accepts
+// e: bound on BOTH coordinates
+__device__ __forceinline__ void fast_project(const FastProj &f, double t, double scale, double &x2, double &y2, double &e) {
+	const double kx = __builtin_fma(t, f.B.x, f.A.x), ky = __builtin_fma(t, f.B.y, f.A.y), kz = __builtin_fma(t, f.B.z, f.A.z);
+	double r = __builtin_amdgcn_rcp(kz);
+	r = __builtin_fma(r, __builtin_fma(-kz, r, 1.0), r);
+	r = __builtin_fma(r, __builtin_fma(-kz, r, 1.0), r);           // 1/kz to 2 ulp
+	const double rs = r*scale;
+	x2 = kx*rs; y2 = ky*rs;
+	// |pk.x/pk.z - kx/kz| <= (ekx + |x| ekz)/(|kz| - ekz): with ekz <= |kz|/1024 (else the bound is made useless) the
+	// denominator is >= 0.999 |kz|; + 8u|x| for the quotient, reciprocal and product roundings of either evaluation
+	const double ar = fabs(rs)*(f.ekz*fabs(r) <= 0x1p-10 ? 1.002 : __builtin_inf());
+	const double am = fmax(fabs(kx), fabs(ky))*fabs(r);            // the larger |coordinate| / scale
+	e = __builtin_fma(am*scale, 0x1p-49, (f.ek + am*f.ekz)*ar);
+}
+// the reference's own operations for one label (pinhole_project_label_sd without the t test, which the caller made)
+// (returned by value: reference parameters would pin the caller's coordinates to scratch memory)
+__device__ __noinline__ double2 exact_label_point(const srh_camera &refcam, const srh_camera &oth, int px, int py, double scale, double t)
+{
+	const Ray ray = cam_unproject(refcam, (px + 0.5) / scale, (py + 0.5) / scale);
+	const Vec3 point = ray.src + t*ray.dir;
+	const Vec3 pl = matvec(oth.R, point) + load3(oth.t);
+	const Vec3 pk = matvec(oth.K, pl);
+	const SharedDivisor z = shared_divisor(pk.z);
+	double2 r;
+	r.x = div_by(pk.x, z)*scale;
+	r.y = div_by(pk.y, z)*scale;
+	return r;
+}
+// is truncation of v certain under the bound e?  (every integer counts as a boundary; far outside any image: no)
+__device__ __forceinline__ bool trunc_certain(double v, double e) { return fabs(v) < 0x1p28 && fabs(v - __builtin_rint(v)) > e; }
+
 template <class Visitor>
 __device__ __forceinline__ void walk_curve_pinhole(const Ray &ray, const srh_camera &refcam, const ViewDev &oth,
                                                    const srh_params &P, const double *__restrict__ tnum, Visitor &vis)
