@@ -325,7 +325,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
     if args.arith in ("fma", "f32") and workload in ("c1", "c4", "c5"):
         sys.exit("--arith fma / f32 apply to the dense row-aligned TwoView path (c2, c3, small)")
     arith_code = {"certified": capi.ARITH_CERTIFIED, "exact": capi.ARITH_EXACT, "fma": capi.ARITH_FMA, "f32": capi.ARITH_F32}[args.arith]
-    if args.arith != "exact" and workload not in ("c1", "c5"):
+    if args.arith != "exact" and workload not in ("c1", "c5") and not args.no_exact_check:
         # untimed: the same pass in the reference's arithmetic, to count the depths the chosen arithmetic changes
         # (certified: must be 0 -- it is the parity mode; fma / f32: the measured winner-mismatch rate)
         ctx.set_option("arith", capi.ARITH_EXACT)
@@ -579,6 +579,9 @@ def main():
     ap.add_argument("--shard", default="pairs", choices=["pairs", "rows"],
                     help="N > 1, TwoView workloads: 'pairs' (default) = one pair per GPU, weak scaling; 'rows' = ONE pair cut "
                          "into N row bands, bands gathered on rank 0, cross-check there: strong scaling")
+    ap.add_argument("--no-exact-check", action="store_true",
+                    help="skip the untimed pass in the reference's arithmetic that counts the depths the chosen arithmetic changes "
+                         "(profiling passes: only the kernels of the timed steps are to be traced)")
     ap.add_argument("--no-configs", action="store_true",
                     help="headline line only: skip the short driver-timed legs of the other BASELINE configurations")
     args = ap.parse_args()

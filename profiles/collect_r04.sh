@@ -21,14 +21,14 @@ echo "bench lines done"
 # per-kernel time (C4: one view in flight, SRH_MVS_ASYNC=0: bench.py takes its kernels_ms from such a pass as well)
 export SRH_MVS_ASYNC=0
 for w in c3 c4 c5 c2; do
-	rocprofv3 --kernel-trace --stats -d "$OUT/stats_$w" --output-format csv -- $B --workload $w --steps 3 --warmup 1 --cpu-rows 0 --no-configs > "$OUT/stats_$w.log" 2>&1
+	rocprofv3 --kernel-trace --stats -d "$OUT/stats_$w" --output-format csv -- $B --workload $w --steps 3 --warmup 1 --cpu-rows 0 --no-configs --no-exact-check > "$OUT/stats_$w.log" 2>&1
 	cp "$(find "$OUT/stats_$w" -name '*kernel_stats.csv' | head -1)" "$OUT/${w}_kernel_stats.csv" 2>/dev/null
 	rm -rf "$OUT/stats_$w"
 done
 echo "kernel stats done"
 pmc() { # tag workload counters...
 	local tag=$1 w=$2; shift 2
-	rocprofv3 --pmc "$@" -d "$OUT/pmc_$tag" --output-format csv -- $B --workload $w --steps 1 --warmup 0 --cpu-rows 0 --no-configs > "$OUT/pmc_$tag.log" 2>&1
+	rocprofv3 --pmc "$@" -d "$OUT/pmc_$tag" --output-format csv -- $B --workload $w --steps 1 --warmup 0 --cpu-rows 0 --no-configs --no-exact-check > "$OUT/pmc_$tag.log" 2>&1
 	cp "$(find "$OUT/pmc_$tag" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$tag.csv" 2>/dev/null
 	grep -o '"build_id": "[0-9a-f]*"' "$OUT/pmc_$tag.log" | head -1 > "$OUT/pmc_$tag.build"
 	rm -rf "$OUT/pmc_$tag"
