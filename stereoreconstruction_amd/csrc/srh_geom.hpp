@@ -262,13 +262,34 @@ SRH_HD bool clip_line(int &x0, int &y0, int &x1, int &y1, int w, int h) {
 	for (int guard = 0; guard < 16; ++guard) {
 		if (!(oc0 | oc1)) return true;
 		if (oc0 & oc1) return false;
-		long long x = 0, y = 0;
 		const int oc = oc0 ? oc0 : oc1;
+#ifdef __HIP_DEVICE_COMPILE__
+		// One truncating division p0 + ((p1 - p0)*(lim - q0))/(q1 - q0) for the four cases (the GPU has no 64-bit integer
+		// divide: four inlined software divisions were 600 instructions per round for the whole wave).  The factors are
+		// 32-bit; when their product is below 2^52 it is exact in a double, the FP64 quotient truncates to the integer
+		// quotient or one past it in magnitude, and the exact remainder (one fma) tells which.  Larger products (coordinates
+		// beyond +-2^21, saturated projections) take the 64-bit division.
+		const bool horiz = (oc & 12) != 0;                           // cut by y = h / y = 0: the result is an x
+		const int p0 = horiz ? x0 : y0, p1 = horiz ? x1 : y1, q0 = horiz ? y0 : x0, q1 = horiz ? y1 : x1;
+		const int lim = (oc & 8) ? h : (oc & 4) ? 0 : (oc & 2) ? w : 0;
+		const double fa = (double)p1 - (double)p0, fb = (double)lim - (double)q0, fd = (double)q1 - (double)q0;
+		const double num = fa*fb;
+		long long cut;
+		if (__builtin_fabs(num) < 0x1p52) {
+			int q = (int)(num/fd);                                    // |quotient| <= |p1 - p0| < 2^31: the cut lies on the segment
+			const double r = __builtin_fma(-(double)q, fd, num);        // exact
+			if (r != 0.0 && ((r < 0.0) != (num < 0.0))) q -= ((num < 0.0) != (fd < 0.0)) ? -1 : 1;
+			cut = (long long)p0 + q;
+		} else cut = (long long)p0 + (((long long)p1 - p0)*((long long)lim - q0))/((long long)q1 - q0);
+		const long long x = horiz ? cut : (long long)lim, y = horiz ? (long long)lim : cut;
+#else
+		long long x = 0, y = 0;
 		const long long X0 = x0, Y0 = y0, X1 = x1, Y1 = y1;
 		if (oc & 8)      { x = X0 + ((X1 - X0)*(h - Y0))/(Y1 - Y0); y = h; }
 		else if (oc & 4) { x = X0 + ((X1 - X0)*(0 - Y0))/(Y1 - Y0); y = 0; }
 		else if (oc & 2) { y = Y0 + ((Y1 - Y0)*(w - X0))/(X1 - X0); x = w; }
 		else if (oc & 1) { y = Y0 + ((Y1 - Y0)*(0 - X0))/(X1 - X0); x = 0; }
+#endif
 		if (oc == oc0) { x0 = (int)x; y0 = (int)y; oc0 = out_code(x0, y0, w, h); }
 		else           { x1 = (int)x; y1 = (int)y; oc1 = out_code(x1, y1, w, h); }
 	}

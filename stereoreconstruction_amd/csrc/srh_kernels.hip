@@ -1135,6 +1135,9 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 #define MS_CAP_PEAKS 2240             // the same for the top-K request (room for its queue)
 #define MS_PQ 2                       // top-K request: pairs a lane may have waiting
 #define MS_MAXW 96                    // windows per wave
+#ifndef MS_CPY
+#define MS_CPY 4                      // box copy: loads in flight per lane (8 was measured: registers spill, the slots slow down by a third)
+#endif
 #ifndef MS_AHEAD
 #define MS_AHEAD 4                    // list entries in flight per lane
 #endif
@@ -1265,22 +1268,23 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 		const int X0 = (int)(d.z & 0xffffu), Y0 = (int)(d.z >> 16), X1 = (int)(d.w & 0xffffu), Y1 = (int)(d.w >> 16);
 		const int cols = X1 - X0 + 1 + 2*R, rows = Y1 - Y0 + 1 + 2*R, stride = cols | 1;
 		// ---- copy the box (with its margin of R) into the wave's LDS: element (r, c) at r*stride + c; four loads per
-		// lane in flight (the copy is a chain of memory round trips otherwise)
+		// lane in flight (the copy is a chain of memory round trips otherwise).  (Pairs of columns per lane -- 16-byte loads
+		// at 8-byte alignment, ds_write2_b64 -- were measured: the copies took 45 % longer.)
 		{
 			const int total = rows*stride;
 			const int qs = 64 / stride, rs = 64 - qs*stride;
 			int r = lane / stride, c = lane - r*stride;
 			gptr src = (gptr)(B.gray + (size_t)(Y0 - R)*OW + (X0 - R));
-			for (int idx = lane; idx < total; idx += 4*64) {
-				double v[4];
+			for (int idx = lane; idx < total; idx += MS_CPY*64) {
+				double v[MS_CPY];
 #pragma unroll
-				for (int j = 0; j < 4; ++j) {
+				for (int j = 0; j < MS_CPY; ++j) {
 					v[j] = (idx + 64*j < total && c < cols) ? src[(size_t)r*OW + c] : 0.0;
 					r += qs; c += rs;
 					if (c >= stride) { c -= stride; ++r; }
 				}
 #pragma unroll
-				for (int j = 0; j < 4; ++j)
+				for (int j = 0; j < MS_CPY; ++j)
 					if (idx + 64*j < total) sb[idx + 64*j] = v[j];
 			}
 		}
@@ -1402,8 +1406,24 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 			if (be != 0xffffffffu) {
 				const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 				bestDepth = candidate_depth(A.cam, B.cam, P, ray, (int)(be & 0xffffu), (int)(be >> 16));
-				// certified: the winner is the reference's; the score handed to the combine step is the reference's too
-				if (CERT) bestCost = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, (int)(be & 0xffffu), (int)(be >> 16));
+				// certified: the winner is the reference's; the score handed to the combine step is the reference's too --
+				// the exact kernel's own sweeps once more for this one candidate (a staged wave's windows lie inside the other
+				// image, this unit's taps are all usable: the fast form applies), its 25 taps straight from memory
+				if (CERT) {
+					gptr bp = (gptr)(B.gray + (size_t)((int)(be >> 16) - R)*OW + ((int)(be & 0xffffu) - R));
+					double gx[T], mRx = 0;
+#pragma unroll
+					for (int row = 0; row < WS; ++row)
+#pragma unroll
+						for (int col = 0; col < WS; ++col) gx[row*WS + col] = bp[(size_t)row*OW + col];
+#pragma unroll
+					for (int t = 0; t < T; ++t) { gx[t] = w[t]*gx[t]; mRx += gx[t]; }
+					mRx = div_by(mRx, twd);
+					double x1 = 0, x3 = 0;
+#pragma unroll
+					for (int t = 0; t < T; ++t) { const double b = gx[t] - mRx; x1 += a[t]*b; x3 += b*b; }
+					bestCost = (s2 * x3 < 1e-10) ? 0.0 : x1 / sqrt(s2 * x3);
+				}
 			}
 			bout[0] = bestCost; bout[1] = bestDepth;
 		}
