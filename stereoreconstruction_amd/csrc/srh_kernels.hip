@@ -1141,9 +1141,6 @@ void mvs_list_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighList 
 #ifndef MS_AHEAD
 #define MS_AHEAD 4                    // list entries in flight per lane
 #endif
-#ifndef MS_NC
-#define MS_NC 1                       // slots evaluated side by side (2 was measured: slower)
-#endif
 #ifndef MS_CA
 #define MS_CA 2                       // certified form: partial sums per sum (independent dependency chains)
 #endif
@@ -1292,104 +1289,117 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 #ifdef SRH_PROFILE_PHASES
 		ph_slots += (unsigned long long)(ke - kb);
 #endif
-		// MS_NC slots per trip.  A candidate's sums are single dependent chains (a dependent FP64 instruction issues 12
-		// cycles after its producer, profiles/microbench/fp64_chain_latency.hip); two slots side by side would give two
-		// independent chains, but their 100 product registers spill -- measured slower than one slot per trip with the
-		// SIMD's second wave filling the gaps.  MS_NC = 1 is what ships.
-		for (int k = kb; k < ke; k += MS_NC) {
-			uint32_t e[MS_NC];
-			const double *gp[MS_NC];
+		// One slot per trip (two side by side were measured: their 100 product registers spill).  The slots are software-
+		// pipelined over the LDS: the second sweep consumes g_t for the last time and puts the NEXT slot's tap in its place,
+		// so that the first sweep of the next trip -- a dependent chain that used to start behind 15 LDS reads with eight
+		// waves of the compute unit queueing at the LDS -- finds its operands in registers.  (The first slot of a window is
+		// read on the spot: its box has only just been copied.)
+		auto pop = [&](int slot) -> uint32_t {                         // list entry of `slot`: the ring holds the slots in order
+			const uint32_t e = ering[0];
 #pragma unroll
-			for (int u = 0; u < MS_NC; ++u) {
-				if (k + u < ke) {                                        // (uniform) -- the ring holds the slots in order
-					e[u] = ering[0];
-#pragma unroll
-					for (int j = 0; j + 1 < MS_AHEAD; ++j) ering[j] = ering[j + 1];
-					ering[MS_AHEAD - 1] = k + u + MS_AHEAD < nslots && k + u + MS_AHEAD < n ? cl[(size_t)(k + u + MS_AHEAD)*64] : MQ_PAD;
-				} else e[u] = MQ_PAD;
-				const int off = e[u] != MQ_PAD ? ((int)(e[u] >> 16) - Y0)*stride + ((int)(e[u] & 0xffffu) - X0) : 0;
-				gp[u] = sb + off;
-			}
-			// p_t = weight*gray of the other view (multiviewstereo.cpp:150-151, 171); meanR is their sum / totalWeight
-			double g[MS_NC][T], mR[MS_NC], s1[MS_NC], s3[MS_NC];
-			double mRx[MS_NC][MS_CA > 1 ? MS_CA - 1 : 1], s3x[MS_NC][MS_CA > 1 ? MS_CA - 1 : 1];   // certified: the other partial sums (mRx: of meanR, then of sum1)
-#pragma unroll
-			for (int u = 0; u < MS_NC; ++u) { mR[u] = 0; for (int k = 0; k < MS_CA - 1; ++k) mRx[u][k] = 0; }
+			for (int j = 0; j + 1 < MS_AHEAD; ++j) ering[j] = ering[j + 1];
+			ering[MS_AHEAD - 1] = slot + MS_AHEAD < nslots && slot + MS_AHEAD < n ? cl[(size_t)(slot + MS_AHEAD)*64] : MQ_PAD;
+			return e;
+		};
+		auto box_at = [&](uint32_t e) -> const double * {
+			return sb + (e != MQ_PAD ? ((int)(e >> 16) - Y0)*stride + ((int)(e & 0xffffu) - X0) : 0);
+		};
+		double g[T];
+		uint32_t e = MQ_PAD;
+		if (kb < ke) {
+			e = pop(kb);
+			const double *gp = box_at(e);
 #pragma unroll
 			for (int row = 0; row < WS; ++row)
 #pragma unroll
-				for (int col = 0; col < WS; ++col)
+				for (int col = 0; col < WS; ++col) g[row*WS + col] = gp[row*stride + col];
+		}
+		for (int k = kb; k < ke; ++k) {
+			const uint32_t ecur = e;
+			e = k + 1 < ke ? pop(k + 1) : MQ_PAD;                        // (uniform)
+			const double *gn = box_at(e);                                // (a pad, or nothing to come: any address of the box)
+			// p_t = weight*gray of the other view (multiviewstereo.cpp:150-151, 171); meanR is their sum / totalWeight
+			double mR = 0, s1 = 0, s3 = 0;
+			double mRx[MS_CA > 1 ? MS_CA - 1 : 1], s3x[MS_CA > 1 ? MS_CA - 1 : 1];   // certified: the other partial sums (mRx: of meanR, then of sum1)
 #pragma unroll
-					for (int u = 0; u < MS_NC; ++u) {
-						const int t = row*WS + col;
-						if (CERT) {
-							// (g keeps the gray value; MS_CA partial sums: the exact kernel's sums are single dependent chains, one
-							// instruction per 12 cycles and wave -- the bound holds for any order of summation)
-							g[u][t] = gp[u][row*stride + col];
-							if (t % MS_CA == 0) mR[u] = __builtin_fma(w[t], g[u][t], mR[u]); else mRx[u][t % MS_CA - 1] = __builtin_fma(w[t], g[u][t], mRx[u][t % MS_CA - 1]);
-						} else { g[u][t] = w[t]*gp[u][row*stride + col]; mR[u] += g[u][t]; }
-					}
+			for (int k = 0; k < MS_CA - 1; ++k) mRx[k] = 0;
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
+				if (CERT) {
+					// (g keeps the gray value; MS_CA partial sums: the exact kernel's sums are single dependent chains, one
+					// instruction per 12 cycles and wave -- the bound holds for any order of summation)
+					if (t % MS_CA == 0) mR = __builtin_fma(w[t], g[t], mR); else mRx[t % MS_CA - 1] = __builtin_fma(w[t], g[t], mRx[t % MS_CA - 1]);
+				} else { g[t] = w[t]*g[t]; mR += g[t]; }
+			}
 			if (CERT) {
 #pragma unroll
-				for (int u = 0; u < MS_NC; ++u)
-#pragma unroll
-					for (int k = 0; k < MS_CA - 1; ++k) { mR[u] += mRx[u][k]; mRx[u][k] = 0; s3x[u][k] = 0; }
+				for (int k = 0; k < MS_CA - 1; ++k) { mR += mRx[k]; mRx[k] = 0; s3x[k] = 0; }
 			}
+			mR = div_by(mR, twd);                                        // mR / tw, the same bits (srh_walk.hpp)
 #pragma unroll
-			for (int u = 0; u < MS_NC; ++u) { mR[u] = div_by(mR[u], twd); s1[u] = 0; s3[u] = 0; }   // mR / tw, the same bits (srh_walk.hpp)
+			for (int row = 0; row < WS; ++row) {
+				if (CERT) {
+					// (the row's b_t first, then the sums.  Measured without effect, like 3 or 4 partial sums per sum: a fused
+					// multiply-add with three register operands issues at 80 % of the FP64 rate at two waves per SIMD,
+					// profiles/microbench/fp64_rate_mi355x.txt, and the slot loop runs at three quarters of that)
+					double b[WS];
 #pragma unroll
-			for (int t = 0; t < T; ++t)
+					for (int col = 0; col < WS; ++col) b[col] = __builtin_fma(w[row*WS + col], g[row*WS + col], -mR);
 #pragma unroll
-				for (int u = 0; u < MS_NC; ++u) {
-					if (CERT) {
-						const double b = __builtin_fma(w[t], g[u][t], -mR[u]);
-						if (t % MS_CA == 0) { s1[u] = __builtin_fma(a[t], b, s1[u]); s3[u] = __builtin_fma(b, b, s3[u]); }
-						else { mRx[u][t % MS_CA - 1] = __builtin_fma(a[t], b, mRx[u][t % MS_CA - 1]); s3x[u][t % MS_CA - 1] = __builtin_fma(b, b, s3x[u][t % MS_CA - 1]); }
-					} else {
-						const double b = g[u][t] - mR[u];
-						s1[u] += a[t]*b;
-						s3[u] += b*b;
+					for (int col = 0; col < WS; ++col) {
+						const int t = row*WS + col;
+						if (t % MS_CA == 0) { s1 = __builtin_fma(a[t], b[col], s1); s3 = __builtin_fma(b[col], b[col], s3); }
+						else { mRx[t % MS_CA - 1] = __builtin_fma(a[t], b[col], mRx[t % MS_CA - 1]); s3x[t % MS_CA - 1] = __builtin_fma(b[col], b[col], s3x[t % MS_CA - 1]); }
+					}
+				} else {
+#pragma unroll
+					for (int col = 0; col < WS; ++col) {
+						const int t = row*WS + col;
+						const double b = g[t] - mR;
+						s1 += a[t]*b;
+						s3 += b*b;
 					}
 				}
+#pragma unroll
+				for (int col = 0; col < WS; ++col) g[row*WS + col] = gn[row*stride + col];   // the next slot's window row
+				__builtin_amdgcn_sched_barrier(0);                         // (in this order: a row's registers are free before they are refilled)
+			}
 			if (CERT) {
 #pragma unroll
-				for (int u = 0; u < MS_NC; ++u)
-#pragma unroll
-					for (int k = 0; k < MS_CA - 1; ++k) { s1[u] += mRx[u][k]; s3[u] += s3x[u][k]; }
+				for (int k = 0; k < MS_CA - 1; ++k) { s1 += mRx[k]; s3 += s3x[k]; }
 			}
-#pragma unroll
-			for (int u = 0; u < MS_NC; ++u) {
+			{
 				// A score has an effect only when it is > threshold and >= the best so far (>= 0), hence >= bound.  With
 				// sum1 >= 0:  sum1^2 < bound^2 * den * (1 - 1e-6)  puts the exact quotient below bound*(1 - 5e-7), out of reach
 				// of the roundings of the square root and the division (and of the three products here).  A negative sum1
 				// gives a negative score, without effect when the threshold is >= 0.  When no lane of the wave can be
 				// affected, the square root and the division are skipped.
-				const double den = s2 * s3[u];
+				const double den = s2 * s3;
 				const double bound = bestCost > thr0 ? bestCost : thr0;
 				bool hopeless;
-				if (e[u] == MQ_PAD) hopeless = true;
-				else if (CERT && !(s3[u] >= sig3)) { hopeless = false; amb = true; }   // a candidate the bound does not cover: the unit is redone
+				if (ecur == MQ_PAD) hopeless = true;
+				else if (CERT && !(s3 >= sig3)) { hopeless = false; amb = true; }   // a candidate the bound does not cover: the unit is redone
 				else if (!(den >= 1e-10)) hopeless = P.peak_threshold >= 0.0;        // score 0 (or NaN)
-				else if (s1[u] < 0.0) hopeless = P.peak_threshold >= 0.0;
+				else if (s1 < 0.0) hopeless = P.peak_threshold >= 0.0;
 				// (certified: the fused score is within e0 of the reference's; 5e-7*bound covers e0 once bound >= 1e-3)
-				else hopeless = (!CERT || bound >= 1e-3) && s1[u]*s1[u] < bound*bound*den*0.999999;
+				else hopeless = (!CERT || bound >= 1e-3) && s1*s1 < bound*bound*den*0.999999;
 				if (__all(hopeless)) continue;
-				const double c = (den < 1e-10) ? 0.0 : s1[u] / sqrt(den);
+				const double c = (den < 1e-10) ? 0.0 : s1 / sqrt(den);
 				if (CERT) {
-					if (e[u] != MQ_PAD && !hopeless) {
+					if (ecur != MQ_PAD && !hopeless) {
 						// the reference keeps the largest (score, depth) pair among the scores above the threshold; bestCost / be
 						// follow the fused maximum, amb says it is not certainly the reference's
 						if (!(fabs(c - P.peak_threshold) > cb.e0)) amb = true;   // the threshold decision itself (NaN: ambiguous)
 						else if (c > P.peak_threshold) {
 							// bestCost is the largest fused score so far (initially 0 with no candidate: the reference's start)
-							if (c > bestCost + 2*cb.e0) { bestCost = c; be = e[u]; amb_tie = false; }   // every earlier score is out of reach
-							else if (c >= bestCost - 2*cb.e0 && e[u] != be) { amb_tie = true; if (c > bestCost) { bestCost = c; be = e[u]; } }
+							if (c > bestCost + 2*cb.e0) { bestCost = c; be = ecur; amb_tie = false; }   // every earlier score is out of reach
+							else if (c >= bestCost - 2*cb.e0 && ecur != be) { amb_tie = true; if (c > bestCost) { bestCost = c; be = ecur; } }
 						}
 					}
-				} else if (e[u] != MQ_PAD && c > P.peak_threshold) {        // multiviewstereo.cpp:589-594, 654-660
-					if (PEAKS) { if (all) { s_pc[pqn][tid] = c; s_pe[pqn][tid] = e[u]; ++pqn; } }
-					else if (c > bestCost) { bestCost = c; be = e[u]; }
-					else if (c == bestCost && e[u] != be) redo = true;       // exact tie of two candidates: depths decide
+				} else if (ecur != MQ_PAD && c > P.peak_threshold) {        // multiviewstereo.cpp:589-594, 654-660
+					if (PEAKS) { if (all) { s_pc[pqn][tid] = c; s_pe[pqn][tid] = ecur; ++pqn; } }
+					else if (c > bestCost) { bestCost = c; be = ecur; }
+					else if (c == bestCost && ecur != be) redo = true;       // exact tie of two candidates: depths decide
 				}
 			}
 			if (PEAKS && __any(pqn == MS_PQ)) pflush();
