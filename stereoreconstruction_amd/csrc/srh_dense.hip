@@ -205,7 +205,9 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		// the strip kernel's LDS-image layout [tile][row][pixel][WP]: the 32 pixels' taps of one window row are 3 KB of
 		// contiguous bytes.  Stored as they stand (a lane's 96 bytes, 16 at a time) every store instruction touches 64
 		// cache lines (measured: +25 % kernel time); so each window row goes through LDS -- a 6 KB staging row --
-		// and leaves as whole kilobytes.  Each wave has its own staging row; the barriers only order LDS traffic.
+		// and leaves as whole kilobytes.  Each wave has its own staging row and a wave's LDS operations execute in program
+		// order, so nothing has to be waited for: the fences below only keep the compiler from reordering.  (They were
+		// workgroup barriers, which also wait for the wave's global stores of the row before: -2 % of the kernel.)
 		constexpr int WP = (WS + 1) & ~1;
 		static_assert(GW_TW == 2*SRH_WTILE, "a wave covers two window-buffer tiles");
 		__shared__ __align__(16) double stage_buf[GW_ROWS][GW_TW*WP];
@@ -214,7 +216,8 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		constexpr size_t TILE_D = (size_t)SRH_WTILE*WS*WP;   // doubles per tile
 #pragma unroll
 		for (int a = 0; a < WS; ++a) {
-			__syncthreads();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 #pragma unroll
 			for (int b = 0; b < WS; ++b) w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
 #pragma unroll
@@ -223,7 +226,8 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 				*reinterpret_cast<double2 *>(stage + i*WP + b) = v;
 			}
 			stage[i*WP + WS - 1] = w[a][WS - 1];
-			__syncthreads();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 			// 16-byte pieces of the staged row: piece q = doubles 2q, 2q+1 of pixel 2q / WP
 #pragma unroll
 			for (int k = 0; k < (GW_TW*WP/2 + GW_TW - 1)/GW_TW; ++k) {
