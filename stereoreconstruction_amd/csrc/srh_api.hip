@@ -155,6 +155,19 @@ struct srh_context {
 	struct TvDefer { Counters *host = nullptr; bool queued = false, strip = false, cert = false; };
 	TvDefer tv_defer[2];
 	TvDefer *defer = nullptr;
+	// ... and runs the second pass on a stream of its own with its own band buffers (swapped into the context for its
+	// launches, tv_slot_swap): the two passes share nothing but the views, and one pass alone leaves the device idle between
+	// its kernels (~10 us each, a dozen per pass), in their tails and -- the weights kernels, one wave per SIMD -- inside them
+	struct TvSlot {
+		hipStream_t stream = nullptr;
+		hipEvent_t go = nullptr, done = nullptr;
+		Counters *d_cnt = nullptr; int *d_span = nullptr;
+		double *wbuf = nullptr, *cost = nullptr, *tnum = nullptr, *pconst = nullptr;
+		PixRange *prange = nullptr; uint32_t *cflag = nullptr, *lcand = nullptr, *lrowinfo = nullptr; int32_t *lcount = nullptr, *lmeta = nullptr;
+		size_t wbuf_cap = 0, cost_cap = 0, tnum_cap = 0, pconst_cap = 0, prange_cap = 0, cflag_cap = 0, lcand_cap = 0, lrowinfo_cap = 0,
+		       lcount_cap = 0, lmeta_cap = 0;
+	} tv_slot;
+	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	std::map<std::string, ProfEntry> prof;
@@ -555,6 +568,15 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->prange) hipFree(c->prange);
 	if (c->cflag) hipFree(c->cflag);
 	for (auto &d : c->tv_defer) if (d.host) hipHostFree(d.host);
+	{
+		srh_context::TvSlot &T = c->tv_slot;
+		if (T.stream) { hipStreamSynchronize(T.stream); hipStreamDestroy(T.stream); }
+		if (T.go) hipEventDestroy(T.go);
+		if (T.done) hipEventDestroy(T.done);
+		if (T.d_cnt) hipFree(T.d_cnt);
+		if (T.d_span) hipFree(T.d_span);
+		if (T.tnum) hipFree(T.tnum);
+	}
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
 	for (int i = 0; i < SRH_MAX_VIEWS; ++i) if (c->mrf_stream[i]) hipStreamDestroy(c->mrf_stream[i]);
@@ -623,6 +645,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		release_band_buffers(c);
 		return SRH_OK;
 	}
+	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
 #ifdef SRH_EXPERIMENT
 	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
@@ -748,6 +771,9 @@ static size_t held_band_bytes(const srh_context *c) {
 	         + c->lrowinfo_cap*4 + c->lmeta_cap*4 + c->mvs_wdesc_cap*4 + c->mvs_nwin_cap*4 + c->cflag_cap*4;
 	for (const MvsSlot &S : c->mvs_slot)
 		b += S.wbuf_cap*8 + S.cost_cap*8 + S.lcount_cap*4 + S.lcand_cap*4 + S.mvs_wdesc_cap*4 + S.mvs_nwin_cap*4;
+	const srh_context::TvSlot &T = c->tv_slot;
+	b += T.wbuf_cap*8 + T.cost_cap*8 + T.pconst_cap*8 + T.prange_cap*sizeof(PixRange) + T.cflag_cap*4 + T.lcand_cap*4 + T.lrowinfo_cap*4
+	   + T.lcount_cap*4 + T.lmeta_cap*4;
 	return b;
 }
 
@@ -778,6 +804,12 @@ static void release_band_buffers(srh_context *c) {
 		drop(S.wbuf, S.wbuf_cap); drop(S.cost, S.cost_cap); drop(S.lcount, S.lcount_cap); drop(S.lcand, S.lcand_cap);
 		drop(S.mvs_wdesc, S.mvs_wdesc_cap); drop(S.mvs_nwin, S.mvs_nwin_cap);
 	}
+	// (called with everything drained; while the second TwoView pass is being queued the slot holds the FIRST pass's
+	// buffers, which may be in use: with_thinner_bands waits for that stream as well)
+	srh_context::TvSlot &T = c->tv_slot;
+	drop(T.wbuf, T.wbuf_cap); drop(T.cost, T.cost_cap); drop(T.pconst, T.pconst_cap); drop(T.prange, T.prange_cap);
+	drop(T.cflag, T.cflag_cap); drop(T.lcand, T.lcand_cap); drop(T.lrowinfo, T.lrowinfo_cap); drop(T.lcount, T.lcount_cap);
+	drop(T.lmeta, T.lmeta_cap);
 }
 
 // Run `body`; when it fails because a band buffer could not be allocated, wait for everything in flight, release the
@@ -794,6 +826,7 @@ static int with_thinner_bands(srh_context *c, F body) {
 		for (MvsSlot &S : c->mvs_slot) if (S.stream) { (void)hipStreamSynchronize(S.stream); S.pending = false; }
 		if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
 		(void)hipStreamSynchronize(c->stream);
+		if (c->tv_slot.stream) (void)hipStreamSynchronize(c->tv_slot.stream);   // (either of the two is the other pass's)
 		release_band_buffers(c);
 		c->budget_cap = used/2;
 		c->stats.band_retries += 1;
@@ -1283,6 +1316,23 @@ extern "C" int srh_twoview_cross_check(srh_context *c, int left, int right, cons
 	return SRH_OK;
 }
 
+// the context's stream and TwoView band buffers <-> the second pass's
+static void tv_slot_swap(srh_context *c) {
+	srh_context::TvSlot &T = c->tv_slot;
+	std::swap(c->stream, T.stream);
+	std::swap(c->d_cnt, T.d_cnt); std::swap(c->d_span, T.d_span);
+	std::swap(c->wbuf, T.wbuf); std::swap(c->wbuf_cap, T.wbuf_cap);
+	std::swap(c->cost, T.cost); std::swap(c->cost_cap, T.cost_cap);
+	std::swap(c->tnum, T.tnum); std::swap(c->tnum_cap, T.tnum_cap);
+	std::swap(c->pconst, T.pconst); std::swap(c->pconst_cap, T.pconst_cap);
+	std::swap(c->prange, T.prange); std::swap(c->prange_cap, T.prange_cap);
+	std::swap(c->cflag, T.cflag); std::swap(c->cflag_cap, T.cflag_cap);
+	std::swap(c->lcand, T.lcand); std::swap(c->lcand_cap, T.lcand_cap);
+	std::swap(c->lrowinfo, T.lrowinfo); std::swap(c->lrowinfo_cap, T.lrowinfo_cap);
+	std::swap(c->lcount, T.lcount); std::swap(c->lcount_cap, T.lcount_cap);
+	std::swap(c->lmeta, T.lmeta); std::swap(c->lmeta_cap, T.lmeta_cap);
+}
+
 static bool tv_pass_stands(const srh_context::TvDefer &d) {
 	const Counters &h = *d.host;
 	return !(d.strip && h.strip_overflow != 0) && h.cert_overflow == 0 && h.not_row_aligned == 0;
@@ -1298,6 +1348,28 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 		if (!d.host) HIP_TRY(hipHostMalloc((void **)&d.host, sizeof(Counters)));
 		d.queued = false;
 	}
+	if (c->tv_overlap) {
+		srh_context::TvSlot &T = c->tv_slot;
+		if (!T.stream) {
+			HIP_TRY(hipStreamCreateWithFlags(&T.stream, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&T.go, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&T.done, hipEventDisableTiming));
+			HIP_TRY(hipMalloc((void **)&T.d_cnt, sizeof(Counters)));
+			HIP_TRY(hipMalloc((void **)&T.d_span, 4*sizeof(int)));
+		}
+		// the NaN-bordered planes both passes read (twoview_wta_run makes them on demand, on its own stream) exist at `go`
+		if (p->window_radius == 5 || p->window_radius == 2)
+			for (int k = 0; k < 2; ++k) {
+				ViewHost &v = c->views[k == 0 ? left : right];
+				if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
+				if (!v.tvp_valid) {
+					Scope s(c, "padded_plane_kernel");
+					launch_padded_plane(c->stream, v.gray_tv, v.w, v.h, v.tvp);
+					v.tvp_valid = true;
+				}
+			}
+		HIP_TRY(hipEventRecord(T.go, c->stream));
+	}
 	// progress steps as TwoViewStereo emits them (twoviewstereo.cpp:234,405,597,225)
 	progress(c, 1, "Computing cost volume for left image...");
 	c->defer = &c->tv_defer[0];
@@ -1306,10 +1378,28 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 	if (rc) return rc;
 	if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 	progress(c, 3, "Computing cost volume for right image...");
-	c->defer = &c->tv_defer[1];
-	rc = srh_twoview_wta(c, right, left, p, 0, 0);
-	c->defer = nullptr;
-	if (rc) return rc;
+	if (c->tv_overlap && c->tv_defer[0].queued) {
+		// the first pass is queued and unverified (the dense plan): the second one beside it, from the point `go` of the
+		// context's stream (before the first pass: the views and their padded planes are complete there)
+		srh_context::TvSlot &T = c->tv_slot;
+		HIP_TRY(hipStreamWaitEvent(T.stream, T.go, 0));
+		tv_slot_swap(c);
+		c->defer = &c->tv_defer[1];
+		rc = srh_twoview_wta(c, right, left, p, 0, 0);
+		c->defer = nullptr;
+		const hipError_t e = rc ? hipStreamSynchronize(c->stream) : hipEventRecord(T.done, c->stream);   // (c->stream: the slot's, still)
+		tv_slot_swap(c);
+		if (rc) return rc;
+		if (e != hipSuccess) return fail(SRH_E_DEVICE, "second TwoView pass: %s", hipGetErrorString(e));
+		HIP_TRY(hipStreamWaitEvent(c->stream, T.done, 0));            // whatever follows on the context's stream sees both maps
+		// (srh_get_stats reads the context's counters and reports the last pass's, as it does without the overlap)
+		HIP_TRY(hipMemcpyAsync(c->d_cnt, T.d_cnt, sizeof(Counters), hipMemcpyDeviceToDevice, c->stream));
+	} else {
+		c->defer = &c->tv_defer[1];
+		rc = srh_twoview_wta(c, right, left, p, 0, 0);
+		c->defer = nullptr;
+		if (rc) return rc;
+	}
 	if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 	srh_context::TvDefer &d0 = c->tv_defer[0], &d1 = c->tv_defer[1];
 	if (d0.queued && d1.queued) {
