@@ -36,6 +36,7 @@ from stereoreconstruction_amd.distributed import (HipMultiViewEngine, HipTwoView
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (datasheet)
+TV_OVERLAP = os.environ.get("SRH_BENCH_TV_OVERLAP", "1") != "0"   # srh_twoview_compute's two passes side by side (the library's default)
 
 WORKLOADS = {
     # name: (W, H, D, weight_kind, seed, description)
@@ -335,6 +336,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         ctx.twoview_wta(0, 1, p)
         mismatch = float((exact_l.view(np.uint64) != ctx.download_depth(0).view(np.uint64)).mean())
     ctx.set_option("arith", arith_code)
+    ctx.set_option("tv_overlap", 1 if TV_OVERLAP else 0)
     # Depth hand-over: both maps are copied device-to-device into a staging tensor; with N > 1 ranks they are
     # gathered on rank 0 (RCCL over xGMI).  The gather of step k runs while step k+1 computes (two staging
     # buffers, async collective); everything is drained inside the timed region by fence().
@@ -396,8 +398,24 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    prof = ctx.profile()
+    prof_timed = ctx.profile()
     stats = ctx.stats()
+    # per-kernel durations (roofline): srh_twoview_compute runs its two passes side by side on two streams, so the HIP
+    # events around a kernel of the timed steps also time the other pass's share of the GPU; an extra, untimed run of the
+    # same step with the passes one after the other (option tv_overlap 0) gives each kernel's own duration
+    # (SRH_BENCH_TV_OVERLAP=0: the whole run that way -- the rocprofv3 passes of profiles/collect_r04.sh)
+    psteps = args.steps
+    if TV_OVERLAP and not rows_shard:
+        psteps = min(args.steps, 2)
+        ctx.set_option("tv_overlap", 0)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(psteps):
+            step()
+        fence()
+        ctx.profile_enable(False)
+        ctx.set_option("tv_overlap", 1)
+    prof = ctx.profile()
     certified = None
     if stats["n_certified"]:
         # (the last pass of the timed steps: right -> left)
@@ -414,13 +432,13 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         # (u8 RGB+mask of the reference view, u8 gray+mask of the other view, f64 depth out);
         # one step covers 2*W*H reference pixels, spread over `launches/steps` launches.
         share = (len(shard_units(H, world, 0)) / H) if rows_shard else 1.0   # what rank 0's profile covers of the pair
-        alg_bytes_total = 14.0 * 2 * W * H * args.steps * share
+        alg_bytes_total = 14.0 * 2 * W * H * psteps * share
         bytes_per_launch = alg_bytes_total / launches
         avg_ms = ms / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         T = (2 * p.window_radius + 1) ** 2
         flops_per_step = hyp_per_step_per_gpu * (15.0 * T + 8) * share
-        valu_achieved = flops_per_step * args.steps / (ms * 1e-3) / 1e12
+        valu_achieved = flops_per_step * psteps / (ms * 1e-3) / 1e12
         # the PMC files were collected on the exact mode: no traffic / instruction figures are claimed for the opt-in modes
         pmc_mode = args.arith if stats["n_certified"] or args.arith != "certified" else "exact"   # what the dominant kernel really ran
         traffic = pmc_traffic(workload, name, pmc_mode)
@@ -458,9 +476,12 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
                          "frac": round(valu_achieved / VALU_PEAK, 5), "traffic": traffic,
                          "executed": pmc_executed(workload, name, avg_ms, pmc_mode),
                          "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                         "alg_flops_per_launch": round(flops_per_step * args.steps / launches),
+                         "alg_flops_per_launch": round(flops_per_step * psteps / launches),
                          "flops_per_hyp": 15 * T + 8,
-                         "note": "nominal flops against the FMA datasheet peak over the launch time measured in THIS run (HIP events); 'traffic' and "
+                         "note": "nominal flops against the FMA datasheet peak over the launch time measured in THIS run (HIP events"
+                                 + ("; from %d untimed steps with the two passes one after the other, option tv_overlap 0: the timed steps run them "
+                                    "side by side and a kernel's events then span the other pass's share of the GPU, kernels_ms_timed" % psteps
+                                    if TV_OVERLAP and not rows_shard else "") + "); 'traffic' and "
                                  "'executed' take their per-launch counts from the committed rocprofv3 --pmc passes (profiles/pmc_*.json), "
                                  "only the time they are divided by is live",
                          "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -469,6 +490,8 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
                                  "traffic_over_algorithmic": (round(traffic / bytes_per_launch, 1) if traffic else None)}},
             "kernels_ms": {k: [round(v[0], 3), v[1]] for k, v in sorted(prof.items())},
         }
+        if TV_OVERLAP and not rows_shard:
+            result["kernels_ms_timed"] = {k: [round(v[0], 3), v[1]] for k, v in sorted(prof_timed.items())}
         if world == 1 and args.cpu_rows > 0:
             base, cpu_depth, y0 = cpu_baseline(L, R, ml, mr, cams3, zmin, zmax, D, wkind,
                                                 args.cpu_rows if workload != "c1" else max(args.cpu_rows, 24),

@@ -20,6 +20,8 @@ timeout -k 10 300 $B --workload c3 --arith fma --steps 5 --warmup 2 --cpu-rows 0
 echo "bench lines done"
 # per-kernel time (C4: one view in flight, SRH_MVS_ASYNC=0: bench.py takes its kernels_ms from such a pass as well)
 export SRH_MVS_ASYNC=0
+# (and the two TwoView passes one after the other: side by side, a kernel's duration includes the other pass's share of the GPU)
+export SRH_BENCH_TV_OVERLAP=0
 for w in c3 c4 c5 c2; do
 	rocprofv3 --kernel-trace --stats -d "$OUT/stats_$w" --output-format csv -- $B --workload $w --steps 3 --warmup 1 --cpu-rows 0 --no-configs --no-exact-check > "$OUT/stats_$w.log" 2>&1
 	cp "$(find "$OUT/stats_$w" -name '*kernel_stats.csv' | head -1)" "$OUT/${w}_kernel_stats.csv" 2>/dev/null
@@ -40,7 +42,7 @@ for w in c3 c4 c5; do
 	pmc ${w}_mix1 $w SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_MFMA
 	pmc ${w}_mix2 $w SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS
 done
-unset SRH_MVS_ASYNC
+unset SRH_MVS_ASYNC SRH_BENCH_TV_OVERLAP
 for w in c3 c4 c5; do python3 profiles/pmc_table.py $(ls "$OUT"/pmc_${w}_mix*.csv 2>/dev/null) > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
 # where the fused strip kernel's time goes: phase stamps (diagnostic build) and the loop-repeat experiment (experiment build)
 bash profiles/exp_r04_strip_fma.sh "$OUT" > /dev/null 2>&1
