@@ -174,6 +174,9 @@ int  srh_synchronize(srh_context *ctx);
  *   "mvs_async"       1 (default): srh_mvs_initial_estimate only queues a view's kernels, on one of two side streams in
  *                     turn (two views in flight); 0: one view at a time, the call returns when the view is done.
  *                     Either way the maps are complete whenever another entry point can observe them.
+ *   "tv_overlap"      1 (default): srh_twoview_compute queues its second pass on a stream and band buffers of its own beside
+ *                     the first (the passes share only the views; the cross-check waits for both); 0: one after the other
+ *                     on the context's stream.  Identical bits; the second set of band buffers counts against the budget.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
  *   "band_budget_mb"  device scratch per row band the caller asks for (default 32768: a 1920x1080x256 refractive pair
  *                     in one band).  A run never plans with more than a quarter of the device memory that is free at
@@ -218,7 +221,9 @@ int  srh_twoview_wta(srh_context *ctx, int ref_slot, int oth_slot, const srh_par
  * filtered left map; in place on the two slots' depth maps. */
 int  srh_twoview_cross_check(srh_context *ctx, int left_slot, int right_slot, const srh_params *p);
 /* computeDepthMaps minus colourisation (twoviewstereo.cpp:150-227): both passes +
- * cross-check, progress steps 1,3,5,8; synchronous; host outputs may be NULL. */
+ * cross-check, progress steps 1,3,5,8; synchronous; host outputs may be NULL.  The two passes
+ * run side by side on the device (option "tv_overlap"); the progress steps are emitted as the
+ * passes are QUEUED. */
 int  srh_twoview_compute(srh_context *ctx, int left_slot, int right_slot, const srh_params *p,
                          double *left_depth_out, double *right_depth_out);
 
