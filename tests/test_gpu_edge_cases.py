@@ -323,3 +323,47 @@ def test_two_contexts_share_one_gpu(hip_ctx):
         assert other.stats()["band_budget_bytes"] > 0
     assert np.array_equal(_bits(a_l), _bits(b_l)) and np.array_equal(_bits(a_r), _bits(b_r))
     assert np.array_equal(_bits(a_l), _bits(c_l)) and np.array_equal(_bits(a_r), _bits(c_r))
+
+
+def test_twoview_compute_passes_side_by_side_or_one_after_the_other(hip_ctx):
+    """srh_twoview_compute queues its second pass on a stream and band buffers of its own beside the first (option
+    tv_overlap, default 1): the same bits and the same counters as with the passes one after the other -- on the dense plan
+    (where the overlap happens), on a plan the device refutes in both passes (force_dense on a verged rig: both maps are
+    redone one after the other), on the list path (no overlap: its passes wait for their counters), and again after the
+    band buffers were released under it (allocation failures with the second set in use)."""
+    runs = [("geodesic_masks", dict(w=160, h=96, D=24), 0), ("adaptive_rect", dict(w=96, h=64, D=32, radius=5), 0),
+            ("adaptive_verged", dict(w=72, h=44, D=20, radius=5), 1), ("adaptive_refractive", dict(w=96, h=60, D=20, radius=5), 0)]
+    for name, kw, force_dense in runs:
+        case = cases.get_twoview(name, **kw)
+        cams, p = cases.hip_inputs(case)
+        cases.upload_case(hip_ctx, case, cams)
+        hip_ctx.set_option("force_dense", force_dense)
+        got = {}
+        try:
+            for ov in (1, 0, 1):
+                hip_ctx.set_option("tv_overlap", ov)
+                l, r = hip_ctx.twoview_compute(0, 1, p)
+                st = hip_ctx.stats()
+                cur = (l, r, st["n_eval"], st["n_pixels"], st["used_dense_path"])
+                if ov in got:
+                    prev = got[ov]
+                    assert np.array_equal(_bits(prev[0]), _bits(cur[0])) and np.array_equal(_bits(prev[1]), _bits(cur[1])) and prev[2:] == cur[2:]
+                got[ov] = cur
+            assert np.array_equal(_bits(got[0][0]), _bits(got[1][0])) and np.array_equal(_bits(got[0][1]), _bits(got[1][1])), name
+            assert got[0][2:] == got[1][2:], (name, got[0][2:], got[1][2:])
+        finally:
+            hip_ctx.set_option("force_dense", 0)
+            hip_ctx.set_option("tv_overlap", 1)
+    # allocation failures while both sets of band buffers are wanted: thinner bands, the same bits
+    case = cases.get_twoview("geodesic_masks", w=160, h=96, D=24)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    want = hip_ctx.twoview_compute(0, 1, p)
+    st0 = hip_ctx.stats()
+    try:
+        hip_ctx.set_option("debug_alloc_limit_mb", 2)
+        got2 = hip_ctx.twoview_compute(0, 1, p)
+        assert hip_ctx.stats()["band_retries"] > st0["band_retries"]
+    finally:
+        hip_ctx.set_option("debug_alloc_limit_mb", 0)
+    assert np.array_equal(_bits(want[0]), _bits(got2[0])) and np.array_equal(_bits(want[1]), _bits(got2[1]))
