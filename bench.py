@@ -481,7 +481,9 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
                          "note": "nominal flops against the FMA datasheet peak over the launch time measured in THIS run (HIP events"
                                  + ("; from %d untimed steps with the two passes one after the other, option tv_overlap 0: the timed steps run them "
                                     "side by side and a kernel's events then span the other pass's share of the GPU, kernels_ms_timed" % psteps
-                                    if TV_OVERLAP and not rows_shard else "") + "); 'traffic' and "
+                                    if TV_OVERLAP and not rows_shard else "") + ")"
+                                 + ("; frac above 1: the certified one-pass form retires the reference's nominal flops with fewer executed "
+                                    "operations -- 'executed' is the utilisation" if valu_achieved > VALU_PEAK else "") + "; 'traffic' and "
                                  "'executed' take their per-launch counts from the committed rocprofv3 --pmc passes (profiles/pmc_*.json), "
                                  "only the time they are divided by is live",
                          "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
