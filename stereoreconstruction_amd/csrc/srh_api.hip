@@ -97,6 +97,7 @@ struct srh_context {
 	ViewHost views[SRH_MAX_VIEWS];
 	ViewDev *d_views = nullptr;
 	int32_t *d_slots = nullptr;
+	int32_t slots_host[SRH_MAX_VIEWS] = {0}; int slots_n = 0;   // what d_slots holds (srh_mvs_cross_check: the same list for every view of a run)
 	Counters *d_cnt = nullptr;
 	int *d_span = nullptr;
 	double *wbuf = nullptr;   size_t wbuf_cap = 0;      // doubles
@@ -576,6 +577,15 @@ extern "C" void srh_destroy(srh_context *c) {
 		if (T.d_cnt) hipFree(T.d_cnt);
 		if (T.d_span) hipFree(T.d_span);
 		if (T.tnum) hipFree(T.tnum);
+		if (T.wbuf) hipFree(T.wbuf);
+		if (T.cost) hipFree(T.cost);
+		if (T.pconst) hipFree(T.pconst);
+		if (T.prange) hipFree(T.prange);
+		if (T.cflag) hipFree(T.cflag);
+		if (T.lcand) hipFree(T.lcand);
+		if (T.lrowinfo) hipFree(T.lrowinfo);
+		if (T.lcount) hipFree(T.lcount);
+		if (T.lmeta) hipFree(T.lmeta);
 	}
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
@@ -1753,8 +1763,14 @@ extern "C" int srh_mvs_cross_check(srh_context *c, const int32_t *slots, int nvi
 	if (view_index < 0 || view_index >= nviews) return fail(SRH_E_INVALID, "view_index %d outside [0,%d)", view_index, nviews);
 	for (int i = 0; i < nviews; ++i) if ((rc = check_slot(c, slots[i], true))) return rc;
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipMemcpyAsync(c->d_slots, slots, sizeof(int32_t)*nviews, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));   // `slots` is caller memory
+	// the view list travels once per run: MultiViewStereo::crossCheck is called per view with the same list, and a copy per
+	// call (from caller memory: with a host wait) put a copy, two dispatch gaps and a host round trip between the kernels
+	if (c->slots_n != nviews || memcmp(c->slots_host, slots, sizeof(int32_t)*nviews) != 0) {
+		memcpy(c->slots_host, slots, sizeof(int32_t)*nviews);
+		c->slots_n = nviews;
+		HIP_TRY(hipMemcpyAsync(c->d_slots, c->slots_host, sizeof(int32_t)*nviews, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));                   // (the context's copy may change with the next call)
+	}
 	const ViewHost &A = c->views[slots[view_index]];
 	{ Scope s(c, "mvs_cross_check_kernel");
 	  launch_mvs_cross_check(c->stream, c->d_views, c->d_slots, nviews, view_index, A.w, A.h, *p); }
