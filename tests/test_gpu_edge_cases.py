@@ -367,3 +367,39 @@ def test_twoview_compute_passes_side_by_side_or_one_after_the_other(hip_ctx):
     finally:
         hip_ctx.set_option("debug_alloc_limit_mb", 0)
     assert np.array_equal(_bits(want[0]), _bits(got2[0])) and np.array_equal(_bits(want[1]), _bits(got2[1]))
+
+
+def test_caller_owned_stream(hip_ctx):
+    """srh_set_stream: the library works on a stream of the caller's (here one of torch's): srh_twoview_compute with its
+    second pass on the library's side stream, and queued MultiViewStereo estimates, give the bits of the context's own
+    stream; work the caller puts on its stream afterwards is ordered behind them."""
+    torch = pytest.importorskip("torch")
+    tv = cases.get_twoview("geodesic_masks", w=160, h=96, D=24)
+    cams, p = cases.hip_inputs(tv)
+    cases.upload_case(hip_ctx, tv, cams)
+    want = hip_ctx.twoview_compute(0, 1, p)
+    stream = torch.cuda.Stream()
+    hip_ctx.set_stream(stream.cuda_stream)
+    try:
+        got = hip_ctx.twoview_compute(0, 1, p)
+        assert np.array_equal(_bits(want[0]), _bits(got[0])) and np.array_equal(_bits(want[1]), _bits(got[1]))
+        # a MultiViewStereo estimate queued on a side stream, its map copied device-to-device on the caller's stream
+        mv = cases.get_mvs("mvs_geodesic", nviews=3, w=128, h=96, D=24)
+        mcams, mp = cases.hip_inputs(mv)
+        cases.upload_case(hip_ctx, mv, mcams)
+        neigh = capi.mvs_neighbours(mcams, mp)
+        out = torch.empty((96, 128), dtype=torch.float64, device="cuda")
+        hip_ctx.mvs_initial_estimate(0, neigh[0], mp)                # queued on a side stream, ordered into the caller's
+        ptr = hip_ctx.depth_device_ptr(0)
+        hip_ctx.copy_depth_to_device(0, out.data_ptr(), 96 * 128 * 8)   # (on the caller's stream, behind the estimate)
+        stream.synchronize()
+        got0 = out.cpu().numpy()
+    finally:
+        hip_ctx.set_stream(0)
+    hip_ctx.set_option("mvs_async", 0)
+    try:
+        hip_ctx.mvs_initial_estimate(0, neigh[0], mp)
+        ref0 = hip_ctx.download_depth(0)
+    finally:
+        hip_ctx.set_option("mvs_async", 1)
+    assert ptr and np.array_equal(_bits(ref0), _bits(got0))
