@@ -800,6 +800,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		FastProj fp = {};
 		double e1 = 0.0;                                            // bound of the kept point (0: it is the reference's own value)
 		int d1 = 0;                                                 // its label
+		int jx1 = 0, jy1 = 0;                                       // its truncated coordinates (certified projections)
 		if (fastp && active) {
 			const double ta = fabs(tnum[0]), tb = fabs(tnum[P.num_depth_levels - 1]);
 			fp = fast_proj_setup(ray, B.cam, ((ta > tb ? ta : tb)/fabs(nd))*1.000001);
@@ -814,7 +815,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 					double x2, y2, e;
 					fast_project(fp, t, P.image_scale, x2, y2, e);
 					if (!(trunc_certain(x2, e) && trunc_certain(y2, e))) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, t); x2 = p.x; y2 = p.y; e = 0.0; }
-					if (isnan_d(x1)) { x1 = x2; y1 = y2; e1 = e; d1 = d; }
+					if (isnan_d(x1)) { x1 = x2; y1 = y2; e1 = e; d1 = d; jx1 = trunc_sat(x2); jy1 = trunc_sat(y2); }
 					else {
 						double dx = x2 - x1, dy = y2 - y1;
 						double dd = dx*dx + dy*dy;
@@ -824,13 +825,20 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 						if (!(fabs(dd - 1.0) > m)) {
 							// the one-pixel test is not decided by the fast values: both points by the reference's operations
 							if (e != 0.0) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, t); x2 = p.x; y2 = p.y; e = 0.0; }
-							if (e1 != 0.0) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, div_by(tnum[d1], ndd)); x1 = p.x; y1 = p.y; e1 = 0.0; }
+							if (e1 != 0.0) { const double2 p = exact_label_point(A.cam, B.cam, x, y, P.image_scale, div_by(tnum[d1], ndd)); x1 = p.x; y1 = p.y; e1 = 0.0; jx1 = trunc_sat(x1); jy1 = trunc_sat(y1); }
 							dx = x2 - x1; dy = y2 - y1;
 							dd = dx*dx + dy*dy;
 						}
 						if (dd >= 1) {
-							int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
-							if (clip_line(ix0, iy0, ix1, iy1, OW, OH)) {  // 6-arg LineIterator, multiviewstereo.cpp:783
+							// (the kept point's truncations travel with it: two conversions per kept label instead of four)
+							// (a coordinate that passed trunc_certain is a number below 2^28: the plain conversion is trunc_sat's)
+							int ix0 = jx1, iy0 = jy1, ix1, iy1;
+							if (__all(e != 0.0)) { ix1 = (int)x2; iy1 = (int)y2; } else { ix1 = trunc_sat(x2); iy1 = trunc_sat(y2); }
+							jx1 = ix1; jy1 = iy1;
+							// (both end points inside the image: clipLine returns the segment as it is)
+							const bool in0 = (unsigned)ix0 < (unsigned)OW && (unsigned)iy0 < (unsigned)OH;
+							const bool in1 = (unsigned)ix1 < (unsigned)OW && (unsigned)iy1 < (unsigned)OH;
+							if ((in0 && in1) || clip_line(ix0, iy0, ix1, iy1, OW, OH)) {  // 6-arg LineIterator, multiviewstereo.cpp:783
 								lw.begin(ix0, iy0, ix1, iy1, 0, 0);
 								seg = true;
 							}
@@ -880,7 +888,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 				while (seg && lw.has_next() && qn < MQ_QN) {
 					int tx, ty;
 					lw.current(tx, ty);
-					if (tx >= 0 && ty >= 0 && tx < OW && ty < OH) { s_q[qn][tid] = (uint32_t)tx | ((uint32_t)ty << 16); ++qn; }
+					s_q[qn][tid] = (uint32_t)tx | ((uint32_t)ty << 16); ++qn;   // (inside the image: the segment was clipped)
 					lw.next();
 				}
 				const bool more = seg && lw.has_next();
