@@ -1323,6 +1323,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 		const double nd = dot(nrm, ray.dir);
 		if (!(fabs(nd) < 1e-10)) {
 			double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+			int jx1 = 0, jy1 = 0;                                     // the kept point's truncated coordinates travel with it
 			const SharedDivisor nd_sd = shared_divisor(nd);           // 256 labels are divided by this one n.dir
 #ifdef SRH_EXPERIMENT
 			const int exp_nd = g_exp_scan_mode == 2 ? 2 : P.num_depth_levels;
@@ -1332,10 +1333,11 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 #endif
 				double x2, y2;
 				if (!pinhole_project_label_sd(ray, nd_sd, tnum[d], Rv.cam, P.image_scale, x2, y2)) continue;
-				if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
+				if (isnan_d(x1)) { x1 = x2; y1 = y2; jx1 = trunc_sat(x2); jy1 = trunc_sat(y2); continue; }
 				const double dx = x2 - x1, dy = y2 - y1;
 				if (!(dx*dx + dy*dy >= 1)) continue;
-				const int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+				const int ix0 = jx1, iy0 = jy1, ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+				jx1 = ix1; jy1 = iy1;
 				const int a = ix0 < ix1 ? ix0 : ix1, b = ix0 < ix1 ? ix1 : ix0;
 				if (iy0 == y && iy1 == y && a >= lo && b <= hi) {
 					// a segment inside row y: LineIterator with deltay == 0 visits (a..b, y) in

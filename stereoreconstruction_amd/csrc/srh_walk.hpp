@@ -33,6 +33,7 @@ __device__ __forceinline__ void walk_curve(const Ray &ray, const srh_camera &ref
 	const Vec3 normal = load3(refcam.pdir);
 	const int OW = oth.w, OH = oth.h;
 	double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+	int jx1 = 0, jy1 = 0;
 	int lastx = -2147483647, lasty = -2147483647;               // MVS std::unique state
 	// label-independent parts of intersect(ray, plane) and of the other camera's refraction
 	const Vec3 pn = normalized(normal);
@@ -54,10 +55,11 @@ __device__ __forceinline__ void walk_curve(const Ray &ray, const srh_camera &ref
 		if (!cam_project(oth.cam, point, &oth_bn)) continue;
 		const double x2 = point.x*P.image_scale;
 		const double y2 = point.y*P.image_scale;
-		if (isnan_d(x1)) { x1 = x2; y1 = y2; continue; }
+		if (isnan_d(x1)) { x1 = x2; y1 = y2; jx1 = trunc_sat(x2); jy1 = trunc_sat(y2); continue; }
 		const double dx = x2 - x1, dy = y2 - y1;
 		if (!(dx*dx + dy*dy >= 1)) continue;
-		int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+		int ix0 = jx1, iy0 = jy1, ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);   // (the kept point's truncations travel with it)
+		jx1 = ix1; jy1 = iy1;
 		LineWalk lw;
 		bool ok = true;
 		if (MVS) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ void walk_curve(const Ray &ray, const srh_camera &ref
 			while (lw.has_next()) {
 				int tx, ty;
 				lw.current(tx, ty);
-				if (tx >= 0 && ty >= 0 && tx < OW && ty < OH && oth.mask[(size_t)ty*OW + tx] == 1) {
+				if ((unsigned)tx < (unsigned)OW && (unsigned)ty < (unsigned)OH && oth.mask[(size_t)ty*OW + tx] == 1) {
 					if (MVS) {
 						// std::unique over consecutive kept points, multiviewstereo.cpp:801-807
 						if (!(tx == lastx && ty == lasty)) { lastx = tx; lasty = ty; vis(tx, ty); }
