@@ -736,6 +736,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		if (active) ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 		int qn = 0;
 		uint32_t last = 0xffffffffu;                                // std::unique state (last kept point)
+		uint32_t *cp = cand + (unit >> 6)*(size_t)cmax*64 + (unit & 63);   // list slot nk of this lane (wave-tiled lists)
 
 		typedef const __attribute__((address_space(1))) uint8_t *gmask;   // global_load: not coupled to the LDS queue's counter
 		const gmask bmask = (gmask)B.mask;
@@ -743,17 +744,18 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 			for (int k0 = 0; __any(k0 < qn); k0 += 8) {
 				uint32_t e[8];
 				uint8_t m[8];
+				// (reads and loads without conditions -- an entry past the lane's count becomes pixel (0, 0) -- so that the
+				// eight mask bytes are in flight together: as conditional loads each one waited for its own round trip)
 #pragma unroll
-				for (int j = 0; j < 8; ++j) e[j] = k0 + j < qn ? s_q[k0 + j][tid] : 0u;
+				for (int j = 0; j < 8; ++j) { const uint32_t raw = s_q[k0 + j][tid]; e[j] = k0 + j < qn ? raw : 0u; }
+#pragma unroll
+				for (int j = 0; j < 8; ++j) m[j] = bmask[(size_t)(e[j] >> 16)*OW + (e[j] & 0xffffu)];
 #pragma unroll
 				for (int j = 0; j < 8; ++j)
-					m[j] = k0 + j < qn ? bmask[(size_t)(e[j] >> 16)*OW + (e[j] & 0xffffu)] : (uint8_t)0;
-#pragma unroll
-				for (int j = 0; j < 8; ++j)
-					if (m[j] == 1 && e[j] != last) {                // mask == WHITE, then std::unique (:786-807)
+					if (k0 + j < qn && m[j] == 1 && e[j] != last) {   // mask == WHITE, then std::unique (:786-807)
 						last = e[j];
-						if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = e[j];
-						++nk; ++nreal;
+						if (nk < cmax) *cp = e[j];
+						cp += 64; ++nk; ++nreal;
 						const us2 ev = __builtin_bit_cast(us2, e[j]);               // v_pk_min_u16 / v_pk_max_u16: x and y at once
 						flo = __builtin_elementwise_min(flo, ev);
 						fhi = __builtin_elementwise_max(fhi, ev);
@@ -765,8 +767,8 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 #pragma unroll
 			for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_xor(top, dd); top = o > top ? o : top; }
 			if (active)
-				for (; nk < top; ++nk)
-					if (nk < cmax) cand[((unit >> 6)*(size_t)cmax + nk)*64 + (unit & 63)] = MQ_PAD;
+				for (; nk < top; ++nk, cp += 64)
+					if (nk < cmax) *cp = MQ_PAD;
 			if (wdesc && top > wbase) {
 #pragma unroll
 				for (int dd = 1; dd < 64; dd <<= 1) {
@@ -807,8 +809,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		}
 		for (int d = 0; d < P.num_depth_levels; ++d) {
 			bool seg = false;
-			LineWalk lw;
-			lw.x = 1; lw.xend = 0; lw.y = 0; lw.error = 0; lw.ystep = 0; lw.deltax = 0; lw.deltay = 0; lw.steep = false;
+			int sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;                     // the label's segment (seg), clipped
 			if (FASTP) { if (active) {
 				const double t = div_by(tnum[d], ndd);
 				if (!(fabs(nd) < 1e-10) && !(t < 1e-10)) {
@@ -839,7 +840,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 							const bool in0 = (unsigned)ix0 < (unsigned)OW && (unsigned)iy0 < (unsigned)OH;
 							const bool in1 = (unsigned)ix1 < (unsigned)OW && (unsigned)iy1 < (unsigned)OH;
 							if ((in0 && in1) || clip_line(ix0, iy0, ix1, iy1, OW, OH)) {  // 6-arg LineIterator, multiviewstereo.cpp:783
-								lw.begin(ix0, iy0, ix1, iy1, 0, 0);
+								sx0 = ix0; sy0 = iy0; sx1 = ix1; sy1 = iy1;
 								seg = true;
 							}
 							x1 = x2; y1 = y2; e1 = e; d1 = d;
@@ -872,7 +873,7 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 						if (dx*dx + dy*dy >= 1) {
 							int ix0 = trunc_sat(x1), iy0 = trunc_sat(y1), ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
 							if (clip_line(ix0, iy0, ix1, iy1, OW, OH)) {  // 6-arg LineIterator, multiviewstereo.cpp:783
-								lw.begin(ix0, iy0, ix1, iy1, 0, 0);
+								sx0 = ix0; sy0 = iy0; sx1 = ix1; sy1 = iy1;
 								seg = true;
 							}
 #ifdef SRH_EXPERIMENT
@@ -884,6 +885,11 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 					}
 				}
 			}
+			// (one place where the walker's state is made: set in the branches above it had to be given values on every
+			// path around them -- two dozen register moves per label)
+			LineWalk lw;
+			lw.x = 1; lw.xend = 0; lw.y = 0; lw.error = 0; lw.ystep = 0; lw.deltax = 0; lw.deltay = 0; lw.steep = false;
+			if (seg) lw.begin(sx0, sy0, sx1, sy1, 0, 0);
 			for (;;) {
 				while (seg && lw.has_next() && qn < MQ_QN) {
 					int tx, ty;
