@@ -452,7 +452,11 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
             "config": {"workload": desc + "; TwoView WTA both directions + cross-check; one pair per GPU",
                        "width": W, "height": H, "depth_levels": D, "window_radius": int(p.window_radius),
                        "weights": "geodesic" if wkind == capi.WEIGHT_GEODESIC else "adaptive",
-                       "pairs_per_gpu": 1, "parallelism": (("ONE pair in %d row bands, %s gather to rank 0, cross-check there" if rows_shard else "%.0s pairs sharded, %s gather")
+                       "pairs_per_gpu": 1,
+                       # (weak scaling: rank r computes its OWN pair -- C5: seed + r, SURVEY 8(d)'s eight pairs ...50 to ...57;
+                       # other workloads: seed + 0x10000*r)
+                       "pair_seed_rank0": seed, "pair_seed_of_rank_r": ("seed + r" if workload == "c5" else "seed + 0x10000*r") if not rows_shard else "one pair",
+                       "parallelism": (("ONE pair in %d row bands, %s gather to rank 0, cross-check there" if rows_shard else "%.0s pairs sharded, %s gather")
                                                            % (world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                        "dense_path": bool(stats["used_dense_path"]),
                        "arithmetic": ("certified (default): fused multiply-adds in the strip kernel's cost loops, every WTA decision checked "
@@ -545,6 +549,35 @@ def other_configs(args, rank, world, dev, dev_index, backend):
     return out
 
 
+RANK_TIMEOUT_S = float(os.environ.get("SRH_BENCH_RANK_TIMEOUT_S", "300"))   # rendezvous + every collective of a rank
+
+
+def comm_record(dist, backend, world, dev):
+    """What the collective layer saw, machine-readable on the JSON line: backend, world size, the RCCL version torch's
+    backend reports and the one the library's own transport would load (ncclGetVersion), and `ranks_seen` = an
+    all-reduce of 1 over the job (1 without a process group)."""
+    import torch
+    rec = {"backend": backend if world > 1 else None, "world_size": world, "rccl_version": None, "rccl_version_library": None,
+           "ranks_seen": 1, "rank_timeout_s": RANK_TIMEOUT_S if world > 1 else None}
+    try:
+        v = torch.cuda.nccl.version()
+        rec["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else int(v)
+    except Exception as e:                                        # (a torch build without the binding: say so, do not fail the run)
+        rec["rccl_version"] = "unavailable: %s" % type(e).__name__
+    try:
+        from stereoreconstruction_amd import capi
+        rec["rccl_version_library"] = capi.comm_version() or None
+    except Exception:
+        pass
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        rec["ranks_seen"] = int(one.item())
+        if rec["ranks_seen"] != world:
+            raise SystemExit("bench.py: all-reduce of 1 saw %d ranks of %d" % (rec["ranks_seen"], world))
+    return rec
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one -- before
     anything here has initialised HIP or torch.cuda; a process that has touched the GPU is never exec'ed over -- with the
@@ -569,23 +602,54 @@ def self_launch(n):
         for line in stream:
             (sys.stdout if line.startswith("{") else sys.stderr).write(line)
             sys.stdout.flush()
+    import signal
     import threading
     reader = threading.Thread(target=pump, args=(procs[0].stdout,), daemon=True)
     reader.start()
+
+    def stop_ranks(grace=5.0):
+        # the exact PIDs this launcher started: terminate, then kill what is still there after the grace period
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        t_end = time.monotonic() + grace
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+
+    # a launcher that is told to stop (timeout -k, the driver, Ctrl-C) takes its ranks with it: left alone they would keep
+    # their GPUs and wait in a collective, under the next measurement on the box
+    def on_signal(signum, _frame):
+        stop_ranks()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_signal)
+    # a rank that never arrives (rendezvous, a hung collective) must end the launch, not hang it: every rank's own
+    # process-group timeout is RANK_TIMEOUT_S; the launcher gives the whole run a deadline as the last resort
+    deadline = time.monotonic() + float(os.environ.get("SRH_BENCH_LAUNCH_DEADLINE_S", "1500"))
     code = 0
     alive = list(procs)
-    while alive:
-        for pr in list(alive):
-            rc = pr.poll()
-            if rc is None:
-                continue
-            alive.remove(pr)
-            if rc != 0 and code == 0:
-                code = rc if rc > 0 else 128 - rc
-                for other in alive:                               # a rank is gone: the others would wait in a collective for ever
-                    other.terminate()
-        if alive:
-            time.sleep(0.05)
+    try:
+        while alive:
+            for pr in list(alive):
+                rc = pr.poll()
+                if rc is None:
+                    continue
+                alive.remove(pr)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 128 - rc
+                    for other in alive:                           # a rank is gone: the others would wait in a collective for ever
+                        other.terminate()
+            if alive and time.monotonic() > deadline:
+                sys.stderr.write("bench.py: ranks still running at the launch deadline, stopping them\n")
+                code = code or 124
+                break
+            if alive:
+                time.sleep(0.05)
+    finally:
+        stop_ranks()
     reader.join(timeout=10)
     return code
 
@@ -629,13 +693,20 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
+        import datetime
+        # a finite timeout on the rendezvous and on every collective: a rank that never arrives makes the others fail
+        # (non-zero exit of these child processes; the launcher then stops the rest), never wait for ever
+        tmo = datetime.timedelta(seconds=RANK_TIMEOUT_S)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")   # a timed-out collective tears the process down
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+    comm = comm_record(dist, backend, world, dev) if rank == 0 or world > 1 else None
 
     if args.workload == "c4":
         result = run_c4(args, rank, world, dev, dev_index, backend)
+        result["comm"] = comm
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -644,6 +715,7 @@ def main():
         return
 
     result = run_twoview(args, args.workload, rank, world, dev, dev_index, backend)
+    result["comm"] = comm
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_configs and args.arith in ("certified", "exact"):
         result["configs"] = other_configs(args, rank, world, dev, dev_index, backend)
     if world > 1:

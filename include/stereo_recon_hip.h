@@ -331,7 +331,15 @@ int  srh_refraction_error(srh_context *ctx, int slot1, int slot2, int npairs, co
  * first use; SRH_E_UNSUPPORTED if it is absent. */
 #define SRH_COMM_ID_BYTES 128
 int  srh_comm_unique_id(void *id_out);
+/* The communicator is non-blocking (ncclConfig_t::blocking = 0): a rank that never arrives at the rendezvous, or a call
+ * that stays "in progress" longer than the timeout (srh_comm_set_timeout_ms, default 120 000 ms), returns SRH_E_DEVICE
+ * after the communicator has been aborted -- a missing rank ends the job with an error instead of hanging it. */
 int  srh_comm_init(srh_context *ctx, int nranks, int rank, const void *id);
+int  srh_comm_set_timeout_ms(int ms);
+/* NCCL_VERSION_CODE of the loaded librccl (ncclGetVersion), 0 when there is none; what the context's communicator
+ * spans (0 ranks, rank -1 without one) */
+int  srh_comm_version(void);
+int  srh_comm_info(srh_context *ctx, int *nranks, int *rank);
 /* Gather the depth map of `slot` (w*h doubles, equal on all ranks) to `root`:
  * recv_dev (DEVICE, nranks*w*h doubles, rank order) is written on the root only. */
 int  srh_comm_gather_depth(srh_context *ctx, int slot, int root, void *recv_dev);

@@ -52,16 +52,16 @@ unset SRH_MVS_ASYNC
 for w in c3 c4 c5; do python3 profiles/pmc_table.py $(ls "$OUT"/pmc_${w}_mix*.csv "$OUT"/pmc_${w}_tc*.csv 2>/dev/null) > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
 # per-phase stamps of the strip kernel (diagnostic build: never the shipped library), both forms
 for strip in 8 4; do
-	SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so SRH_BENCH_STRIP=$strip timeout -k 10 200 $B --workload c3 --steps 2 --warmup 1 --cpu-rows 0 --no-configs > /dev/null 2> "$OUT/phases_strip$strip.err"
+	SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_prof.so SRH_BENCH_STRIP=$strip timeout -k 10 200 $B --workload c3 --steps 2 --warmup 1 --cpu-rows 0 --no-configs > /dev/null 2> "$OUT/phases_strip$strip.err"
 	grep "srh dbg" "$OUT/phases_strip$strip.err" | grep -v rows | tail -9 > "$OUT/c3_strip${strip}_phases.txt"
 done
 # phases of the geodesic kernel (C3) and of the staged MVS cost kernel (C4), diagnostic build
-SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so timeout -k 10 200 $B --workload c3 --steps 1 --warmup 1 --cpu-rows 0 --no-configs 2>&1 >/dev/null | grep "geodesic kernel" | tail -1 > "$OUT/c3_geodesic_phases.txt"
-SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so SRH_MVS_ASYNC=0 timeout -k 10 200 $B --workload c4 --steps 1 --warmup 1 --cpu-rows 0 --no-configs 2>&1 >/dev/null | grep "staged MVS" | tail -8 > "$OUT/c4_staged_phases.txt"
+SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_prof.so timeout -k 10 200 $B --workload c3 --steps 1 --warmup 1 --cpu-rows 0 --no-configs 2>&1 >/dev/null | grep "geodesic kernel" | tail -1 > "$OUT/c3_geodesic_phases.txt"
+SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_prof.so SRH_MVS_ASYNC=0 timeout -k 10 200 $B --workload c4 --steps 1 --warmup 1 --cpu-rows 0 --no-configs 2>&1 >/dev/null | grep "staged MVS" | tail -8 > "$OUT/c4_staged_phases.txt"
 # what the block loops cost: every tile's loops repeated 1, 2, 3 times (timing experiment build), per-tile and strip kernels
 {
 	for strip in 0 8; do for rep in 1 2 3; do
-		SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_exp.so SRH_BENCH_STRIP=$strip SRH_BENCH_EXP_REPEAT=$rep timeout -k 10 200 $B --workload c3 --steps 3 --warmup 1 --cpu-rows 0 --no-configs > "$OUT/rep.json" 2>/dev/null
+		SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_exp.so SRH_BENCH_STRIP=$strip SRH_BENCH_EXP_REPEAT=$rep timeout -k 10 200 $B --workload c3 --steps 3 --warmup 1 --cpu-rows 0 --no-configs > "$OUT/rep.json" 2>/dev/null
 		python3 -c "
 import json
 d=json.load(open('$OUT/rep.json'))

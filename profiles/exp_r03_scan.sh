@@ -1,6 +1,6 @@
 set -u
 O=gpurun_out/r3scan; mkdir -p $O
-export SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_exp.so
+export SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_exp.so
 for mode in 0 1 2; do
 SRH_BENCH_EXP_SCAN_MODE=$mode timeout -k 10 200 python3 bench.py --workload c3 --steps 3 --warmup 1 --cpu-rows 0 --no-configs > $O/mode$mode.json 2> $O/mode$mode.err
 python3 -c "

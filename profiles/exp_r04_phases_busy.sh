@@ -5,7 +5,7 @@
 OUT=${1:-gpurun_out/r04}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-PROF=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so
+PROF=$PWD/profiles/lib/libstereo_recon_hip_prof.so
 for a in certified exact; do
 	SRH_LIBRARY=$PROF timeout -k 10 180 python3 bench.py --workload c4 --steps 1 --warmup 0 --cpu-rows 0 --no-configs --arith $a 2>&1 >/dev/null < /dev/null \
 		| grep "staged MVS cost" | sort | uniq -c | sort -rn | head -4 | sed "s/^/arith $a: /"

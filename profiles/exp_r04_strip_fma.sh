@@ -5,12 +5,12 @@ set -u
 O=${1:-gpurun_out/r4f}; mkdir -p $O
 B="python3 bench.py --workload c3 --cpu-rows 0 --no-configs"
 for ar in certified exact; do
-  SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_prof.so timeout -k 10 200 $B --steps 2 --warmup 1 --arith $ar > $O/phases_$ar.json 2> $O/phases_$ar.err
+  SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_prof.so timeout -k 10 200 $B --steps 2 --warmup 1 --arith $ar > $O/phases_$ar.json 2> $O/phases_$ar.err
   grep "srh dbg" $O/phases_$ar.err | grep -v rows | tail -9 > $O/c3_strip8_phases_$ar.txt
 done
 {
 for ar in certified exact; do for rep in 1 2 3; do
-  SRH_LIBRARY=$PWD/stereoreconstruction_amd/libstereo_recon_hip_exp.so SRH_BENCH_EXP_REPEAT=$rep timeout -k 10 200 $B --steps 3 --warmup 1 --arith $ar > $O/rep.json 2>/dev/null
+  SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_exp.so SRH_BENCH_EXP_REPEAT=$rep timeout -k 10 200 $B --steps 3 --warmup 1 --arith $ar > $O/rep.json 2>/dev/null
   python3 -c "
 import json
 d=json.load(open('$O/rep.json'))

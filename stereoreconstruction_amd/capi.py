@@ -92,7 +92,7 @@ EXPORTS = [
     "srh_mvs_initial_estimate_peaks", "srh_mvs_mrf_estimate_views",
     "srh_comm_unique_id", "srh_comm_init", "srh_comm_gather_depth", "srh_comm_allgather_depth", "srh_comm_allgather_host",
     "srh_comm_allgather_views",
-    "srh_comm_destroy",
+    "srh_comm_destroy", "srh_comm_set_timeout_ms", "srh_comm_version", "srh_comm_info",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
 ]
 
@@ -168,6 +168,9 @@ def lib():
     L.srh_comm_allgather_depth.argtypes = [vp, C.c_int, vp]
     L.srh_comm_allgather_host.argtypes = [vp, c_double_p, C.c_size_t, c_double_p]
     L.srh_comm_destroy.argtypes = [vp]
+    L.srh_comm_set_timeout_ms.argtypes = [C.c_int]
+    L.srh_comm_version.restype = C.c_int
+    L.srh_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.srh_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.srh_profile_enable.argtypes = [vp, C.c_int]
     L.srh_profile_reset.argtypes = [vp]
@@ -249,6 +252,15 @@ def mvs_neighbours(cams, p):
     _check(lib().srh_mvs_neighbours(n, arr, C.byref(p), neigh.ctypes.data_as(c_int32_p),
                                     cnt.ctypes.data_as(c_int32_p)))
     return [[int(v) for v in neigh[i, :cnt[i]]] for i in range(n)]
+
+
+def comm_version():
+    """NCCL_VERSION_CODE of the librccl the library loads (ncclGetVersion), 0 when there is none: srh_comm_version."""
+    return int(lib().srh_comm_version())
+
+
+def comm_set_timeout_ms(ms):
+    _check(lib().srh_comm_set_timeout_ms(int(ms)))
 
 
 def hw_queues_requested():

@@ -141,6 +141,7 @@ struct srh_context {
 	size_t budget_cap = 0;                              // 0 = none; set by with_thinner_bands after an out-of-memory run
 	size_t budget_used = 0;                             // what band_budget() returned last
 	size_t mem_limit = 0;                               // option "mem_limit_mb": pretend the device has only this much free (tests)
+	size_t alloc_limit = 0;                             // option "debug_alloc_limit_mb": band buffers above this size are refused (tests)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
 	void *user = nullptr;
@@ -215,6 +216,8 @@ struct Scope {
 // Band buffers grow on demand.  A request the device cannot serve is not the end of the call: g_oom tells the entry
 // point (with_thinner_bands below) to release the band buffers, halve the band budget and run again.
 // g_alloc_limit (option "debug_alloc_limit_mb") makes requests above a size fail the same way: the test of that path.
+// (both are set from the context at the start of every retrying entry point -- with_thinner_bands -- so that a limit set
+// through one thread applies to calls made on another)
 static thread_local bool g_oom = false;
 static thread_local size_t g_alloc_limit = 0;
 
@@ -484,14 +487,8 @@ extern "C" int srh_create(int device, srh_context **out) {
 	srh_context *c = new srh_context();
 	c->device = device;
 	memset(&c->stats, 0, sizeof(c->stats));
-	if (const char *s = getenv("SRH_WBUF_MB")) { long mb = atol(s); if (mb > 0) c->wbuf_budget = (size_t)mb << 20; }
-	if (const char *s = getenv("SRH_FORCE_GENERIC")) c->force_generic = atoi(s) != 0;
-	if (const char *s = getenv("SRH_LIST_ROWS")) c->list_rows = atoi(s) != 0;
-	if (const char *s = getenv("SRH_STRIP")) c->strip = atoi(s);
-	if (const char *s = getenv("SRH_CERT_FORM")) { const int a = atoi(s); if (a == 1 || a == 2) c->cert_form = a; }
-	if (const char *s = getenv("SRH_ARITH")) { const int a = atoi(s); if (a >= 0 && a <= 3) c->arith = a; }
-	if (const char *s = getenv("SRH_MVS_STAGED")) c->mvs_staged = atoi(s) != 0;
-	if (const char *s = getenv("SRH_MVS_ASYNC")) c->mvs_async = atoi(s) != 0;
+	// (no environment overrides: which arithmetic / path a host runs is decided by srh_set_option alone, and reported
+	// by srh_get_stats; bench.py maps its own SRH_BENCH_* variables to options)
 	{ int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus; }
 	hipError_t e2 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
 	if (e2 != hipSuccess) { delete c; return fail(SRH_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
@@ -647,7 +644,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	// tests of the budget logic: pretend the device has only `value` MB to give / refuse band buffers above `value` MB
 	if (!strcmp(name, "mem_limit_mb")) { c->mem_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
 	if (!strcmp(name, "debug_alloc_limit_mb")) {
-		g_alloc_limit = value > 0 ? (size_t)value << 20 : 0;
+		c->alloc_limit = g_alloc_limit = value > 0 ? (size_t)value << 20 : 0;
 		// the band buffers a bigger run left behind would serve every later request without an allocation: start afresh
 		for (MvsSlot &S : c->mvs_slot) if (S.stream) HIP_TRY(hipStreamSynchronize(S.stream));
 		if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
@@ -656,6 +653,8 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		return SRH_OK;
 	}
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
+	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
+	if (!strcmp(name, "debug_mvs_cmax_hint")) { c->mvs_cmax_hint = value > 0 ? (int)((value + 7) & ~7L) : 0; return SRH_OK; }
 #ifdef SRH_EXPERIMENT
 	if (!strcmp(name, "exp_repeat")) { exp_set((int)value, -1); return SRH_OK; }
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
@@ -828,12 +827,17 @@ template <class F>
 static int with_thinner_bands(srh_context *c, F body) {
 	for (;;) {
 		g_oom = false;
+		g_alloc_limit = c->alloc_limit;
 		const int rc = body();
 		if (rc != SRH_E_DEVICE || !g_oom) return rc;
 		g_oom = false;
 		const size_t used = c->budget_used;
 		if (used <= ((size_t)1 << 20)) return rc;                   // already the thinnest bands there are
-		for (MvsSlot &S : c->mvs_slot) if (S.stream) { (void)hipStreamSynchronize(S.stream); S.pending = false; }
+		// Everything in flight is drained before the band buffers go.  A MultiViewStereo view queued earlier on the other
+		// slot stays PENDING: its kernels are complete now, but its list-capacity check (mvs_settle_slot: h_maxc is pinned
+		// and stays valid) has not been made -- the retried call, or whichever entry point comes next, settles it and
+		// redoes the view if a list was cut.
+		for (MvsSlot &S : c->mvs_slot) if (S.stream) (void)hipStreamSynchronize(S.stream);
 		if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
 		(void)hipStreamSynchronize(c->stream);
 		if (c->tv_slot.stream) (void)hipStreamSynchronize(c->tv_slot.stream);   // (either of the two is the other pass's)
@@ -1421,11 +1425,13 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 		if (right_out) HIP_TRY(hipMemcpyAsync(right_out, Rv.depth, (size_t)Rv.w*Rv.h*sizeof(double), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		if (tv_pass_stands(d0) && tv_pass_stands(d1)) {
-			c->stats.n_pixels = (int64_t)(d0.host->n_pixels + d1.host->n_pixels);
-			c->stats.n_eval = (int64_t)(d0.host->n_eval + d1.host->n_eval);
-			c->stats.n_eval_device = (int64_t)(d0.host->n_eval_device + d1.host->n_eval_device);
-			c->stats.n_certified = (int64_t)(d0.host->n_certified + d1.host->n_certified);
-			c->stats.n_flagged = (int64_t)(d0.host->n_flagged + d1.host->n_flagged);
+			// (every counter of srh_stats is the LAST pass's -- right -> left -- on this path as on the verified ones and in
+			// srh_get_stats, which reads the context's device counters: the second pass's were copied there above)
+			c->stats.n_pixels = (int64_t)d1.host->n_pixels;
+			c->stats.n_eval = (int64_t)d1.host->n_eval;
+			c->stats.n_eval_device = (int64_t)d1.host->n_eval_device;
+			c->stats.n_certified = (int64_t)d1.host->n_certified;
+			c->stats.n_flagged = (int64_t)d1.host->n_flagged;
 			c->stats.used_dense_path = 1;
 			c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 			progress(c, 8, "Finished!");
@@ -1766,10 +1772,11 @@ extern "C" int srh_mvs_cross_check(srh_context *c, const int32_t *slots, int nvi
 	// the view list travels once per run: MultiViewStereo::crossCheck is called per view with the same list, and a copy per
 	// call (from caller memory: with a host wait) put a copy, two dispatch gaps and a host round trip between the kernels
 	if (c->slots_n != nviews || memcmp(c->slots_host, slots, sizeof(int32_t)*nviews) != 0) {
+		c->slots_n = 0;                                             // (a failed copy must not leave a cache entry behind)
 		memcpy(c->slots_host, slots, sizeof(int32_t)*nviews);
-		c->slots_n = nviews;
 		HIP_TRY(hipMemcpyAsync(c->d_slots, c->slots_host, sizeof(int32_t)*nviews, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));                   // (the context's copy may change with the next call)
+		c->slots_n = nviews;
 	}
 	const ViewHost &A = c->views[slots[view_index]];
 	{ Scope s(c, "mvs_cross_check_kernel");
@@ -2096,8 +2103,33 @@ extern "C" int srh_comm_init(srh_context *c, int nranks, int rank, const void *i
 	if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SRH_E_INVALID, "rank %d of %d", rank, nranks);
 	HIP_TRY(hipSetDevice(c->device));
 	if (c->comm) { rccl_comm_destroy(c->comm); c->comm = nullptr; }
-	if (const char *e = rccl_comm_init(&c->comm, nranks, rank, id)) return fail(SRH_E_UNSUPPORTED, "RCCL: %s", e);
+	// (non-blocking communicator: a rank that never arrives is an error after the timeout, not a hang)
+	if (const char *e = rccl_comm_init(&c->comm, nranks, rank, id)) { c->comm = nullptr; c->comm_ranks = 0; return fail(SRH_E_DEVICE, "RCCL: %s", e); }
 	c->comm_ranks = nranks; c->comm_rank = rank;
+	return SRH_OK;
+}
+
+// a collective that failed or timed out: the communicator is aborted (its peers' calls then fail too instead of
+// waiting), the context has none until srh_comm_init is called again
+static int comm_failed(srh_context *c, const char *what, const char *e) {
+	const int rc = fail(SRH_E_DEVICE, "RCCL %s: %s", what, e);
+	rccl_comm_abort(c->comm);
+	c->comm = nullptr; c->comm_ranks = 0;
+	return rc;
+}
+
+extern "C" int srh_comm_version(void) { return rccl_version(); }
+
+extern "C" int srh_comm_set_timeout_ms(int ms) {
+	if (ms <= 0) return fail(SRH_E_INVALID, "timeout must be > 0 ms");
+	rccl_set_timeout_ms(ms);
+	return SRH_OK;
+}
+
+extern "C" int srh_comm_info(srh_context *c, int *nranks, int *rank) {
+	if (!c) return fail(SRH_E_INVALID, "null context");
+	if (nranks) *nranks = c->comm ? c->comm_ranks : 0;
+	if (rank) *rank = c->comm ? c->comm_rank : -1;
 	return SRH_OK;
 }
 
@@ -2110,7 +2142,7 @@ extern "C" int srh_comm_gather_depth(srh_context *c, int slot, int root, void *r
 	const ViewHost &v = c->views[slot];
 	if (const char *e = rccl_gather_f64(c->comm, c->comm_ranks, c->comm_rank, root, v.depth, (double *)recv_dev,
 	                                    (size_t)v.w*v.h, c->stream))
-		return fail(SRH_E_DEVICE, "RCCL gather: %s", e);
+		return comm_failed(c, "gather", e);
 	return SRH_OK;
 }
 
@@ -2121,7 +2153,7 @@ extern "C" int srh_comm_allgather_depth(srh_context *c, int slot, void *recv_dev
 	HIP_TRY(hipSetDevice(c->device));
 	const ViewHost &v = c->views[slot];
 	if (const char *e = rccl_allgather_f64(c->comm, v.depth, (double *)recv_dev, (size_t)v.w*v.h, c->stream))
-		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
+		return comm_failed(c, "all-gather", e);
 	return SRH_OK;
 }
 
@@ -2137,7 +2169,7 @@ extern "C" int srh_comm_allgather_host(srh_context *c, const double *send_host, 
 	if ((rc = ensure(c->wbuf, c->wbuf_cap, count*(size_t)(c->comm_ranks + 1)))) return rc;
 	HIP_TRY(hipMemcpyAsync(c->wbuf, send_host, count*sizeof(double), hipMemcpyHostToDevice, c->stream));
 	if (const char *e = rccl_allgather_f64(c->comm, c->wbuf, c->wbuf + count, count, c->stream))
-		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
+		return comm_failed(c, "all-gather", e);
 	HIP_TRY(hipMemcpyAsync(recv_host, c->wbuf + count, count*(size_t)c->comm_ranks*sizeof(double), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return SRH_OK;
@@ -2169,7 +2201,7 @@ extern "C" int srh_comm_allgather_views(srh_context *c, const int32_t *slots, in
 		HIP_TRY(hipMemcpyAsync(send + (size_t)(v - lo)*npix, vh.depth, (size_t)vh.w*vh.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
 	}
 	if (const char *e = rccl_allgather_f64(c->comm, send, recv, (size_t)per*npix, c->stream))
-		return fail(SRH_E_DEVICE, "RCCL all-gather: %s", e);
+		return comm_failed(c, "all-gather", e);
 	for (int r = 0; r < world; ++r) {
 		if (r == rank) continue;
 		int rlo, rhi;

@@ -8,8 +8,11 @@
 #include "srh_internal.hpp"
 
 #include <dlfcn.h>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <rccl/rccl.h>                                       // types and the config initialiser only: the library itself is dlopen'ed
 
 namespace srh {
 
@@ -20,7 +23,11 @@ enum { RCCL_FLOAT64 = 8 };                                   // ncclFloat64
 struct RcclApi {
 	void *lib = nullptr;
 	int (*GetUniqueId)(rccl_unique_id *) = nullptr;
-	int (*CommInitRank)(rccl_comm *, int, rccl_unique_id, int) = nullptr;
+	int (*CommInitRankConfig)(rccl_comm *, int, rccl_unique_id, int, ncclConfig_t *) = nullptr;
+	int (*CommGetAsyncError)(rccl_comm, int *) = nullptr;
+	int (*CommAbort)(rccl_comm) = nullptr;
+	int (*CommCount)(rccl_comm, int *) = nullptr;
+	int (*GetVersion)(int *) = nullptr;
 	int (*CommDestroy)(rccl_comm) = nullptr;
 	int (*AllGather)(const void *, void *, size_t, int, rccl_comm, hipStream_t) = nullptr;
 	int (*Send)(const void *, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
@@ -41,7 +48,11 @@ const char *rccl_load() {
 #define SRH_SYM(field, name) \
 	*(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) { dlclose(h); return "librccl lacks " name; }
 	SRH_SYM(GetUniqueId, "ncclGetUniqueId")
-	SRH_SYM(CommInitRank, "ncclCommInitRank")
+	SRH_SYM(CommInitRankConfig, "ncclCommInitRankConfig")
+	SRH_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
+	SRH_SYM(CommAbort, "ncclCommAbort")
+	SRH_SYM(CommCount, "ncclCommCount")
+	SRH_SYM(GetVersion, "ncclGetVersion")
 	SRH_SYM(CommDestroy, "ncclCommDestroy")
 	SRH_SYM(AllGather, "ncclAllGather")
 	SRH_SYM(Send, "ncclSend")
@@ -63,16 +74,58 @@ const char *rccl_unique_id_get(void *out128) {
 	return nullptr;
 }
 
+// The communicator is NON-BLOCKING (ncclConfig_t::blocking = 0): no call into RCCL can hold a rank for ever.  A call
+// that answers ncclInProgress is polled (ncclCommGetAsyncError) until it settles or `timeout_ms` has passed; a rank that
+// never arrives at the rendezvous, or a peer that dies inside a collective, then becomes an error string here -- the
+// caller returns SRH_E_DEVICE and the process can exit non-zero -- after the communicator has been aborted.
+static int g_timeout_ms = 120000;
+void rccl_set_timeout_ms(int ms) { g_timeout_ms = ms > 0 ? ms : 120000; }
+
+static const char *rccl_settle(rccl_comm c, int rc, const char *what) {
+	static thread_local char msg[160];
+	if (rc == ncclSuccess) return nullptr;
+	if (rc != ncclInProgress) return g_rccl.GetErrorString(rc);
+	const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(g_timeout_ms);
+	for (;;) {
+		int st = ncclSuccess;
+		const int q = g_rccl.CommGetAsyncError(c, &st);
+		if (q != ncclSuccess) return g_rccl.GetErrorString(q);
+		if (st == ncclSuccess) return nullptr;
+		if (st != ncclInProgress) return g_rccl.GetErrorString(st);
+		if (std::chrono::steady_clock::now() > t_end) {
+			snprintf(msg, sizeof(msg), "%s still in progress after %d ms (a rank missing or gone?): communicator aborted", what, g_timeout_ms);
+			return msg;
+		}
+		std::this_thread::sleep_for(std::chrono::microseconds(200));
+	}
+}
+
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128) {
 	if (const char *e = rccl_load()) return e;
 	rccl_unique_id id;
 	memcpy(&id, id128, sizeof(id));
 	rccl_comm c = nullptr;
-	const int rc = g_rccl.CommInitRank(&c, nranks, id, rank);
-	if (rc) return g_rccl.GetErrorString(rc);
+	ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+	cfg.blocking = 0;
+	const int rc = g_rccl.CommInitRankConfig(&c, nranks, id, rank, &cfg);
+	if (const char *e = rccl_settle(c, rc, "ncclCommInitRank")) {
+		if (c) g_rccl.CommAbort(c);
+		return e;
+	}
+	int n = 0;
+	if (g_rccl.CommCount(c, &n) != ncclSuccess || n != nranks) { g_rccl.CommAbort(c); return "communicator does not span the ranks asked for"; }
 	*comm = c;
 	return nullptr;
 }
+
+// NCCL_VERSION_CODE of the loaded library (e.g. 22703), 0 if it cannot be loaded
+int rccl_version() {
+	if (rccl_load()) return 0;
+	int v = 0;
+	return g_rccl.GetVersion(&v) == ncclSuccess ? v : 0;
+}
+
+void rccl_comm_abort(void *comm) { if (comm && g_rccl.CommAbort) g_rccl.CommAbort((rccl_comm)comm); }
 
 void rccl_comm_destroy(void *comm) { if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy((rccl_comm)comm); }
 
@@ -81,9 +134,10 @@ const char *rccl_gather_f64(void *comm, int nranks, int rank, int root, const do
                             size_t count, hipStream_t st)
 {
 	int rc = g_rccl.GroupStart();
-	if (rc) return g_rccl.GetErrorString(rc);
+	if (rc && rc != ncclInProgress) return g_rccl.GetErrorString(rc);
+	rc = 0;
 	if (rank == root) {
-		for (int r = 0; r < nranks && !rc; ++r) {
+		for (int r = 0; r < nranks && (!rc || rc == ncclInProgress); ++r) {
 			if (r == rank) continue;
 			rc = g_rccl.Recv(recv + (size_t)r*count, count, RCCL_FLOAT64, r, (rccl_comm)comm, st);
 		}
@@ -91,8 +145,8 @@ const char *rccl_gather_f64(void *comm, int nranks, int rank, int root, const do
 		rc = g_rccl.Send(send, count, RCCL_FLOAT64, root, (rccl_comm)comm, st);
 	}
 	const int rc2 = g_rccl.GroupEnd();
-	if (rc) return g_rccl.GetErrorString(rc);
-	if (rc2) return g_rccl.GetErrorString(rc2);
+	if (rc && rc != ncclInProgress) return g_rccl.GetErrorString(rc);
+	if (const char *e = rccl_settle((rccl_comm)comm, rc2, "the gather's ncclGroupEnd")) return e;
 	if (rank == root) {
 		if (hipMemcpyAsync(recv + (size_t)rank*count, send, count*sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
 			return "hipMemcpyAsync of the root's own map failed";
@@ -102,7 +156,7 @@ const char *rccl_gather_f64(void *comm, int nranks, int rank, int root, const do
 
 const char *rccl_allgather_f64(void *comm, const double *send, double *recv, size_t count, hipStream_t st) {
 	const int rc = g_rccl.AllGather(send, recv, count, RCCL_FLOAT64, (rccl_comm)comm, st);
-	return rc ? g_rccl.GetErrorString(rc) : nullptr;
+	return rccl_settle((rccl_comm)comm, rc, "ncclAllGather");
 }
 
 } // namespace srh

@@ -275,8 +275,10 @@ SRH_HD bool clip_line(int &x0, int &y0, int &x1, int &y1, int w, int h) {
 		const double fa = (double)p1 - (double)p0, fb = (double)lim - (double)q0, fd = (double)q1 - (double)q0;
 		const double num = fa*fb;
 		long long cut;
-		if (__builtin_fabs(num) < 0x1p52) {
-			int q = (int)(num/fd);                                    // |quotient| <= |p1 - p0| < 2^31: the cut lies on the segment
+		if (__builtin_fabs(num) < 0x1p52 && __builtin_fabs(fa) < 0x1p31) {
+			// |quotient| <= |p1 - p0| < 2^31 (the cut lies on the segment; every caller's coordinates come out of trunc_sat,
+			// +-2^29, and anything wider takes the 64-bit branch like the host)
+			int q = (int)(num/fd);
 			const double r = __builtin_fma(-(double)q, fd, num);        // exact
 			if (r != 0.0 && ((r < 0.0) != (num < 0.0))) q -= ((num < 0.0) != (fd < 0.0)) ? -1 : 1;
 			cut = (long long)p0 + q;

@@ -321,6 +321,9 @@ bool launch_twoview_rows_refill(hipStream_t st, int width, int oth_width, const 
 const char *rccl_unique_id_get(void *out128);
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);
 void rccl_comm_destroy(void *comm);
+void rccl_comm_abort(void *comm);
+void rccl_set_timeout_ms(int ms);      // how long a call into RCCL may stay "in progress" (rendezvous, collectives); default 120 s
+int  rccl_version();                   // NCCL_VERSION_CODE of the loaded librccl, 0 if there is none
 const char *rccl_gather_f64(void *comm, int nranks, int rank, int root, const double *send, double *recv,
                             size_t count, hipStream_t st);
 const char *rccl_allgather_f64(void *comm, const double *send, double *recv, size_t count, hipStream_t st);

@@ -12,6 +12,7 @@
 #include "project/imageset.hpp"         // ImageSet::defaultImageForCamera (project/imageset.hpp:83)
 #include "project/projectimage.hpp"     // ProjectImage::file (project/projectimage.hpp:41)
 #include "util/ray.hpp"                 // Ray3d::point
+#include "util/vectorimage.hpp"         // RGBA
 
 #include <cstring>
 
@@ -58,4 +59,18 @@ std::vector<Eigen::Vector3d> TwoViewStereo::epipolarCurve(const Ray3d &ray, cons
 	curve.reserve(pts.size());
 	for (size_t k = 0; k < pts.size(); ++k) curve.push_back(Eigen::Vector3d(pts[k][0], pts[k][1], pts[k][2]));
 	return curve;
+}
+
+// stereo/multiviewstereo.hpp:36-39 / multiviewstereo.cpp:291-315 with the reference's own types
+void outputPLYFile(const std::string &path, const std::vector<PLYPoint> &points) {
+	std::vector<double> xyz(points.size()*3);
+	std::vector<unsigned char> rgb(points.size()*3);
+	for (size_t i = 0; i < points.size(); ++i) {
+		for (int k = 0; k < 3; ++k) xyz[i*3 + k] = points[i].first[k];
+		// (the reference prints static_cast<int>(rgb.r): writePLY prints the byte as an int)
+		rgb[i*3 + 0] = static_cast<unsigned char>(static_cast<int>(points[i].second.r));
+		rgb[i*3 + 1] = static_cast<unsigned char>(static_cast<int>(points[i].second.g));
+		rgb[i*3 + 2] = static_cast<unsigned char>(static_cast<int>(points[i].second.b));
+	}
+	srq::writePLY(path, points.size(), xyz.data(), rgb.data());
 }

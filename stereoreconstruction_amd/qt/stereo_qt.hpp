@@ -22,6 +22,7 @@
 
 #include <array>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <memory>
@@ -34,12 +35,23 @@ FORWARD_DECLARE(Camera);
 FORWARD_DECLARE(ImageSet);
 class Ray3d;
 class VectorImage;
+struct RGBA;                            // util/vectorimage.hpp:28
 namespace Eigen {
 template <typename Scalar, int Rows, int Cols, int Options, int MaxRows, int MaxCols> class Matrix;   // (Eigen's own forward declaration, minus its defaults)
 typedef Matrix<double, 3, 1, 0, 3, 1> Vector3d;
 }
 
+// stereo/multiviewstereo.hpp:36-39, verbatim but for Ray3d::Point spelt as what it is (util/ray.hpp:32: Eigen::Vector3d).
+// Both are incomplete types here; outputPLYFile is DEFINED in the glue translation unit, over srq::writePLY below.
+typedef std::pair<Eigen::Vector3d, RGBA> PLYPoint;
+//! Output a set of points to a PLY file
+void outputPLYFile(const std::string &path, const std::vector<PLYPoint> &points);
+
 namespace srq {
+
+// the text outputPLYFile writes (multiviewstereo.cpp:291-315): ASCII header, then "x y z r g b" per point through
+// operator<< of an ofstream; xyz = 3 doubles per point, rgb = 3 bytes per point (the reference prints static_cast<int>(rgb.r))
+void writePLY(const std::string &path, size_t npoints, const double *xyz, const unsigned char *rgb);
 
 // VectorImage::fromQImage (util/vectorimage.cpp:48-64): the raw 32-bit scanline words as R,G,B,A bytes.  (A smooth-
 // scaled ARGB32 image is ARGB32_Premultiplied; the reference reads it raw, and so does this.)  Images that are not
@@ -101,7 +113,7 @@ public:
 	srh_params &params() { return params_; }
 	QString lastError() const { return error_; }
 
-protected:
+public: // Task implementation continued: public in the reference as well (stereo/twoviewstereo.hpp:50-52)
 	void runTask() { computeDepthMaps(); }
 
 private:

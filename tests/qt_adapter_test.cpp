@@ -102,6 +102,17 @@ int main(int argc, char **argv) {
 		printf("ingest %dx%d\n", img.w, img.h);
 		return 0;
 	}
+	if (argc >= 3 && !strcmp(argv[1], "ply")) {
+		// the reference's free function with its own signature (stereo/multiviewstereo.hpp:36-39), and runTask() called
+		// from outside the class as the reference allows (stereo/twoviewstereo.hpp:52: public)
+		std::vector<PLYPoint> pts;
+		pts.push_back(PLYPoint(Eigen::Vector3d(1.5, -2.25, 1e-7), RGBA(255, 0, 17)));
+		pts.push_back(PLYPoint(Eigen::Vector3d(123456.789, 0.1, 3.0), RGBA(1.9, 254.2, 128)));
+		outputPLYFile(argv[2], pts);
+		void (TwoViewStereo::*rt)() = &TwoViewStereo::runTask;
+		printf("ply %d\n", rt != nullptr ? 1 : 0);
+		return 0;
+	}
 	if (argc >= 4 && !strcmp(argv[1], "twoview")) {
 		// spec: w h minDepth maxDepth levels scale left.raw right.raw leftmask.raw|- rightmask.raw|-  then two cameras
 		std::ifstream in(argv[2]);

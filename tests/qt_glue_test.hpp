@@ -36,6 +36,7 @@ private:
 // the curve query's arguments: the test's ray simply remembers the pixel it was cast from
 class Ray3d { public: int x, y; Ray3d(int x_, int y_) : x(x_), y(y_) { } };
 class VectorImage { };
+struct RGBA { double r, g, b, a; RGBA(double r_ = 0, double g_ = 0, double b_ = 0, double a_ = 255) : r(r_), g(g_), b(b_), a(a_) { } };
 namespace Eigen {
 template <typename Scalar, int Rows, int Cols, int Options, int MaxRows, int MaxCols> class Matrix {
 public:
@@ -60,4 +61,17 @@ std::vector<Eigen::Vector3d> TwoViewStereo::epipolarCurve(const Ray3d &ray, cons
 	std::vector<Eigen::Vector3d> curve;
 	for (size_t k = 0; k < pts.size(); ++k) curve.push_back(Eigen::Vector3d(pts[k][0], pts[k][1], pts[k][2]));
 	return curve;
+}
+
+// stereo/multiviewstereo.hpp:36-39 over the test driver's types (the reference's: qt/glue_reference.cpp)
+void outputPLYFile(const std::string &path, const std::vector<PLYPoint> &points) {
+	std::vector<double> xyz(points.size()*3);
+	std::vector<unsigned char> rgb(points.size()*3);
+	for (size_t i = 0; i < points.size(); ++i) {
+		for (int k = 0; k < 3; ++k) xyz[i*3 + k] = points[i].first[k];
+		rgb[i*3 + 0] = static_cast<unsigned char>(static_cast<int>(points[i].second.r));
+		rgb[i*3 + 1] = static_cast<unsigned char>(static_cast<int>(points[i].second.g));
+		rgb[i*3 + 2] = static_cast<unsigned char>(static_cast<int>(points[i].second.b));
+	}
+	srq::writePLY(path, points.size(), xyz.data(), rgb.data());
 }

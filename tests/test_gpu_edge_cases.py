@@ -309,6 +309,43 @@ def test_band_budget_follows_free_memory_and_survives_allocation_failures(hip_ct
         hip_ctx.set_option("band_budget_mb", 32768)               # (forgets the halvings)
 
 
+def test_queued_view_with_a_cut_list_survives_the_oom_retry_of_the_next_call(hip_ctx):
+    """A MultiViewStereo view queued with a list capacity that turns out too small is redone when its slot is settled.
+    When the NEXT call runs out of memory in between, with_thinner_bands drains everything and releases the band buffers:
+    the queued view must still get its capacity check (round-4 advisor: it was dropped, leaving a depth map made from cut
+    lists).  View 0 is queued on 8 rows (small buffers: below the debug allocation limit) with a capacity hint of 8
+    candidates; view 1's full-height call is refused its buffers and retried with thinner bands."""
+    mv = cases.get_mvs("mvs_geodesic", nviews=3, w=128, h=96, D=24)
+    cams, p = cases.hip_inputs(mv)
+    neigh = capi.mvs_neighbours(cams, p)
+    cases.upload_case(hip_ctx, mv, cams)
+    hip_ctx.set_option("mvs_async", 0)
+    try:
+        hip_ctx.mvs_initial_estimate(0, neigh[0], p, 0, 8)
+        want0 = hip_ctx.download_depth(0)[:8].copy()
+        hip_ctx.mvs_initial_estimate(1, neigh[1], p)
+        want1 = hip_ctx.download_depth(1)
+    finally:
+        hip_ctx.set_option("mvs_async", 1)
+    cases.upload_case(hip_ctx, mv, cams)                          # (fresh depth maps)
+    st0 = hip_ctx.stats()
+    try:
+        hip_ctx.set_option("band_budget_mb", 32768)
+        hip_ctx.set_option("debug_alloc_limit_mb", 1)
+        hip_ctx.set_option("debug_mvs_cmax_hint", 8)              # far below the ~50 candidates of a curve here
+        hip_ctx.mvs_initial_estimate(0, neigh[0], p, 0, 8)        # queued on slot 0: lists cut at 8 entries
+        hip_ctx.mvs_initial_estimate(1, neigh[1], p)              # slot 1: buffers refused -> drained, released, retried
+        got1 = hip_ctx.download_depth(1)
+        got0 = hip_ctx.download_depth(0)[:8]
+        assert hip_ctx.stats()["band_retries"] > st0["band_retries"]
+    finally:
+        hip_ctx.set_option("debug_alloc_limit_mb", 0)
+        hip_ctx.set_option("debug_mvs_cmax_hint", 0)
+        hip_ctx.set_option("band_budget_mb", 32768)
+    assert np.array_equal(_bits(got0), _bits(want0))
+    assert np.array_equal(_bits(got1), _bits(want1))
+
+
 def test_two_contexts_share_one_gpu(hip_ctx):
     """A second context on the same GPU (a GUI host beside a batch job, the loopback transport's shards): each plans its
     bands from what is free when it runs; both give the same bits."""

@@ -49,6 +49,20 @@ def test_ingest_of_the_example_images_equals_the_fixture():
 
 
 @needs_bin
+def test_output_ply_file_with_the_reference_signature():
+    """outputPLYFile(const std::string &, const std::vector<PLYPoint> &) with PLYPoint = std::pair<Ray3d::Point, RGBA>
+    (stereo/multiviewstereo.hpp:36-39) through the Qt binding's header: the text of multiviewstereo.cpp:291-315
+    (operator<< of an ofstream: six significant digits; colours as static_cast<int>)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "p.ply")
+        assert _run("ply", out)["ply"] == "1"
+        want = ("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
+                "property uchar diffuse_red\nproperty uchar diffuse_green\nproperty uchar diffuse_blue\nend_header\n"
+                "1.5 -2.25 1e-07 255 0 17\n123457 0.1 3 1 254 128\n")
+        assert open(out).read() == want
+
+
+@needs_bin
 def test_ingest_alpha_rule_and_opaque_images():
     """alpha == 255 <=> mask WHITE, decided on a fast-scaled copy; an image without alpha channel gets an all-WHITE mask."""
     from PIL import Image
