@@ -706,7 +706,8 @@ def main():
 
     if args.workload == "c4":
         result = run_c4(args, rank, world, dev, dev_index, backend)
-        result["comm"] = comm
+        if result is not None:
+            result["comm"] = comm
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -715,7 +716,8 @@ def main():
         return
 
     result = run_twoview(args, args.workload, rank, world, dev, dev_index, backend)
-    result["comm"] = comm
+    if result is not None:
+        result["comm"] = comm
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_configs and args.arith in ("certified", "exact"):
         result["configs"] = other_configs(args, rank, world, dev, dev_index, backend)
     if world > 1:

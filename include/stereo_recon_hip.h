@@ -133,6 +133,17 @@ int  srh_camera_from_krt(const double K[9], const double R[9], const double t[3]
 int  srh_camera_from_p(const double P[12], const double dist[5],
                        const double plane_normal[3], double plane_dist, double refr_index,
                        srh_camera *out);
+/* The certified arithmetic's error bound (option "arith" = 3) for these parameters, host arithmetic only:
+ * a fast-form candidate with A = sqrt(sum2), B = sqrt(sum3) has |cost_fused - cost_reference| <= k1/B + k2/A + k3, and is
+ * certified when that is <= e0, i.e. sum3 >= srh_cert_sigma3(p, mvs, sum2); the one-pass form also needs
+ * Q3 <= zmax2*sum3.  m_hi = max_color_diff + e0; ok = 0: the parameters leave the bound no room (the reference's
+ * arithmetic runs).  mvs != 0: the free cost_ncc of MultiViewStereo (score itself, e0 = 2^-36). */
+typedef struct srh_cert_info {
+	double e0, k1, k2, k3, zmax2, m_hi;
+	int32_t ok, taps;
+} srh_cert_info;
+int    srh_cert_bound(const srh_params *p, int mvs, srh_cert_info *out);
+double srh_cert_sigma3(const srh_params *p, int mvs, double sum2);
 /* MultiViewStereo::runTask neighbour selection (multiviewstereo.cpp:335-360):
  * neigh[v*p->num_neighbours + k], count[v]. */
 int  srh_mvs_neighbours(int nviews, const srh_camera *cams, const srh_params *p,
@@ -219,6 +230,16 @@ int  srh_twoview_wta(srh_context *ctx, int ref_slot, int oth_slot, const srh_par
                      int y0, int y1);
 /* crossCheck (twoviewstereo.cpp:596-672): left pass, then right pass reading the
  * filtered left map; in place on the two slots' depth maps. */
+/* DIAGNOSTIC (evidence for the certified arithmetic, tests/test_gpu_cert_rows.py): the cost rows of reference rows
+ * [y0, y1) on the row-aligned dense plan as the cost kernel leaves them -- what the scan looks up.  form: 0 = the
+ * reference's arithmetic, 3 = two fused sweeps, 5 = one-pass (the certified forms), 1 = fused unchecked; raw != 0: the
+ * certified forms WITHOUT their in-kernel exact redo (an uncertified candidate is NaN).  Layout of cost_out (doubles):
+ * [row][tile of 32 pixels][k = column - range.lo, < *cstride_out][pixel of the tile]; an entry the kernels never wrote
+ * reads as a NaN with all bits set.  range_out: (lo, hi) per pixel, hi < lo = no candidates.  cost_out == NULL: only
+ * *cstride_out (to size the buffer: rows * ceil(w/32)*32 * cstride doubles).  The rows must fit one band;
+ * SRH_E_UNSUPPORTED when the pair does not take the dense plan. */
+int  srh_twoview_cost_rows(srh_context *ctx, int ref_slot, int other_slot, const srh_params *p, int y0, int y1, int form, int raw,
+                           double *cost_out, size_t cost_doubles, int32_t *range_out, int *cstride_out, int *used_strip_kernel);
 int  srh_twoview_cross_check(srh_context *ctx, int left_slot, int right_slot, const srh_params *p);
 /* computeDepthMaps minus colourisation (twoviewstereo.cpp:150-227): both passes +
  * cross-check, progress steps 1,3,5,8; synchronous; host outputs may be NULL.  The two passes

@@ -81,11 +81,11 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
 EXPORTS = [
     "srh_abi_version", "srh_build_id", "srh_last_error", "srh_device_count", "srh_hw_queues_requested",
     "srh_params_twoview_defaults", "srh_params_mvs_defaults", "srh_camera_from_krt", "srh_camera_from_p",
-    "srh_mvs_neighbours",
+    "srh_mvs_neighbours", "srh_cert_bound", "srh_cert_sigma3",
     "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
-    "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute",
+    "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute", "srh_twoview_cost_rows",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
     "srh_epipolar_preview", "srh_refraction_error",
     "srh_mrf_params_defaults", "srh_mvs_mrf_estimate", "srh_mvs_mrf_state", "srh_mvs_mrf_dims", "srh_mvs_initial_estimate_mrf",
@@ -95,6 +95,11 @@ EXPORTS = [
     "srh_comm_destroy", "srh_comm_set_timeout_ms", "srh_comm_version", "srh_comm_info",
     "srh_get_stats", "srh_profile_enable", "srh_profile_reset", "srh_profile_get", "srh_profile_dump",
 ]
+
+
+class CertInfo(C.Structure):
+    _fields_ = [("e0", C.c_double), ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double), ("zmax2", C.c_double),
+                ("m_hi", C.c_double), ("ok", C.c_int32), ("taps", C.c_int32)]
 
 
 class StereoHipError(RuntimeError):
@@ -128,6 +133,9 @@ def lib():
                                       C.c_double, C.c_double, C.POINTER(Camera)]
     L.srh_camera_from_p.argtypes = [c_double_p, c_double_p, c_double_p, C.c_double, C.c_double, C.POINTER(Camera)]
     L.srh_mvs_neighbours.argtypes = [C.c_int, C.POINTER(Camera), C.POINTER(Params), c_int32_p, c_int32_p]
+    L.srh_cert_bound.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(CertInfo)]
+    L.srh_cert_sigma3.argtypes = [C.POINTER(Params), C.c_int, C.c_double]
+    L.srh_cert_sigma3.restype = C.c_double
     L.srh_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.srh_destroy.argtypes = [vp]
     L.srh_destroy.restype = None
@@ -157,6 +165,8 @@ def lib():
     L.srh_view_depth_copy_from_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.srh_twoview_wta.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
     L.srh_twoview_cross_check.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params)]
+    L.srh_twoview_cost_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, C.c_size_t,
+                                        c_int32_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
     L.srh_mvs_initial_estimate.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.c_int, C.c_int, vp]
     L.srh_mvs_cross_check.argtypes = [vp, c_int32_p, C.c_int, C.c_int, C.POINTER(Params)]
@@ -261,6 +271,18 @@ def comm_version():
 
 def comm_set_timeout_ms(ms):
     _check(lib().srh_comm_set_timeout_ms(int(ms)))
+
+
+def cert_bound(p, mvs=False):
+    """srh_cert_bound: the constants of the certified arithmetic's error bound for these parameters, as a dict."""
+    ci = CertInfo()
+    _check(lib().srh_cert_bound(C.byref(p), 1 if mvs else 0, C.byref(ci)))
+    return {k: getattr(ci, k) for k, _ in CertInfo._fields_}
+
+
+def cert_sigma3(p, sum2, mvs=False):
+    """srh_cert_sigma3: the smallest sum3 for which a candidate of a pixel with this sum2 is certified (+inf: none)."""
+    return float(lib().srh_cert_sigma3(C.byref(p), 1 if mvs else 0, float(sum2)))
 
 
 def hw_queues_requested():
@@ -395,6 +417,20 @@ class Context:
         _check(lib().srh_twoview_compute(self._h, left_slot, right_slot, C.byref(p), None, None))
 
     # -- MultiViewStereo
+    def twoview_cost_rows(self, ref, oth, p, y0, y1, form, raw=False):
+        """srh_twoview_cost_rows (diagnostic) -> (cost (rows, w, cstride) float64 with cost[r, x, k] the cost of column
+        lo + k, range (rows, w, 2) int32, used_strip_kernel)."""
+        w, h = self.view_size(ref)
+        cs, us = C.c_int(0), C.c_int(0)
+        _check(lib().srh_twoview_cost_rows(self._h, ref, oth, C.byref(p), y0, y1, form, 1 if raw else 0, None, 0, None, C.byref(cs), C.byref(us)))
+        rows, tiles = y1 - y0, (w + 31) // 32
+        buf = np.empty((rows, tiles, cs.value, 32), dtype=np.float64)
+        rng = np.empty((rows, w, 2), dtype=np.int32)
+        _check(lib().srh_twoview_cost_rows(self._h, ref, oth, C.byref(p), y0, y1, form, 1 if raw else 0, _dptr(buf), buf.size,
+                                           rng.ctypes.data_as(c_int32_p), C.byref(cs), C.byref(us)))
+        cost = np.ascontiguousarray(buf.transpose(0, 1, 3, 2)).reshape(rows, tiles * 32, cs.value)[:, :w]
+        return cost, rng, bool(us.value)
+
     def mvs_initial_estimate(self, view_slot, neigh_slots, p, y0=0, y1=0, peaks_dev=None):
         ng = np.ascontiguousarray(neigh_slots, dtype=np.int32)
         _check(lib().srh_mvs_initial_estimate(self._h, view_slot, ng.ctypes.data_as(c_int32_p), len(ng),

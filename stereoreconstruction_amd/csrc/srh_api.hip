@@ -172,6 +172,9 @@ struct srh_context {
 	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
+	// srh_twoview_cost_rows (diagnostic): the dense plan stops after the cost kernel of its one band and hands the rows out
+	struct Diag { int form = 0; bool raw = false; double *cost = nullptr; size_t cost_doubles = 0; int32_t *range = nullptr;
+	              int cstride = 0, rows = 0; bool done = false, strip = false; } *diag = nullptr;
 	std::map<std::string, ProfEntry> prof;
 	std::vector<PendingEvt> pending;
 	srh_stats stats;
@@ -309,6 +312,22 @@ extern "C" void srh_params_twoview_defaults(srh_params *p) {
 extern "C" void srh_params_mvs_defaults(srh_params *p) {
 	srh_params_twoview_defaults(p);
 	p->window_radius = 2;                 // multiviewstereo.cpp:91
+}
+
+// The constants of the certified arithmetic's error bound for these parameters (srh_internal.hpp, CertBound; DESIGN.md
+// 2b): host arithmetic only -- what tests/test_cert_bound.py checks against an exact replay of the three arithmetics.
+extern "C" int srh_cert_bound(const srh_params *p, int mvs, srh_cert_info *out) {
+	if (!p || !out) return fail(SRH_E_INVALID, "null argument");
+	if (p->window_radius < 1 || p->window_radius > 15) return fail(SRH_E_INVALID, "window_radius %d outside [1,15]", p->window_radius);
+	const CertBound c = cert_bound(*p, mvs != 0);
+	out->e0 = c.e0; out->k1 = c.k1; out->k2 = c.k2; out->k3 = c.e0 - c.room; out->zmax2 = c.zmax2; out->m_hi = c.m_hi;
+	out->ok = c.ok; out->taps = (2*p->window_radius + 1)*(2*p->window_radius + 1);
+	return SRH_OK;
+}
+
+extern "C" double srh_cert_sigma3(const srh_params *p, int mvs, double sum2) {
+	if (!p || p->window_radius < 1 || p->window_radius > 15) return __builtin_nan("");
+	return cert_bound(*p, mvs != 0).sigma3(sum2);
 }
 
 static bool near_zero(double x) { return (x <= 1e-10 && x >= -1e-10); }   // camera.cpp:51-52
@@ -1027,9 +1046,12 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 	// strip kernel does not run, or the parameters leave the bound no room, the reference's arithmetic
 	bool cert_ok = c->arith == 3 && cert_bound(*p).ok != 0;
 	c->stats.n_certified = c->stats.n_flagged = 0;
-	// the exact redo of flagged pixels is launched for a fixed capacity (the host does not wait for the count): a band
-	// that flags more (adversarial images: exact ties everywhere) makes the whole pass run again in mode 0
-	auto redo_capacity = [](size_t band_pixels) { return (int)std::min<size_t>(std::max<size_t>(band_pixels/32, 256), 16384); };
+	// The exact redo of flagged pixels is launched for a CAPACITY -- the whole band: the list buffer holds every pixel of it,
+	// the redo kernels share the list in grid-stride loops and read the count on the device -- so however many pixels flag
+	// (adversarial images: exact ties everywhere) each is redone once, the host never waits for the count, and no pass is
+	// ever repeated as a whole for it.  (Round 4 launched for 1/32 of the band, at most 16 384 pixels, and repeated the
+	// whole pass in mode 0 beyond that: a cliff at 0.79 % of C3.)
+	auto redo_capacity = [](size_t band_pixels) { return (int)std::min<size_t>(band_pixels, (size_t)1 << 30); };
 	for (int attempt = 0; attempt < 4; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		// ---- arbitrary geometry: candidate lists (the one-thread-per-pixel walk kernel is the last resort)
@@ -1251,7 +1273,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						{ Scope s(c, "twoview_strip_cost_kernel");
 						  launch_twoview_strip_cost(c->stream, c->d_views, ref, oth, W, H, *p, by, nr, c->wbuf, c->pconst, c->prange,
 						                            c->views[ref].tvp, c->views[oth].tvp, c->views[oth].fullp, c->cost, cstride,
-						                            c->d_cnt, arith, c->num_cus, lanes); }
+						                            c->d_cnt, arith, c->num_cus, lanes, c->diag && c->diag->raw); }
 						Scope s(c, "twoview_lazy_fill_kernel");
 						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
 						                         c->views[ref].tvp, c->views[oth].tvp, true, lanes, lanes == 8, c->cost, cstride, c->d_cnt);
@@ -1270,11 +1292,29 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					}
 					return SRH_OK;
 				};
+				if (c->diag) {
+					// diagnostic: this band's cost rows under the arithmetic asked for, as the cost kernel leaves them (raw: the
+					// certified forms without the in-kernel exact redo, NaN where uncertified), and the pixels' column ranges
+					srh_context::Diag &dg = *c->diag;
+					dg.cstride = cstride; dg.rows = nr; dg.strip = strip;
+					const size_t nd = (size_t)nr*((W + 31)/32)*32*(size_t)cstride;
+					if (by != y0 || nr != y1 - y0) return fail(SRH_E_UNSUPPORTED, "cost rows: the rows asked for do not fit one band (%d of %d)", nr, y1 - y0);
+					if (dg.cost) {
+						if (dg.cost_doubles < nd) return fail(SRH_E_INVALID, "cost rows: buffer of %zu doubles, %zu needed", dg.cost_doubles, nd);
+						HIP_TRY(hipMemsetAsync(c->cost, 0xff, nd*sizeof(double), c->stream));   // (never-written entries read as a NaN with payload -1)
+						if ((rc = cost_pass(dg.form))) return rc;
+						HIP_TRY(hipMemcpyAsync(dg.cost, c->cost, nd*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+						if (dg.range) HIP_TRY(hipMemcpyAsync(dg.range, c->prange, (size_t)nr*W*sizeof(PixRange), hipMemcpyDeviceToHost, c->stream));
+						HIP_TRY(hipStreamSynchronize(c->stream));
+					}
+					dg.done = true;
+					return SRH_OK;
+				}
 				if (cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 				if ((rc = cost_pass(cost_arith))) return rc;
 				{ Scope s(c, "twoview_scan_kernel");
 				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
-				                      cert ? c->cflag : nullptr, -1); }
+				                      cert ? c->cflag : nullptr, -1, cert && strip ? c->pconst : nullptr); }
 				if (cert) {
 					// the pixels whose decisions the bound does not cover, in the reference's arithmetic: their cost rows are
 					// refilled and they are scanned again -- launched for a capacity, the count stays on the device
@@ -1314,6 +1354,31 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 	}
 	c->stats.used_strip_kernel = strip ? 1 : 0;
 	c->stats.used_dense_path = dense ? 1 : 0;
+	return SRH_OK;
+}
+
+// Diagnostic (tests/test_gpu_cert_rows.py): the cost rows of rows [y0, y1) on the row-aligned dense plan, straight from the
+// cost kernel -- what the scan would look up.  form: 0 the reference's arithmetic, 3 two fused sweeps, 5 one-pass (the
+// certified forms); raw != 0: without the in-kernel exact redo (uncertified candidates are NaN).
+extern "C" int srh_twoview_cost_rows(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1, int form, int raw,
+                                     double *cost_out, size_t cost_doubles, int32_t *range_out, int *cstride_out, int *used_strip)
+{
+	int rc;
+	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
+	if (form != 0 && form != 3 && form != 5 && form != 1) return fail(SRH_E_INVALID, "form must be 0, 1, 3 or 5");
+	if ((form == 3 || form == 5) && !cert_bound(*p).ok) return fail(SRH_E_UNSUPPORTED, "the parameters leave the error bound no room");
+	srh_context::Diag dg;
+	dg.form = form; dg.raw = raw != 0; dg.cost = cost_out; dg.cost_doubles = cost_doubles; dg.range = range_out;
+	c->diag = &dg;
+	const int keep_arith = c->arith; const bool keep_fused = c->use_fused;
+	c->arith = form == 0 ? 0 : 3; c->use_fused = false;
+	rc = twoview_wta_run(c, ref, oth, p, y0, y1);
+	c->arith = keep_arith; c->use_fused = keep_fused;
+	c->diag = nullptr;
+	if (rc) return rc;
+	if (!dg.done) return fail(SRH_E_UNSUPPORTED, "cost rows exist on the row-aligned dense plan only (radius 5 or 2, rectified pinhole pair)");
+	if (cstride_out) *cstride_out = dg.cstride;
+	if (used_strip) *used_strip = dg.strip ? 1 : 0;
 	return SRH_OK;
 }
 

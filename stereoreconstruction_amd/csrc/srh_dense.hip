@@ -1152,9 +1152,9 @@ bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y
 {
 	if (cap <= 0) return true;
 	if (P.window_radius == 5)
-		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)(cap < 512 ? cap : 512)), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_refill_kernel<5>, dim3((unsigned)(cap < 8192 ? cap : 8192)), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
 	else if (P.window_radius == 2)
-		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)(cap < 512 ? cap : 512)), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
+		hipLaunchKernelGGL(twoview_refill_kernel<2>, dim3((unsigned)(cap < 8192 ? cap : 8192)), dim3(64), 0, st, width, P, y0, prange, cflag, cap, wbuf, wimg ? 1 : 0, ref_tvp, oth_tvp, cost, cstride, cnt);
 	else return false;
 	return true;
 }
@@ -1222,7 +1222,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
                          int y0, int nrows, const double *__restrict__ tnum,
                          const double *__restrict__ cost, int cstride,
                          Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
-                         uint32_t *__restrict__ cflag, int nlist, CertBound cb)
+                         uint32_t *__restrict__ cflag, int nlist, CertBound cb, const double *__restrict__ pexact)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
@@ -1289,6 +1289,11 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 		const double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
 		TwoViewScanState st = { __builtin_inf(), __builtin_inf(), -1 };
 		int qn = 0;
+		// pexact (the band's per-pixel constants, given when the cost kernel redoes uncovered candidates in place): a pixel the
+		// cost kernel evaluated in the reference's arithmetic throughout (cert_pixel_exact) -- every stored cost is the
+		// reference's own number, every comparison on them is the reference's
+		bool px_sure = false;
+		if (CERT && pexact) { const double *pc = pexact + ((size_t)trow*W + x)*4; px_sure = cert_pixel_exact(cb, pc[2], pc[3]); }
 
 		// consume `count` queued candidates (count == SC_QN except for the final, partial flush)
 		auto flush = [&](int count) {
@@ -1314,7 +1319,8 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 						// cost, a clamp or a bad_ret of magnitude <= 1e5 -- CertBound::ok)
 						const double t = cv + P.wta_margin;
 						if (!(fabs(t - st.minCost) > 2.5*cb.e0) && col[k] != st.wcol &&
-						    !(cert_sure(cv, P.max_color_diff, cb.m_hi) && cert_sure(st.minCost, P.max_color_diff, cb.m_hi))) n_flag = 1;   // (NaN: flagged)
+						    !(cert_sure(cv, P.max_color_diff, cb.m_hi) && cert_sure(st.minCost, P.max_color_diff, cb.m_hi)) &&
+						    !(px_sure && cv == cv)) n_flag = 1;              // (NaN: flagged, whatever the pixel)
 					}
 					if (cv + P.wta_margin < st.minCost) {           // twoviewstereo.cpp:293-301
 						st.secondBest = st.minCost;
@@ -1391,7 +1397,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 			// the ratio test (twoviewstereo.cpp:303-305) on fused values: minCost within e0, factor*secondBest within |factor|*e0
 			const double rhs = P.second_best_factor*st.secondBest;
 			const double tol = __builtin_fma(fmin(fabs(rhs), 1e300), 1e-15, (1.0 + fabs(P.second_best_factor))*cb.e0);
-			if (!(fabs(st.minCost - rhs) > tol) &&
+			if (!(fabs(st.minCost - rhs) > tol) && !px_sure &&
 			    !(cert_sure(st.minCost, P.max_color_diff, cb.m_hi) && cert_sure(st.secondBest, P.max_color_diff, cb.m_hi))) n_flag = 1;
 		}
 		if (CERT && n_flag) cflag[1 + atomicAdd(&cflag[0], 1u)] = (uint32_t)((size_t)trow*W + x);
@@ -1524,22 +1530,23 @@ void twoview_rescan_wave_kernel(const ViewDev *__restrict__ views, int ref, int 
 // exact scan of the nlist pixels listed in cflag[1..].
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         Counters *cnt, const PixRange *prange, uint32_t *cflag, int nlist)
+                         Counters *cnt, const PixRange *prange, uint32_t *cflag, int nlist, const double *pexact)
 {
 	const int tiles = (width + SC_TW - 1)/SC_TW;
 	const CertBound cb = cert_bound(P);
 	if (!cflag)
 		hipLaunchKernelGGL((twoview_scan_kernel<false, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, nullptr, 0, cb);
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, nullptr, 0, cb, nullptr);
 	else if (nlist < 0)
 		hipLaunchKernelGGL((twoview_scan_kernel<true, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, 0, cb);
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, 0, cb, pexact);
 	else if (nlist > 0 && P.num_depth_levels <= RSW_MAXD && cstride <= 4096)
-		hipLaunchKernelGGL(twoview_rescan_wave_kernel, dim3((unsigned)(nlist < 256 ? nlist : 256)), dim3(64), 0, st,
+		// (the list may hold up to the band's pixels: workgroups share it in a grid-stride loop, the count is read on the device)
+		hipLaunchKernelGGL(twoview_rescan_wave_kernel, dim3((unsigned)(nlist < 2048 ? nlist : 2048)), dim3(64), 0, st,
 		                   views, ref, oth, P, y0, tnum, cost, cstride, prange, cflag, nlist, cnt);
 	else if (nlist > 0)
 		hipLaunchKernelGGL((twoview_scan_kernel<false, true>), dim3((unsigned)((nlist + SC_TW - 1)/SC_TW)), dim3(SC_TW), 0, st,
-		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb);
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb, nullptr);
 }
 
 } // namespace srh

@@ -102,6 +102,12 @@ struct CertBound {
 };
 // certified scan: is this stored cost the very number the reference's arithmetic gives?  (+inf: the initial minCost / secondBest)
 __host__ __device__ inline bool cert_sure(double x, double clamp, double m_hi) { return x == clamp || x > m_hi; }
+// certified cost kernels with the in-kernel redo (strip kernel): a pixel with unusable taps of its own (every candidate in
+// a select form) or whose own window leaves the bound no room (sigma3 = +inf) is evaluated in the reference's arithmetic
+// throughout -- the certified scan treats every stored cost of such a pixel as the reference's very number
+__host__ __device__ inline bool cert_pixel_exact(const CertBound &cb, double sum2, double all_taps_usable) {
+	return !(all_taps_usable != 0.0) || !(cb.sigma3(sum2) < __builtin_inf());
+}
 // mvs: the free cost_ncc of MultiViewStereo (multiviewstereo.cpp:113-189): the score sum1/sqrt(sum2*sum3) itself (no factor
 // 255, no clamp), 25 taps at the reference's radius; e0 = 2^-36 there (scores live in [-1, 1])
 inline CertBound cert_bound(const srh_params &P, bool mvs = false) {
@@ -200,7 +206,8 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 // (launch sized for nlist pixels, the count itself is read on the device)
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         Counters *cnt, const PixRange *prange, uint32_t *cflag = nullptr, int nlist = -1);
+                         Counters *cnt, const PixRange *prange, uint32_t *cflag = nullptr, int nlist = -1,
+                         const double *pexact = nullptr);   // certified scan: the band's pconst when the cost kernel applies cert_pixel_exact
 // the cost rows of the flagged pixels in the reference's arithmetic; `cap` workgroups (the count is read on the device;
 // a count above cap is reported in Counters::cert_overflow); wimg: LDS-image windows, else tile-major
 bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int cap,
@@ -224,7 +231,7 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const srh_params &P, int y0, int nrows, const double *wimg, const double *pconst,
                                const PixRange *prange, const double *ref_tvp, const double *oth_tvp,
                                const uint8_t *oth_fullp, double *cost, int cstride, Counters *cnt, int arith, int num_cus,
-                               int lanes);
+                               int lanes, bool raw = false);   // raw (diagnostics): certified forms without the in-kernel exact redo
 
 #ifdef SRH_PROFILE_PHASES
 void geodesic_phases_fetch(unsigned long long out[5]);

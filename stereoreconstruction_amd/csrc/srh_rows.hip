@@ -676,7 +676,7 @@ bool launch_twoview_rows_refill(hipStream_t st, int width, int oth_width, const 
                                 const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt)
 {
 	if (cap <= 0) return true;
-#define SRH_RR(RR) case RR: hipLaunchKernelGGL(twoview_rows_refill_kernel<RR>, dim3((unsigned)(cap < 256 ? cap : 256)), dim3(256), 0, st, width, P, y0, cflag, cap, \
+#define SRH_RR(RR) case RR: hipLaunchKernelGGL(twoview_rows_refill_kernel<RR>, dim3((unsigned)(cap < 4096 ? cap : 4096)), dim3(256), 0, st, width, P, y0, cflag, cap, \
 	                                           wbuf, ref_tvp, oth_tvp, oth_width, rowinfo, meta, cost, smax, cnt); return true;
 	switch (P.window_radius) { SRH_RR(1) SRH_RR(2) SRH_RR(3) SRH_RR(4) SRH_RR(5) default: return false; }
 #undef SRH_RR

@@ -23,6 +23,8 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
+#include <type_traits>
+
 namespace srh {
 
 #ifdef SRH_EXPERIMENT
@@ -125,6 +127,7 @@ struct StripArgs {
 	int nitems;
 	double weight_cutoff, bad_ret, max_color_diff;
 	CertBound cb;                           // certified arithmetic (AR == 3): the constants of the error bound, srh_internal.hpp
+	int redo;                               // certified forms: 1 = uncovered candidates re-evaluated in place in the reference's arithmetic (default); 0 = raw
 };
 
 template <int R, int NBUF>
@@ -533,6 +536,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 			const bool lall = CS.pc[cur][i][3] != 0.0;
 			// certified arithmetic: the smallest sum3 of a candidate of this pixel for which the bound holds (from its sum2)
 			const double sig3 = CERT ? A.cb.sigma3(CS.pc[cur][i][2]) : 0.0;
+			const bool pix_exact = CERT && A.redo && !(sig3 < __builtin_inf());   // (cert_pixel_exact: the scan applies the same test)
 			const size_t tile = (size_t)r*tiles_per_row + tx;
 			ST_STAMP(3);                               // ranges, (re)staging, requests for the next tile, form of the tile
 			if (e_max >= e_min) {
@@ -558,7 +562,135 @@ void twoview_strip_cost_kernel(const StripArgs A)
 						const int c = c0 + j;
 						if (c >= lo && c <= hi && rfull[rc + j] != 0) { fast = true; ++n_dev; }
 					}
-					if (fast && ONEPASS) {
+					// certified forms: a candidate the bound does not cover is NOT left to the scan (which would flag the whole pixel
+					// for the per-pixel redo): its block is evaluated once more, here and now, in the reference's arithmetic, while the
+					// window and the rows are in LDS.  And a pixel whose own window leaves the bound no room at all (sigma3 = +inf: a
+					// flat window, sum2 ~ 0) takes the reference's arithmetic straight away -- the scan knows such a pixel's stored
+					// values are the reference's very numbers (cert_pixel_exact).  A.redo = 0 (diagnostics): raw fused values, NaN
+					// where uncertified.
+					bool bad_blk = false;
+					// the reference's two sweeps over the window for the block at c0 (FMAc: with fused multiply-adds; CERTc: values
+					// stored for the certified scan, `bad_blk` raised when a candidate's bound is not covered)
+					auto two_sweeps = [&](auto fma_c, auto cert_c) {
+						constexpr bool FMAc = decltype(fma_c)::value, CERTc = decltype(cert_c)::value;
+						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
+						// Both passes are modulo-scheduled by hand (see twoview_dense_cost_kernel): a register is refilled
+						// with the next row's value right after its last use, so the LDS latency is always a row ahead.
+						double r_[NR], wv_[WS], acc[NCB];
+						{
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + s0*RW + rc);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][0][i][0]);
+#pragma unroll
+							for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+#pragma unroll
+							for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv_[2*m] = v.x; wv_[2*m + 1] = v.y; }
+							wv_[WS - 1] = CS.w[wcur][0][i][WS - 1];
+						}
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) acc[j] = 0.0;
+						__builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the pre-header's reads have landed
+#pragma unroll 1
+						for (int row = 0; row < WS; ++row) {
+							int seen = 0;
+							prog_step(1, seen);
+							const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for pass 2
+							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								if (FMAc) {
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) acc[j] = __builtin_fma(wv_[col], r_[col + j], acc[j]);
+								} else {
+									double pr[NCB];
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) pr[j] = wv_[col]*r_[col + j];
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) acc[j] += pr[j];        // meanR += weight*gray
+								}
+								__builtin_amdgcn_sched_barrier(0);
+								if (col & 1) {
+									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
+									const double2 u = wp[col >> 1]; wv_[col - 1] = u.x; wv_[col] = u.y;
+									__builtin_amdgcn_sched_barrier(0);
+								}
+							}
+#pragma unroll
+							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+							wv_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
+							prog_yield(seen);
+						}
+						double mR[NCB], s1[NCB], s3[NCB], av[WS];
+#pragma unroll
+						for (int col = 0; col < WS; ++col) av[col] = CS.lt[s0][i + col];
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) { mR[j] = acc[j]/tw; s1[j] = 0.0; s3[j] = 0.0; }
+						__builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll 1
+						for (int row = 0; row < WS; ++row) {
+							int seen = 0;
+							prog_step(3, seen);
+							const int nrow = row + 1 < WS ? row + 1 : 0;
+							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
+							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
+							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
+							const double *lp = &CS.lt[nsl][i];
+#pragma unroll
+							for (int col = 0; col < WS; ++col) {
+								const double wt = wv_[col];
+								if (FMAc) {
+									const double a = __builtin_fma(wt, av[col], -mL);
+									double bb[NCB];
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) bb[j] = __builtin_fma(wt, r_[col + j], -mR[j]);
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) { s1[j] = __builtin_fma(a, bb[j], s1[j]); s3[j] = __builtin_fma(bb[j], bb[j], s3[j]); }
+								} else {
+									double bb[NCB], u1[NCB], u3[NCB];
+									const double pa = wt*av[col];
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) bb[j] = wt*r_[col + j];
+									__builtin_amdgcn_sched_barrier(0);
+									const double a = pa - mL;                         // pixel_gray_l - meanL
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
+									__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+									for (int j = 0; j < NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
+								}
+								__builtin_amdgcn_sched_barrier(0);
+								av[col] = lp[col];
+								if (col & 1) {
+									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
+									const double2 u = wp[col >> 1]; wv_[col - 1] = u.x; wv_[col] = u.y;
+								}
+								__builtin_amdgcn_sched_barrier(0);
+							}
+#pragma unroll
+							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
+							wv_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
+							prog_yield(seen);
+						}
+#pragma unroll
+						for (int j = 0; j < NCB; ++j) {
+							const int c = c0 + j;
+							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
+								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
+								if (CERTc) {
+									if (!(s3[j] >= sig3) && A.redo) bad_blk = true;
+									crow[(size_t)(c - e_min)*ST_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
+								} else crow[(size_t)(c - e_min)*ST_TP] = (v < A.max_color_diff) ? v : A.max_color_diff;
+							}
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					};
+					if (fast && ONEPASS && !pix_exact) {
 						// ---- certified ONE-PASS form (srh_internal.hpp, CertBound): P = sum w r, Q = sum ((w l - meanL) w) r,
 						// U = sum w^2 r^2 in one sweep over the window; registers are refilled in place a row ahead, as below
 						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
@@ -625,126 +757,13 @@ void twoview_strip_cost_kernel(const StripArgs A)
 								const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
 								const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
 								const bool okc = s3 >= sig3 && s3*A.cb.zmax2 >= q3;
+								if (!okc && A.redo) bad_blk = true;
 								crow[(size_t)(c - e_min)*ST_TP] = !okc ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
 							}
 							__builtin_amdgcn_sched_barrier(0);
 						}
-					} else if (fast) {
-						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
-						// Both passes are modulo-scheduled by hand (see twoview_dense_cost_kernel): a register is refilled
-						// with the next row's value right after its last use, so the LDS latency is always a row ahead.
-						double r_[NR], wv_[WS], acc[NCB];
-						{
-							const double2 *rp = reinterpret_cast<const double2 *>(rbase + s0*RW + rc);
-							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][0][i][0]);
-#pragma unroll
-							for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
-#pragma unroll
-							for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv_[2*m] = v.x; wv_[2*m + 1] = v.y; }
-							wv_[WS - 1] = CS.w[wcur][0][i][WS - 1];
-						}
-#pragma unroll
-						for (int j = 0; j < NCB; ++j) acc[j] = 0.0;
-						__builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the pre-header's reads have landed
-#pragma unroll 1
-						for (int row = 0; row < WS; ++row) {
-							int seen = 0;
-							prog_step(1, seen);
-							const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for pass 2
-							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
-							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
-							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
-#pragma unroll
-							for (int col = 0; col < WS; ++col) {
-								if (FMA) {
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) acc[j] = __builtin_fma(wv_[col], r_[col + j], acc[j]);
-								} else {
-									double pr[NCB];
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) pr[j] = wv_[col]*r_[col + j];
-									__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) acc[j] += pr[j];        // meanR += weight*gray
-								}
-								__builtin_amdgcn_sched_barrier(0);
-								if (col & 1) {
-									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
-									const double2 u = wp[col >> 1]; wv_[col - 1] = u.x; wv_[col] = u.y;
-									__builtin_amdgcn_sched_barrier(0);
-								}
-							}
-#pragma unroll
-							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
-							wv_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
-							prog_yield(seen);
-						}
-						double mR[NCB], s1[NCB], s3[NCB], av[WS];
-#pragma unroll
-						for (int col = 0; col < WS; ++col) av[col] = CS.lt[s0][i + col];
-#pragma unroll
-						for (int j = 0; j < NCB; ++j) { mR[j] = acc[j]/tw; s1[j] = 0.0; s3[j] = 0.0; }
-						__builtin_amdgcn_s_waitcnt(0xC07F);
-#pragma unroll 1
-						for (int row = 0; row < WS; ++row) {
-							int seen = 0;
-							prog_step(3, seen);
-							const int nrow = row + 1 < WS ? row + 1 : 0;
-							const int nsl = s0 + nrow >= NS ? s0 + nrow - NS : s0 + nrow;
-							const double2 *rp = reinterpret_cast<const double2 *>(rbase + nsl*RW + rc);
-							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][nrow][i][0]);
-							const double *lp = &CS.lt[nsl][i];
-#pragma unroll
-							for (int col = 0; col < WS; ++col) {
-								const double wt = wv_[col];
-								if (FMA) {
-									const double a = __builtin_fma(wt, av[col], -mL);
-									double bb[NCB];
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) bb[j] = __builtin_fma(wt, r_[col + j], -mR[j]);
-									__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) { s1[j] = __builtin_fma(a, bb[j], s1[j]); s3[j] = __builtin_fma(bb[j], bb[j], s3[j]); }
-								} else {
-									double bb[NCB], u1[NCB], u3[NCB];
-									const double pa = wt*av[col];
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) bb[j] = wt*r_[col + j];
-									__builtin_amdgcn_sched_barrier(0);
-									const double a = pa - mL;                         // pixel_gray_l - meanL
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) bb[j] = bb[j] - mR[j];   // pixel_gray_r - meanR
-									__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) { u1[j] = a*bb[j]; u3[j] = bb[j]*bb[j]; }
-									__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-									for (int j = 0; j < NCB; ++j) { s1[j] += u1[j]; s3[j] += u3[j]; }
-								}
-								__builtin_amdgcn_sched_barrier(0);
-								av[col] = lp[col];
-								if (col & 1) {
-									const double2 v = rp[col >> 1]; r_[col - 1] = v.x; r_[col] = v.y;
-									const double2 u = wp[col >> 1]; wv_[col - 1] = u.x; wv_[col] = u.y;
-								}
-								__builtin_amdgcn_sched_barrier(0);
-							}
-#pragma unroll
-							for (int m = (WS - 1)/2; m < NR/2; ++m) { const double2 v = rp[m]; r_[2*m] = v.x; r_[2*m + 1] = v.y; }
-							wv_[WS - 1] = CS.w[wcur][nrow][i][WS - 1];
-							prog_yield(seen);
-						}
-#pragma unroll
-						for (int j = 0; j < NCB; ++j) {
-							const int c = c0 + j;
-							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
-								const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-								if (CERT) crow[(size_t)(c - e_min)*ST_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
-								else crow[(size_t)(c - e_min)*ST_TP] = (v < A.max_color_diff) ? v : A.max_color_diff;
-							}
-							__builtin_amdgcn_sched_barrier(0);
-						}
-					}
+					} else if (fast && !ONEPASS && !pix_exact) two_sweeps(std::integral_constant<bool, FMA>(), std::integral_constant<bool, CERT>());
+					if (fast && CERT && (pix_exact || bad_blk)) two_sweeps(std::false_type(), std::false_type());   // (bad_blk is only raised when A.redo)
 				}
 			}
 			if (NWV == 8) __builtin_amdgcn_s_setprio(2);
@@ -890,7 +909,7 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
                                const srh_params &P, int y0, int nrows, const double *wimg, const double *pconst,
                                const PixRange *prange, const double *ref_tvp, const double *oth_tvp,
                                const uint8_t *oth_fullp, double *cost, int cstride, Counters *cnt, int arith, int num_cus,
-                               int lanes)
+                               int lanes, bool raw)
 {
 	(void)views; (void)ref; (void)oth;
 	StripArgs a;
@@ -905,6 +924,7 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
 	a.nitems = nseg*((width + ST_TP - 1)/ST_TP);
 	a.weight_cutoff = P.weight_cutoff; a.bad_ret = P.bad_ret; a.max_color_diff = P.max_color_diff;
 	a.cb = cert_bound(P);
+	a.redo = raw ? 0 : 1;
 	const bool wide = lanes == 16;
 	switch (P.window_radius) {
 	case 5:
