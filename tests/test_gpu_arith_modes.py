@@ -235,10 +235,14 @@ def test_certified_equals_exact_on_adversarial_images(hip_ctx, kind, wkind, stri
     hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr))
     p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
     flagged, scanned = _assert_certified_equals_exact(hip_ctx, p, strip, kind, must_certify=False)
-    print("certified scan, %s / %s: %d of %d pixels flagged and redone%s" % (kind, "geodesic" if wkind else "adaptive", flagged, scanned,
-                                                                         "" if scanned else " (both passes repeated in mode 0)"))
-    if kind in ("flat", "periodic"):
-        assert flagged > 0 or scanned == 0, "an image made of exact ties must trip the bound somewhere"
+    print("certified scan, %s / %s: %d of %d pixels flagged and redone" % (kind, "geodesic" if wkind else "adaptive", flagged, scanned))
+    # (round 5: no pass is ever repeated in mode 0 -- the redo covers the whole band -- so scanned > 0 always; and the strip
+    # kernel evaluates a pixel with a flat window in the reference's arithmetic straight away, so "flat" no longer flags there)
+    assert scanned > 0
+    if kind == "periodic" or (kind == "flat" and strip == 0):
+        assert flagged > 0, "an image made of exact ties must trip the bound somewhere"
+    if kind == "flat" and strip != 0 and wkind == capi.WEIGHT_GEODESIC:
+        assert flagged == 0, "flat windows take the reference's arithmetic in the cost kernel: nothing is left to flag"
 
 
 def test_certified_equals_exact_when_the_parameters_move_the_decisions(hip_ctx):

@@ -55,7 +55,10 @@ def test_strip_forms_match_the_per_tile_kernel_and_the_oracle(hip_ctx, name, ove
                 "strip=%d direction %d: depth bits differ from the per-tile kernel" % (strip, d)
             assert got[d][1]["n_eval"] == ref[d][1]["n_eval"]
             if strip == 4:      # same block geometry as the per-tile kernel (16 block lanes leave other columns to the scan)
-                assert got[d][1]["n_eval_device"] == ref[d][1]["n_eval_device"]
+                # (but for the exact redo of flagged pixels, a cost row each: the strip kernel settles uncovered candidates and
+                # flat-window pixels itself, so the two kernels' scans flag different pixels)
+                slack = (got[d][1]["n_flagged"] + ref[d][1]["n_flagged"]) * (2 * p.num_depth_levels + 8)
+                assert abs(got[d][1]["n_eval_device"] - ref[d][1]["n_eval_device"]) <= slack
     want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
     ok, msg, _ = cases.compare_depth(_run(hip_ctx, p, 8)[0][0], want, RTOL)
     assert ok, msg
