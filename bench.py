@@ -549,6 +549,45 @@ def other_configs(args, rank, world, dev, dev_index, backend):
     return out
 
 
+def flat_area_sweep(dev_index, steps=3, fracs=(0.0, 0.01, 0.05, 0.25, 0.60)):
+    """The certified arithmetic off friendly input (VERDICT r4 #1c): the C3 pair with a growing share of its area made flat /
+    saturated (synthetic.paint_flat_bands), one step = srh_twoview_compute, in the default (certified) arithmetic and in the
+    reference's arithmetic everywhere.  Reported per fraction: ms per step of both, the share of pixels the certified scan
+    flagged for the exact redo (last pass), and that the two modes' depth maps are the same bits.  No pass is ever repeated
+    as a whole: the certified time must grow smoothly from its textured-image value towards the exact mode's."""
+    W, H, D, wkind, seed, _ = WORKLOADS["c3"]
+    L0, R0, ml, mr, _ = synthetic.rectified_pair(W, H, D, seed)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind)
+    out = []
+    with capi.Context(dev_index) as ctx:
+        for frac in fracs:
+            L, R, painted = synthetic.paint_flat_bands(L0, R0, frac)
+            ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl))
+            ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr))
+            rec = {"flat_frac": frac, "rows_painted": painted}
+            maps = {}
+            for mode, code in (("certified", capi.ARITH_CERTIFIED), ("exact", capi.ARITH_EXACT)):
+                ctx.set_option("arith", code)
+                ctx.twoview_compute_device(0, 1, p)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    ctx.twoview_compute_device(0, 1, p)
+                ctx.synchronize()
+                rec["ms_" + mode] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+                st = ctx.stats()
+                if mode == "certified":
+                    rec["flagged_frac_last_pass"] = round(st["n_flagged"] / max(1, st["n_certified"]), 8)
+                    rec["pixels_on_fused_costs_last_pass"] = st["n_certified"]
+                maps[mode] = (ctx.download_depth(0), ctx.download_depth(1))
+            rec["same_bits_as_exact_mode"] = bool(all(np.array_equal(a.view(np.uint64), b.view(np.uint64))
+                                                      for a, b in zip(maps["certified"], maps["exact"])))
+            out.append(rec)
+    return out
+
+
 RANK_TIMEOUT_S = float(os.environ.get("SRH_BENCH_RANK_TIMEOUT_S", "300"))   # rendezvous + every collective of a rank
 
 
@@ -720,6 +759,8 @@ def main():
         result["comm"] = comm
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_configs and args.arith in ("certified", "exact"):
         result["configs"] = other_configs(args, rank, world, dev, dev_index, backend)
+        if args.arith == "certified" and result["config"].get("certified_scan"):
+            result["config"]["certified_scan"]["flat_area_sweep"] = flat_area_sweep(dev_index)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

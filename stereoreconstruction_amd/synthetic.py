@@ -93,6 +93,20 @@ def rectified_pair(w, h, D, seed, d0=8):
     return rgba(left), rgba(right), ones, ones.copy(), disp
 
 
+def paint_flat_bands(left, right, frac, flat=90, saturated=255):
+    """Copies of a pair with `frac` of the area made textureless, in both images at the same place: the top frac/2 of the
+    rows a flat gray, the bottom frac/2 saturated -- the regions in which a support window carries no signal (sum2, sum3 ~ 0:
+    the certified arithmetic's error bound has no room there).  Returns (left, right, rows painted)."""
+    L, R = left.copy(), right.copy()
+    h = L.shape[0]
+    n = int(round(h * frac / 2.0))
+    if n > 0:
+        for img in (L, R):
+            img[:n, :, :3] = flat
+            img[h - n:, :, :3] = saturated
+    return L, R, 2 * n
+
+
 def rectified_cameras(w, h, baseline=1.0):
     """K=[[f,0,W/2],[0,f,H/2],[0,0,1]], f=W, R=I, C_left=0, C_right=(B,0,0) as (K,R,t) triples."""
     f = float(w)
