@@ -58,6 +58,12 @@ WORKLOADS = {
     "c4": (1280, 960, 128, capi.WEIGHT_GEODESIC, 0x5EED0004,
            "C4: 8 views on a semicircle (22.5 deg apart) around a textured sphere, 1280x960, 128 uniform depth "
            "levels, MultiViewStereo r=2, 3 neighbours"),
+    # C1M: the reference's live entry point on its own example data -- StereoWidget -> MultiViewStereo on every camera of the
+    # project (gui/widgets/stereowidget.cpp:974-1002) -- the eight `bunny` views as the reference ingests them
+    # (tests/golden/bunny_views.npz: Qt smooth scaling 0.25, alpha masks, lens distortion), 100 levels 30-80
+    "c1m": (256, 192, 100, capi.WEIGHT_GEODESIC, 0,
+            "C1M: the example project's 8 'bunny' views 1024x768 at scale 0.25 (256x192), 100 uniform depth levels 30-80, "
+            "MultiViewStereo r=2, 3 neighbours, distorted cameras from the project's projection matrices"),
 }
 C4_VIEWS = 8
 
@@ -119,14 +125,22 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     """MultiViewStereo::runTask on C4; returns the JSON dict on rank 0."""
     import torch
     import torch.distributed as dist
-    W, H, D, wkind, seed, desc = WORKLOADS["c4"]
-    if os.environ.get("SRH_BENCH_C4_SMALL"):                   # dev: quick functional run
-        W, H, D = 320, 240, 32
-    cams3 = synthetic.semicircle_rig(C4_VIEWS, W, H, radius=10.0, step_deg=22.5, focal=float(W))
-    rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, seed, sphere_radius=2.0, tex_size=1024)
-    cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
-    zmin, zmax = 8.0, 12.0
-    p = capi.params_mvs(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind,
+    wl = args.workload if args.workload in ("c4", "c1m") else "c4"
+    W, H, D, wkind, seed, desc = WORKLOADS[wl]
+    scale = 1.0
+    if wl == "c1m":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "bunny_views.npz"))
+        rgba, masks, scale = list(g["rgba"]), list(g["mask"]), float(g["scale"][0])
+        cams = [capi.camera_from_p(g["P"][v], g["dist"][v]) for v in range(C4_VIEWS)]
+        zmin, zmax = 30.0, 80.0
+    else:
+        if os.environ.get("SRH_BENCH_C4_SMALL"):               # dev: quick functional run
+            W, H, D = 320, 240, 32
+        cams3 = synthetic.semicircle_rig(C4_VIEWS, W, H, radius=10.0, step_deg=22.5, focal=float(W))
+        rgba, masks, _ = synthetic.render_sphere_views(cams3, W, H, seed, sphere_radius=2.0, tex_size=1024)
+        cams = [capi.camera_from_krt(K, R, t) for (K, R, t) in cams3]
+        zmin, zmax = 8.0, 12.0
+    p = capi.params_mvs(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind, image_scale=scale,
                         cross_check_threshold=2 * (zmax - zmin) / (D - 1))
     neigh = capi.mvs_neighbours(cams, p)
     links = sum(len(n) for n in neigh)
@@ -175,9 +189,13 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     # matched and a curve has as many candidates as its pixel length, so W*H*D*links is neither a bound nor an estimate
     my_views = list(shard_units(C4_VIEWS, world, rank))
     n_eval = 0
+    waves = [0, 0]
     for v in my_views:
         ctx.mvs_initial_estimate(v, neigh[v], p)
-        n_eval += ctx.stats()["n_eval"]
+        st = ctx.stats()
+        n_eval += st["n_eval"]
+        waves[0] += st["mvs_waves_staged"]
+        waves[1] += st["mvs_waves_listed"]
     result = None
     if rank == 0:
         hyp_per_step = W * H * D * links                        # nominal: every pixel x level x neighbour
@@ -192,7 +210,8 @@ def run_c4(args, rank, world, dev, dev_index, backend):
             "metric": "Mdisparity-hypotheses/s (WxHxD)", "value": round(hyp_per_step * args.steps / dt / 1e6, 3),
             "unit": "Mhyp/s", "build_id": capi.build_id(), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if wl == "c4" else "fixture (the example project's eight bunny views, Qt-scaled)",
             "config": {"workload": desc + "; initial estimates + depth-map all-gather + ordered cross-check",
                        "width": W, "height": H, "depth_levels": D, "views": C4_VIEWS, "view_neighbour_links": links,
                        "window_radius": int(p.window_radius), "weights": "geodesic",
@@ -203,11 +222,14 @@ def run_c4(args, rank, world, dev, dev_index, backend):
                                       "-- same bits as 'exact' (DESIGN.md 2b)" if args.arith == "certified"
                                       else "exact: the reference's operation order, no contraction, everywhere"),
                        "masked_in_fraction": round(float(np.mean([m.mean() for m in masks])), 4),
+                       # which cost kernel did the work: 64-pixel waves (per neighbour link) evaluated from LDS copies of the
+                       # other view (mvs_staged_cost_kernel) / by gathers (mvs_list_cost_kernel)
+                       "cost_waves_staged": int(waves[0]), "cost_waves_gathering": int(waves[1]),
                        "n_eval_reference_rank0_per_step": int(n_eval)},
             "roofline": {"bound": "valu_fp64", "kernel": name, "achieved": round(valu, 3), "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(valu / FP64_VALU_PEAK_TFLOPS, 5),
-                         "executed": pmc_executed("c4", name, ms / launches) if not os.environ.get("SRH_BENCH_C4_SMALL") else None,
-                         "traffic": pmc_traffic("c4", name) if not os.environ.get("SRH_BENCH_C4_SMALL") else None,
+                         "executed": pmc_executed(wl, name, ms / launches) if not os.environ.get("SRH_BENCH_C4_SMALL") else None,
+                         "traffic": pmc_traffic(wl, name) if not os.environ.get("SRH_BENCH_C4_SMALL") else None,
                          "avg_launch_ms": round(ms / launches, 4), "launches": launches,
                          "alg_flops_per_launch": round(flops / launches), "flops_per_hyp": 15 * T + 8,
                          "note": "flops = cost evaluations of the reference (n_eval) x 383; value counts nominal W*H*D*links hypotheses; "
@@ -225,8 +247,9 @@ def run_c4(args, rank, world, dev, dev_index, backend):
                                    "n_eval_reference_per_step": int(n_eval), "over_nominal": round(n_eval / hyp_per_step, 4)}
         if world == 1 and args.cpu_rows > 0:
             import oracle_ffi as O
-            ocams = [O.camera_set(K, R, t) for (K, R, t) in cams3]
-            op = O.params_mvs(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind,
+            ocams = ([O.camera_set_p(g["P"][v], g["dist"][v]) for v in range(C4_VIEWS)] if wl == "c1m"
+                     else [O.camera_set(K, R, t) for (K, R, t) in cams3])
+            op = O.params_mvs(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=wkind, image_scale=scale,
                               cross_check_threshold=2 * (zmax - zmin) / (D - 1))
             oimgs = [O.OImage(rgba[v], masks[v]) for v in range(C4_VIEWS)]
             rows = max(args.cpu_rows, 8)
@@ -527,12 +550,12 @@ def other_configs(args, rank, world, dev, dev_index, backend):
     Each leg carries its own CPU-oracle band (parity spot check at full size + baseline rate)."""
     import copy
     out = {}
-    for w, rows in (("c5", 2), ("c4", 8), ("c2", 4), ("c1", 24)):
+    for w, rows in (("c5", 2), ("c4", 8), ("c2", 4), ("c1", 24), ("c1m", 16)):
         a = copy.copy(args)
         a.steps, a.warmup, a.cpu_rows, a.workload, a.cpu_all_cores = 3, 1, rows, w, False
         t0 = time.perf_counter()
         try:
-            r = run_c4(a, rank, world, dev, dev_index, backend) if w == "c4" else run_twoview(a, w, rank, world, dev, dev_index, backend)
+            r = run_c4(a, rank, world, dev, dev_index, backend) if w in ("c4", "c1m") else run_twoview(a, w, rank, world, dev, dev_index, backend)
         except Exception as e:                                   # a leg must never take the headline line down with it
             out[w] = {"error": "%s: %s" % (type(e).__name__, e)}
             continue
@@ -542,6 +565,7 @@ def other_configs(args, rank, world, dev, dev_index, backend):
                   "roofline": {k: r["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
                   "n_eval_reference": r["config"].get("n_eval_reference_last_pass", r["config"].get("n_eval_reference_rank0_per_step")),
                   "evaluated": r.get("evaluated"), "certified_scan": r["config"].get("certified_scan"),
+                  "cost_waves": {k: r["config"].get(k) for k in ("cost_waves_staged", "cost_waves_gathering")} if w in ("c4", "c1m") else None,
                   "winner_mismatch_vs_exact": r["config"].get("winner_mismatch_vs_exact"),
                   "kernels_ms": r["kernels_ms"], "parity_band": cb.get("parity_band"),
                   "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
@@ -743,7 +767,7 @@ def main():
             dist.init_process_group(backend, timeout=tmo)
     comm = comm_record(dist, backend, world, dev) if rank == 0 or world > 1 else None
 
-    if args.workload == "c4":
+    if args.workload in ("c4", "c1m"):
         result = run_c4(args, rank, world, dev, dev_index, backend)
         if result is not None:
             result["comm"] = comm

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 4
+#define SRH_ABI_VERSION 5
 
 enum {
 	SRH_OK = 0,
@@ -97,6 +97,10 @@ typedef struct srh_stats {
 	int64_t n_certified;
 	int64_t n_flagged;
 	int64_t band_budget_bytes;  /* band budget the last run worked with (requested, capped by free device memory) */
+	/* last MultiViewStereo estimate on the list path: 64-pixel waves (per neighbour) whose candidate windows were
+	 * evaluated from LDS copies of the other view (mvs_staged_cost_kernel) / by gathers (mvs_list_cost_kernel: a window
+	 * over an image border, too large, too many) */
+	int64_t mvs_waves_staged, mvs_waves_listed;
 } srh_stats;
 
 typedef struct srh_context srh_context;

@@ -72,7 +72,8 @@ class Stats(C.Structure):
     _fields_ = [("n_pixels", C.c_int64), ("n_eval", C.c_int64), ("n_eval_device", C.c_int64),
                 ("used_dense_path", C.c_int32), ("used_fused_kernel", C.c_int32),
                 ("used_strip_kernel", C.c_int32), ("band_retries", C.c_int32),
-                ("n_certified", C.c_int64), ("n_flagged", C.c_int64), ("band_budget_bytes", C.c_int64)]
+                ("n_certified", C.c_int64), ("n_flagged", C.c_int64), ("band_budget_bytes", C.c_int64),
+                ("mvs_waves_staged", C.c_int64), ("mvs_waves_listed", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
@@ -570,7 +571,8 @@ class Context:
         return dict(n_pixels=s.n_pixels, n_eval=s.n_eval, n_eval_device=s.n_eval_device,
                     used_dense_path=bool(s.used_dense_path), used_fused_kernel=bool(s.used_fused_kernel),
                     used_strip_kernel=bool(s.used_strip_kernel), band_retries=s.band_retries,
-                    n_certified=s.n_certified, n_flagged=s.n_flagged, band_budget_bytes=s.band_budget_bytes)
+                    n_certified=s.n_certified, n_flagged=s.n_flagged, band_budget_bytes=s.band_budget_bytes,
+                    mvs_waves_staged=s.mvs_waves_staged, mvs_waves_listed=s.mvs_waves_listed)
 
     def profile_enable(self, on=True):
         _check(lib().srh_profile_enable(self._h, int(on)))

@@ -880,6 +880,8 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.n_pixels = (int64_t)h.n_pixels;
 	c->stats.n_eval = (int64_t)h.n_eval;
 	c->stats.n_eval_device = (int64_t)h.n_eval_device;
+	c->stats.mvs_waves_staged = (int64_t)h.mvs_waves_staged;
+	c->stats.mvs_waves_listed = (int64_t)h.mvs_waves_listed;
 	c->stats.used_dense_path = used_dense;
 	c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 #ifdef SRH_PROFILE_PHASES

@@ -147,7 +147,8 @@ struct Counters {
 	unsigned long long n_listed, n_slots; // row-run lists: distinct candidates / cost slots (8-column blocks) they occupy
 	unsigned long long strip_overflow;    // strip kernel: tiles whose candidate range does not fit one LDS chunk
 	unsigned long long n_certified, n_flagged;   // certified scan: reference pixels scanned on fused costs / flagged for the exact redo
-	unsigned long long cert_overflow;     // certified redo: a band flagged more pixels than the redo's launch covers
+	unsigned long long cert_overflow;     // certified redo: a flagged pixel with more candidates than the wave rescan holds (the pass is repeated in mode 0)
+	unsigned long long mvs_waves_staged, mvs_waves_listed;   // MultiViewStereo walk kernel: waves (with candidates) left to the staged / the gathering cost kernel
 	unsigned int strip_ticket, strip_pad; // strip kernel: work-item counter of the current launch
 	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
 	unsigned long long dbg_phase[8];

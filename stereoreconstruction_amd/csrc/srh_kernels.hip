@@ -908,7 +908,10 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 		flush();
 	}
 	count[unit] = nk;
-	if (nwin && (tid & 63) == 0) nwin[waveid] = wstaged ? nw : -1;
+	if (nwin && (tid & 63) == 0) {
+		nwin[waveid] = wstaged ? nw : -1;
+		if (!wstaged) atomicAdd(&cnt->mvs_waves_listed, 1ull); else if (nw > 0) atomicAdd(&cnt->mvs_waves_staged, 1ull);
+	}
 	__syncthreads();
 	if (nk) atomicMax(&s_max, nk);
 	__syncthreads();

@@ -10,6 +10,13 @@
                    them (Qt smooth scaling to 0.25, alpha mask) + their K,R,t (Camera::setP path
                    restated in numpy: unpinned Eigen QR) + lens distortion.  BASELINE config C1.
 
+  bunny_views.npz  all EIGHT views of the example project's `bunny` image set as the reference ingests them
+                   (MultiViewStereo::initialize, multiviewstereo.cpp:216-241, through the reference's own Qt calls at scale
+                   0.25), in camera-id order, + bunny_project.xml: the eight cameras' numbers (projection matrices, lens
+                   distortion) and the `bunny` image set of example/project.xml with the image files renamed <id>.raw.
+                   The reference's only live entry point -- StereoWidget -> MultiViewStereo on every camera of the
+                   project (gui/widgets/stereowidget.cpp:974-1002) -- on real, distorted, masked photographs.
+
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 """
 import ctypes as C
@@ -139,6 +146,52 @@ def make_bunny():
           out["right_mask"].mean())
 
 
+def make_bunny_views():
+    R = O.ref()
+    R.refp_load_scaled.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_int, O.c_uint8_p, O.c_uint8_p,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.refp_load_scaled.restype = C.c_int
+    root = ET.parse(os.path.join(REF, "example", "project.xml")).getroot()
+    iset = [s for s in root.find("imageSets") if s.get("id") == "bunny"][0]
+    files = {im.get("for"): im.get("file") for im in iset}
+    cams = sorted(root.find("cameras"), key=lambda c: c.get("id"))           # Project::cameras() is a map: id order
+    ids, rgba, mask, Ps, dists = [], [], [], [], []
+    xml = ['<?xml version="1.0" encoding="UTF-8"?>',
+           "<!-- test fixture (data): the eight cameras of the example project and its `bunny` image set; image files are the",
+           "     Qt-ingested views of tests/golden/bunny_views.npz written as <id>.raw by the test -->", "<project>", " <cameras>"]
+    for cam in cams:
+        cid = cam.get("id")
+        pm, ld = cam.find("projectionMatrix"), cam.find("lensDistortion")
+        P = np.array([[float(pm.get("m%d%d" % (i, j))) for j in (1, 2, 3, 4)] for i in (1, 2, 3)])
+        dist = np.array([float(ld.get(k, "0")) for k in ("k1", "k2", "p1", "p2", "k3")])
+        buf = np.zeros((1024 * 768 * 4,), np.uint8); msk = np.zeros((1024 * 768,), np.uint8)
+        w, h = C.c_int(0), C.c_int(0)
+        ok = R.refp_load_scaled(os.path.join(REF, "example", iset.get("root"), files[cid]).encode(), 0.25,
+                                1024, 768, O.u8ptr(buf), O.u8ptr(msk), C.byref(w), C.byref(h))
+        assert ok, cid
+        ids.append(cid); Ps.append(P); dists.append(dist)
+        rgba.append(buf[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy())
+        mask.append(msk[: w.value * h.value].reshape(h.value, w.value).copy())
+        xml.append('  <camera id="%s">' % cid)
+        xml.append("   <projectionMatrix %s/>" % " ".join('m%d%d="%s"' % (i, j, pm.get("m%d%d" % (i, j))) for i in (1, 2, 3) for j in (1, 2, 3, 4)))
+        xml.append("   <lensDistortion %s/>" % " ".join('%s="%s"' % (k, ld.get(k)) for k in ("k1", "k2", "k3", "p1", "p2") if ld.get(k) is not None))
+        xml.append("  </camera>")
+    xml += [" </cameras>", " <imageSets>", '  <imageSet root="." id="bunny">']
+    xml += ['   <image for="%s" default="yes" file="%s.raw"/>' % (cid, cid) for cid in ids]
+    xml += ["  </imageSet>", " </imageSets>", "</project>", ""]
+    open(os.path.join(HERE, "bunny_project.xml"), "w").write("\n".join(xml))
+    np.savez_compressed(os.path.join(HERE, "bunny_views.npz"), ids=np.array(ids), rgba=np.stack(rgba), mask=np.stack(mask),
+                        P=np.stack(Ps), dist=np.stack(dists), scale=np.array([0.25]))
+    print("bunny_views.npz written:", np.stack(rgba).shape, "mask fractions", [round(float(m.mean()), 3) for m in mask])
+    # the pair fixture is views 0 and 1 of the same ingest
+    g = np.load(os.path.join(HERE, "bunny_pair.npz"))
+    assert np.array_equal(g["left_rgba"], rgba[ids.index("7310085")]) and np.array_equal(g["right_mask"], mask[ids.index("7310087")])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "views":
+        make_bunny_views()
+        sys.exit(0)
     make_ref_pieces()
     make_bunny()
+    make_bunny_views()

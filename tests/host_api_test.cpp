@@ -33,8 +33,14 @@ static bool loadRaw(const std::string &file, double, Image &image, Image &maskSo
 	rd(f, wh, 2);
 	image = Image(wh[0], wh[1]);
 	rd(f, image.rgba.data(), image.rgba.size());
-	fclose(f);
 	maskSource = image;                                // has an alpha channel: mask = alpha == 255
+	// optional w*h mask bytes behind the pixels (a fixture made by the reference's own Qt ingest, where the mask comes
+	// from the FAST-scaled copy and the pixels from the smooth-scaled one, multiviewstereo.cpp:216-237): the mask
+	// source's alpha is that plane
+	std::vector<uint8_t> m(static_cast<size_t>(wh[0])*wh[1]);
+	if (fread(m.data(), 1, m.size(), f) == m.size())
+		for (size_t k = 0; k < m.size(); ++k) maskSource.rgba[4*k + 3] = m[k] ? 255 : 0;
+	fclose(f);
 	return true;
 }
 

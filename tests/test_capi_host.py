@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.srh_abi_version() == 4
+    assert L.srh_abi_version() == 5
 
 
 def _bytes(s):
