@@ -922,37 +922,52 @@ void mvs_walk_kernel(const ViewDev *__restrict__ views, int ref, NeighList nl, s
 }
 
 // cost of one candidate for any validity pattern (window over an image border, cut-off weights):
-// the reference's two sweeps with every tap guarded (multiviewstereo.cpp:113-189).  Rare, so it is
-// kept out of line and reads everything from memory.
+// The reference's two sweeps with every tap guarded (multiviewstereo.cpp:113-189) for one candidate of a unit whose
+// reference-side taps (weights wt, grays gl -- NaN outside the image -- and okl = tap usable on the reference side) are
+// at hand.  Select form: the candidate's 25 taps are fetched with UNCONDITIONAL loads from clamped addresses (one memory
+// round trip for the window; a guarded load per tap -- a branch and a wait of its own each, twice per candidate -- made
+// this routine 50 dependent round trips per candidate, and on real photographs every silhouette pixel comes here: its
+// window reaches over the masked-out background, whose weights are below the cut-off), a skipped tap adds +0.0 to every
+// sum (sums of non-negative products never hold -0.0; sum1 starts at +0.0): the same bits as the guarded loops.
 template <int R>
-__device__ __noinline__ double mvs_cost_general(const ViewDev &A, const ViewDev &B, const double *__restrict__ wq,
-                                                size_t wstride, double cutoff, int x, int y, int cx, int cy)
+__device__ __forceinline__ double mvs_cost_select(const ViewDev &B, const double (&wt)[(2*R + 1)*(2*R + 1)],
+                                                  const double (&gl)[(2*R + 1)*(2*R + 1)], const bool (&okl)[(2*R + 1)*(2*R + 1)],
+                                                  int cx, int cy)
 {
-	constexpr int WS = 2*R + 1;
-	double mL = 0, mR = 0, twg = 0.0;
-#pragma unroll 1
-	for (int row = 0; row < WS; ++row)
-#pragma unroll 1
+	constexpr int WS = 2*R + 1, T = WS*WS;
+	typedef const __attribute__((address_space(1))) double *gptr;
+	const int OW = B.w, OH = B.h;
+	double gr[T];
+	bool ok[T];
+#pragma unroll
+	for (int row = 0; row < WS; ++row) {
+		const int yy = cy - R + row, yc = yy < 0 ? 0 : (yy >= OH ? OH - 1 : yy);
+		gptr rp = (gptr)(B.gray + (size_t)yc*OW);
+#pragma unroll
 		for (int col = 0; col < WS; ++col) {
-			const double gl = mvs_tap(A, x - R + col, y - R + row), gr = mvs_tap(B, cx - R + col, cy - R + row);
-			const double wt = wq[(size_t)(row*WS + col)*wstride];
-			if (gl == gl && gr == gr && wt > cutoff) { mL += wt*gl; mR += wt*gr; twg += wt; }
+			const int xx = cx - R + col, xc = xx < 0 ? 0 : (xx >= OW ? OW - 1 : xx);
+			gr[row*WS + col] = rp[xc];
+			ok[row*WS + col] = okl[row*WS + col] && xx == xc && yy == yc;
 		}
+	}
+	double mL = 0, mR = 0, twg = 0.0;
+#pragma unroll
+	for (int t = 0; t < T; ++t) {
+		const bool o = ok[t] && gr[t] == gr[t];
+		ok[t] = o;
+		const double pl = wt[t]*gl[t], pr = wt[t]*gr[t];
+		mL += o ? pl : 0.0; mR += o ? pr : 0.0; twg += o ? wt[t] : 0.0;
+	}
 	if (twg < 1e-10) return 0;
 	mL /= twg;
 	mR /= twg;
 	double s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll 1
-	for (int row = 0; row < WS; ++row)
-#pragma unroll 1
-		for (int col = 0; col < WS; ++col) {
-			const double gl = mvs_tap(A, x - R + col, y - R + row), gr = mvs_tap(B, cx - R + col, cy - R + row);
-			const double wt = wq[(size_t)(row*WS + col)*wstride];
-			if (gl == gl && gr == gr && wt > cutoff) {
-				const double aa = wt*gl - mL, bb = wt*gr - mR;
-				s1 += aa*bb; s2 += aa*aa; s3 += bb*bb;
-			}
-		}
+#pragma unroll
+	for (int t = 0; t < T; ++t) {
+		const double aa = wt[t]*gl[t] - mL, bb = wt[t]*gr[t] - mR;
+		const double ab = aa*bb, a2 = aa*aa, b2 = bb*bb;
+		s1 += ok[t] ? ab : 0.0; s2 += ok[t] ? a2 : 0.0; s3 += ok[t] ? b2 : 0.0;
+	}
 	if (s2 * s3 < 1e-10) return 0;
 	return s1 / sqrt(s2 * s3);
 }
@@ -980,14 +995,31 @@ __device__ __noinline__ void mvs_unit_general(const ViewDev &A, const ViewDev &B
                                               const uint32_t *__restrict__ cl, int n, double *__restrict__ bout,
                                               double *__restrict__ pk)
 {
+	constexpr int WS = 2*R + 1, T = WS*WS;
 	const Ray ray = cam_unproject(A.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 	double bestCost = 0.0, bestDepth = -1.0;
 	if (pk) for (int k = 0; k < P.top_k; ++k) { pk[2*k] = 0.0; pk[2*k + 1] = -1.0; }
+	// the reference side once per unit
+	double wt[T], gl[T];
+	bool okl[T];
+#pragma unroll
+	for (int row = 0; row < WS; ++row)
+#pragma unroll
+		for (int col = 0; col < WS; ++col) {
+			const int t = row*WS + col, xx = x - R + col, yy = y - R + row;
+			const int xc = xx < 0 ? 0 : (xx >= A.w ? A.w - 1 : xx), yc = yy < 0 ? 0 : (yy >= A.h ? A.h - 1 : yy);
+			wt[t] = wq[(size_t)t*wstride];
+			const double v = A.gray[(size_t)yc*A.w + xc];
+			gl[t] = (xx == xc && yy == yc) ? v : __builtin_nan("");
+			okl[t] = gl[t] == gl[t] && wt[t] > P.weight_cutoff;
+		}
+	uint32_t en = n > 0 ? cl[0] : MQ_PAD;
 	for (int k = 0; k < n; ++k) {
-		const uint32_t e = cl[(size_t)k*64];
+		const uint32_t e = en;
+		if (k + 1 < n) en = cl[(size_t)(k + 1)*64];                  // (the next entry travels under this candidate's arithmetic)
 		if (e == MQ_PAD) continue;                                   // alignment filler of the wave-aligned lists
 		const int cx = (int)(e & 0xffffu), cy = (int)(e >> 16);
-		const double c = mvs_cost_general<R>(A, B, wq, wstride, P.weight_cutoff, x, y, cx, cy);
+		const double c = mvs_cost_select<R>(B, wt, gl, okl, cx, cy);
 		if (c > P.peak_threshold && (pk || c >= bestCost)) {         // multiviewstereo.cpp:589-594, 654-660
 			const double z = candidate_depth(A.cam, B.cam, P, ray, cx, cy);
 			if (c > bestCost || (c == bestCost && z > bestDepth)) { bestCost = c; bestDepth = z; }
