@@ -101,6 +101,9 @@ typedef struct srh_stats {
 	 * evaluated from LDS copies of the other view (mvs_staged_cost_kernel) / by gathers (mvs_list_cost_kernel: a window
 	 * over an image border, too large, too many) */
 	int64_t mvs_waves_staged, mvs_waves_listed;
+	/* last TwoView pass on the dense path: 64-pixel tiles whose pixels all verified the pass's candidate template and were
+	 * scanned over it (twoview_tscan_kernel) / tiles left to the per-pixel curve walk (twoview_scan_kernel) */
+	int64_t scan_tiles_template, scan_tiles_walked;
 } srh_stats;
 
 typedef struct srh_context srh_context;

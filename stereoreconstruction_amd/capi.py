@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("used_dense_path", C.c_int32), ("used_fused_kernel", C.c_int32),
                 ("used_strip_kernel", C.c_int32), ("band_retries", C.c_int32),
                 ("n_certified", C.c_int64), ("n_flagged", C.c_int64), ("band_budget_bytes", C.c_int64),
-                ("mvs_waves_staged", C.c_int64), ("mvs_waves_listed", C.c_int64)]
+                ("mvs_waves_staged", C.c_int64), ("mvs_waves_listed", C.c_int64),
+                ("scan_tiles_template", C.c_int64), ("scan_tiles_walked", C.c_int64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
@@ -572,7 +573,8 @@ class Context:
                     used_dense_path=bool(s.used_dense_path), used_fused_kernel=bool(s.used_fused_kernel),
                     used_strip_kernel=bool(s.used_strip_kernel), band_retries=s.band_retries,
                     n_certified=s.n_certified, n_flagged=s.n_flagged, band_budget_bytes=s.band_budget_bytes,
-                    mvs_waves_staged=s.mvs_waves_staged, mvs_waves_listed=s.mvs_waves_listed)
+                    mvs_waves_staged=s.mvs_waves_staged, mvs_waves_listed=s.mvs_waves_listed,
+                    scan_tiles_template=s.scan_tiles_template, scan_tiles_walked=s.scan_tiles_walked)
 
     def profile_enable(self, on=True):
         _check(lib().srh_profile_enable(self._h, int(on)))

@@ -111,6 +111,9 @@ struct srh_context {
 	double *pconst = nullptr; size_t pconst_cap = 0;    // per-pixel constants of the dense kernel's fast form (4 doubles per pixel of a band)
 	PixRange *prange = nullptr; size_t prange_cap = 0;  // per-pixel candidate column range of a band (strip kernel, scan)
 	uint32_t *cflag = nullptr; size_t cflag_cap = 0;    // certified arithmetic: [count | band pixels whose decisions the bound does not cover]
+	uint8_t *stpl = nullptr; size_t stpl_cap = 0;       // template scan: the pass's candidate template (twoview_template_kernel)
+	uint32_t *tileflag = nullptr; size_t tileflag_cap = 0;  //   and the tiles it leaves to twoview_scan_kernel: [count | tile indices]
+	int tscan = 1;                                      // option "tscan": 1 = template scan on the dense path (default), 0 = every tile through twoview_scan_kernel
 	int strip = 1;                                      // option "strip": 1 = persistent strip cost kernel (default), 0 = one workgroup per tile, 4 / 8 = force the 4- / 8-wave form
 	int num_cus = 256;
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
@@ -166,8 +169,9 @@ struct srh_context {
 		Counters *d_cnt = nullptr; int *d_span = nullptr;
 		double *wbuf = nullptr, *cost = nullptr, *tnum = nullptr, *pconst = nullptr;
 		PixRange *prange = nullptr; uint32_t *cflag = nullptr, *lcand = nullptr, *lrowinfo = nullptr; int32_t *lcount = nullptr, *lmeta = nullptr;
+		uint8_t *stpl = nullptr; uint32_t *tileflag = nullptr;
 		size_t wbuf_cap = 0, cost_cap = 0, tnum_cap = 0, pconst_cap = 0, prange_cap = 0, cflag_cap = 0, lcand_cap = 0, lrowinfo_cap = 0,
-		       lcount_cap = 0, lmeta_cap = 0;
+		       lcount_cap = 0, lmeta_cap = 0, stpl_cap = 0, tileflag_cap = 0;
 	} tv_slot;
 	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
@@ -584,6 +588,8 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->pconst) hipFree(c->pconst);
 	if (c->prange) hipFree(c->prange);
 	if (c->cflag) hipFree(c->cflag);
+	if (c->stpl) hipFree(c->stpl);
+	if (c->tileflag) hipFree(c->tileflag);
 	for (auto &d : c->tv_defer) if (d.host) hipHostFree(d.host);
 	{
 		srh_context::TvSlot &T = c->tv_slot;
@@ -602,6 +608,8 @@ extern "C" void srh_destroy(srh_context *c) {
 		if (T.lrowinfo) hipFree(T.lrowinfo);
 		if (T.lcount) hipFree(T.lcount);
 		if (T.lmeta) hipFree(T.lmeta);
+		if (T.stpl) hipFree(T.stpl);
+		if (T.tileflag) hipFree(T.tileflag);
 	}
 	if (c->mrf) hipFree(c->mrf);
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
@@ -672,6 +680,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 		return SRH_OK;
 	}
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
+	if (!strcmp(name, "tscan")) { c->tscan = value != 0; return SRH_OK; }
 	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
 	if (!strcmp(name, "debug_mvs_cmax_hint")) { c->mvs_cmax_hint = value > 0 ? (int)((value + 7) & ~7L) : 0; return SRH_OK; }
 #ifdef SRH_EXPERIMENT
@@ -828,6 +837,7 @@ static void release_band_buffers(srh_context *c) {
 	drop(c->wbuf, c->wbuf_cap); drop(c->cost, c->cost_cap); drop(c->pconst, c->pconst_cap); drop(c->prange, c->prange_cap);
 	drop(c->lcount, c->lcount_cap); drop(c->lcand, c->lcand_cap); drop(c->lrowinfo, c->lrowinfo_cap); drop(c->lmeta, c->lmeta_cap);
 	drop(c->mvs_wdesc, c->mvs_wdesc_cap); drop(c->mvs_nwin, c->mvs_nwin_cap); drop(c->cflag, c->cflag_cap);
+	drop(c->stpl, c->stpl_cap); drop(c->tileflag, c->tileflag_cap);
 	for (MvsSlot &S : c->mvs_slot) {
 		drop(S.wbuf, S.wbuf_cap); drop(S.cost, S.cost_cap); drop(S.lcount, S.lcount_cap); drop(S.lcand, S.lcand_cap);
 		drop(S.mvs_wdesc, S.mvs_wdesc_cap); drop(S.mvs_nwin, S.mvs_nwin_cap);
@@ -838,6 +848,7 @@ static void release_band_buffers(srh_context *c) {
 	drop(T.wbuf, T.wbuf_cap); drop(T.cost, T.cost_cap); drop(T.pconst, T.pconst_cap); drop(T.prange, T.prange_cap);
 	drop(T.cflag, T.cflag_cap); drop(T.lcand, T.lcand_cap); drop(T.lrowinfo, T.lrowinfo_cap); drop(T.lcount, T.lcount_cap);
 	drop(T.lmeta, T.lmeta_cap);
+	drop(T.stpl, T.stpl_cap); drop(T.tileflag, T.tileflag_cap);
 }
 
 // Run `body`; when it fails because a band buffer could not be allocated, wait for everything in flight, release the
@@ -880,6 +891,8 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.n_pixels = (int64_t)h.n_pixels;
 	c->stats.n_eval = (int64_t)h.n_eval;
 	c->stats.n_eval_device = (int64_t)h.n_eval_device;
+	c->stats.scan_tiles_template = (int64_t)h.scan_tiles_template;
+	c->stats.scan_tiles_walked = (int64_t)h.scan_tiles_walked;
 	c->stats.mvs_waves_staged = (int64_t)h.mvs_waves_staged;
 	c->stats.mvs_waves_listed = (int64_t)h.mvs_waves_listed;
 	c->stats.used_dense_path = used_dense;
@@ -1206,10 +1219,17 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 			HIP_TRY(hipGetLastError());
 			break;
 		}
+		const bool tscan = dense && c->tscan != 0;
 		if (dense) {
-			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
-			Scope s(c, "pinhole_label_table_kernel");
-			launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum);
+			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels + 8))) return rc;   // (+ 8: the template scan reads the table in whole eights)
+			{ Scope s(c, "pinhole_label_table_kernel");
+			  launch_pinhole_label_table(c->stream, c->d_views, ref, *p, false, c->tnum); }
+			if (tscan) {
+				// the pass's candidate template: the reference's walk at one pixel (srh_dense.hip, "template scan")
+				if ((rc = ensure(c->stpl, c->stpl_cap, scan_template_bytes()))) return rc;
+				Scope s(c, "twoview_template_kernel");
+				launch_scan_template(c->stream, c->d_views, ref, oth, *p, y0, y1 - y0, c->tnum, c->stpl);
+			}
 		}
 		size_t rows = 0;
 		for (int pass = 0; pass < 2; ++pass) {
@@ -1229,6 +1249,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*4))) return rc;
 		int lanes = 8;
 		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
+		if (tscan && (rc = ensure(c->tileflag, c->tileflag_cap, rows*(size_t)((W + 63)/64) + 1))) return rc;
 		const bool cert = dense && cert_ok;
 		// (the strip kernel's certified form: 5 = one sweep over the window, 3 = the reference's two sweeps fused; option "cert_form")
 		const int cost_arith = c->arith == 3 ? (cert ? (c->cert_form == 1 ? 5 : 3) : 0) : c->arith;
@@ -1316,7 +1337,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				if ((rc = cost_pass(cost_arith))) return rc;
 				{ Scope s(c, "twoview_scan_kernel");
 				  launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,
-				                      cert ? c->cflag : nullptr, -1, cert && strip ? c->pconst : nullptr); }
+				                      cert ? c->cflag : nullptr, -1, cert && strip ? c->pconst : nullptr, tscan ? c->stpl : nullptr, c->tileflag, c->num_cus); }
 				if (cert) {
 					// the pixels whose decisions the bound does not cover, in the reference's arithmetic: their cost rows are
 					// refilled and they are scanned again -- launched for a capacity, the count stays on the device
@@ -1412,6 +1433,8 @@ static void tv_slot_swap(srh_context *c) {
 	std::swap(c->lrowinfo, T.lrowinfo); std::swap(c->lrowinfo_cap, T.lrowinfo_cap);
 	std::swap(c->lcount, T.lcount); std::swap(c->lcount_cap, T.lcount_cap);
 	std::swap(c->lmeta, T.lmeta); std::swap(c->lmeta_cap, T.lmeta_cap);
+	std::swap(c->stpl, T.stpl); std::swap(c->stpl_cap, T.stpl_cap);
+	std::swap(c->tileflag, T.tileflag); std::swap(c->tileflag_cap, T.tileflag_cap);
 }
 
 static bool tv_pass_stands(const srh_context::TvDefer &d) {

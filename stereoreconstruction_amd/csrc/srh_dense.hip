@@ -13,6 +13,9 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
+#include <algorithm>
+#include <type_traits>
+
 namespace srh {
 
 // ------------------------------------------------------------------ edge planes
@@ -1216,13 +1219,14 @@ struct TwoViewScanState {
 // reference's bits.
 // LISTED: the exact scan of the flagged pixels only (lane k takes pixel cflag[1 + k]; their cost rows were refilled in
 // the reference's arithmetic by twoview_refill_kernel).
+// one tile (64 pixels of a row; LISTED: 64 listed pixels) of twoview_scan_kernel; `bid` = its index in the band
 template <bool CERT, bool LISTED>
-__global__ __launch_bounds__(SC_TW, CERT ? SC_OCC - 1 : SC_OCC)
-void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
-                         int y0, int nrows, const double *__restrict__ tnum,
-                         const double *__restrict__ cost, int cstride,
-                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
-                         uint32_t *__restrict__ cflag, int nlist, CertBound cb, const double *__restrict__ pexact)
+__device__ __forceinline__
+void twoview_scan_tile(const int bid, const ViewDev *__restrict__ views, int ref, int oth, const srh_params &P,
+                       int y0, int nrows, const double *__restrict__ tnum,
+                       const double *__restrict__ cost, int cstride,
+                       Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
+                       uint32_t *__restrict__ cflag, int nlist, const CertBound &cb, const double *__restrict__ pexact)
 {
 	const ViewDev &L = views[ref];
 	const ViewDev &Rv = views[oth];
@@ -1234,13 +1238,13 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	if (LISTED) {
 		// (grid sized by the capacity `nlist`: the count is on the device, twoview_refill_kernel)
 		const uint32_t nflag = cflag[0];
-		const int k = blockIdx.x*SC_TW + tid;
+		const int k = bid*SC_TW + tid;
 		listed_on = k < nlist && (uint32_t)k < nflag;
 		const uint32_t q = listed_on ? cflag[1 + k] : 0u;
 		trow = (int)(q / (uint32_t)W); x = (int)(q % (uint32_t)W);
 	} else {
-		trow = blockIdx.x / tiles_per_row;
-		x = (blockIdx.x % tiles_per_row)*SC_TW + tid;
+		trow = bid / tiles_per_row;
+		x = (bid % tiles_per_row)*SC_TW + tid;
 	}
 	const int y = y0 + trow;
 
@@ -1404,7 +1408,7 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 	}
 	if (listed_on && x < W) L.depth[(size_t)y*W + x] = depth;
 	if (LISTED || !cnt) return;                        // (the pixels were counted by the certified scan)
-	// the workgroup is one wave: its counts are summed by lane shuffles, one atomic each
+	// the tile is one wave: its counts are summed by lane shuffles, one atomic each
 	n_eval = wave_sum_u32(n_eval); n_pix = wave_sum_u32(n_pix); bad = wave_sum_u32(bad); n_flag = wave_sum_u32(n_flag);
 	if (tid == 0) {
 		if (n_eval) atomicAdd(&cnt->n_eval, (unsigned long long)n_eval);
@@ -1412,6 +1416,389 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 		if (bad) atomicAdd(&cnt->not_row_aligned, (unsigned long long)bad);
 		if (CERT && n_pix) atomicAdd(&cnt->n_certified, (unsigned long long)n_pix);
 		if (CERT && n_flag) atomicAdd(&cnt->n_flagged, (unsigned long long)n_flag);
+	}
+}
+
+// tilelist == nullptr: one workgroup per tile of the band (LISTED: per 64 listed pixels).  tilelist = [count | tile
+// indices]: behind twoview_tscan_kernel, only the tiles it left (a pixel whose curve is not certainly the template's),
+// shared by the launch's workgroups in a grid-stride loop; the count is read on the device.
+template <bool CERT, bool LISTED>
+__global__ __launch_bounds__(SC_TW, CERT ? SC_OCC - 1 : SC_OCC)
+void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                         int y0, int nrows, const double *__restrict__ tnum,
+                         const double *__restrict__ cost, int cstride,
+                         Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
+                         uint32_t *__restrict__ cflag, int nlist, CertBound cb, const double *__restrict__ pexact,
+                         const uint32_t *__restrict__ tilelist)
+{
+	if (LISTED || !tilelist) {
+		twoview_scan_tile<CERT, LISTED>((int)blockIdx.x, views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb, pexact);
+		return;
+	}
+	const uint32_t n = tilelist[0];
+	for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+		twoview_scan_tile<CERT, LISTED>((int)tilelist[1 + i], views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb, pexact);
+		__syncthreads();                                              // (the tile's LDS is reused)
+	}
+}
+
+// ------------------------------------------------------------------ template scan
+// On a rectified rig the candidate sequence of a pixel is, up to roundings, the same for every pixel of the image: the
+// label projections differ from pixel to pixel only in the last bits, so every pixel keeps the same labels and its kept
+// points truncate to x + (an offset that depends on the label alone).  twoview_scan_kernel nevertheless re-derives the
+// sequence per pixel -- ~150 instructions per (pixel, label): projection, one-pixel test, truncations, segment set-up,
+// per-candidate queueing -- and that, not the look-ups, is its time (2.3 ms per C3 launch).
+//
+// Here the sequence is made ONCE per pass, by the reference's own operations at one pixel (twoview_template_kernel:
+// per label its state -- not projectable / first point / dropped by the one-pixel test / kept -- and the kept point's
+// column offset; the visiting order of all candidate columns as offsets), and every pixel only VERIFIES that its own
+// curve is that one: label by label with the certified projections of DESIGN.md 2c (fast_project: 3 fused multiply-adds
+// and a reciprocal, with a proven bound on its distance from the reference's value) -- the projectability test on the
+// reference's own t, the one-pixel test decided beyond its bound and as the template has it, both coordinates of a kept
+// point truncating certainly and to the template's column and the pixel's own row.  A pixel that passes has the
+// template's candidate list, entry for entry (the reference's list: twoviewstereo.cpp:999-1054); the look-ups then run
+// over the shared sequence with every lane of the wave on the same entry: no queue, no divergence, the 32 pixels of a
+// tile reading one 256-byte line of the cost rows per entry.  A wave with a pixel that does not pass (a decision inside
+// its bound, a range that does not match) puts its tile on a list, and twoview_scan_kernel -- launched behind this
+// kernel for exactly those tiles -- does them the old way.  Nothing is trusted that is not checked per pixel.
+#define TS_MAXD 1024                   // labels a template holds (more: the old kernel)
+#define TS_MAXS 6144                   // candidate entries
+#define TS_MAXSPAN 1024                // smax - smin + 1
+struct ScanTemplate {
+	int32_t ok, nS, smin, smax, x0, y0;
+	double tabs, tmin, tmax;            // max |tnum[d]| (bound of |t| for fast_proj_setup), smallest and largest tnum[d]
+	// (32-bit entries: a wave reads them with SCALAR loads -- the index is uniform -- eight at a time; bytes and shorts
+	// would come through the vector memory path, a dependent round trip per label)
+	alignas(32) int32_t lab[TS_MAXD + 8];   // per label: state | offset << 8; state 0 not projectable, 1 first point, 2 dropped
+	                                    // (step < 1 pixel), 3 kept, 4 padding behind the last label; offset (first / kept): trunc(x2) - x
+	alignas(32) int32_t S[TS_MAXS + 8]; // candidate columns in visiting order, relative to x
+};
+size_t scan_template_bytes() { return sizeof(ScanTemplate); }
+
+__global__ __launch_bounds__(256)
+void twoview_template_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P, int y0, int nrows,
+                             const double *__restrict__ tnum, ScanTemplate *__restrict__ tpl)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	__shared__ double sx[TS_MAXD], sy[TS_MAXD];
+	__shared__ double s_red[4], s_rmin[4], s_rmax[4];
+	const int D = P.num_depth_levels, tid = threadIdx.x;
+	const int px = L.w/2, py = y0 + nrows/2;
+	if (D > TS_MAXD) { if (tid == 0) tpl->ok = 0; return; }
+	const Ray ray = cam_unproject(L.cam, (px + 0.5) / P.image_scale, (py + 0.5) / P.image_scale);
+	const Vec3 nrm = normalized(load3(L.cam.pdir));
+	const double nd = dot(nrm, ray.dir);
+	const SharedDivisor nd_sd = shared_divisor(nd);
+	double tabs = 0.0, tmn = __builtin_inf(), tmx = -__builtin_inf();
+	for (int d = tid; d < D; d += 256) {
+		double x2, y2;
+		const bool ok = !(fabs(nd) < 1e-10) && pinhole_project_label_sd(ray, nd_sd, tnum[d], Rv.cam, P.image_scale, x2, y2);
+		sx[d] = ok ? x2 : __builtin_nan("");
+		sy[d] = ok ? y2 : 0.0;
+		tabs = fmax(tabs, fabs(tnum[d]));
+		tmn = fmin(tmn, tnum[d]); tmx = fmax(tmx, tnum[d]);
+	}
+#pragma unroll
+	for (int dlt = 1; dlt < 64; dlt <<= 1) {
+		tabs = fmax(tabs, __shfl_xor(tabs, dlt)); tmn = fmin(tmn, __shfl_xor(tmn, dlt)); tmx = fmax(tmx, __shfl_xor(tmx, dlt));
+	}
+	if ((tid & 63) == 0) { s_red[tid >> 6] = tabs; s_rmin[tid >> 6] = tmn; s_rmax[tid >> 6] = tmx; }
+	__syncthreads();
+	// ---- the keep chain: strictly sequential (a label is compared with the last KEPT one), so one lane walks it -- over
+	// LDS only: states and columns of the kept points; the next label's projection is read while this one is decided
+	__shared__ int s_lab[TS_MAXD];
+	__shared__ int s_seg[TS_MAXD][4];                                 // per kept label: a, b (floor columns relative to px), start in S, cover before: lo | hi<<16 biased
+	__shared__ int s_hdr[8];
+	if (tid == 0) {
+		for (int k = 1; k < 4; ++k) { tabs = fmax(tabs, s_red[k]); tmn = fmin(tmn, s_rmin[k]); tmx = fmax(tmx, s_rmax[k]); }
+		int ok = fabs(nd) < 1e-10 ? 0 : 1, nS = 0, nseg = 0, smin = 2147483647, smax = -2147483647;
+		double x1 = __builtin_nan(""), y1 = 0.0;
+		int jx1 = 0, jy1 = 0;
+		double nx = D > 0 ? sx[0] : 0.0, ny = D > 0 ? sy[0] : 0.0;
+		for (int d = 0; d < D && ok; ++d) {
+			const double x2 = nx, y2 = ny;
+			if (d + 1 < D) { nx = sx[d + 1]; ny = sy[d + 1]; }
+			if (isnan_d(x2)) { s_lab[d] = 0; continue; }                  // (a projection that succeeds is never NaN: finite cameras, t >= 1e-10)
+			if (isnan_d(x1)) {
+				x1 = x2; y1 = y2; jx1 = trunc_sat(x2); jy1 = trunc_sat(y2);
+				if (jy1 != py || abs(jx1 - px) > 30000) ok = 0;
+				s_lab[d] = 1 | ((jx1 - px) << 8);
+				continue;
+			}
+			const double dx = x2 - x1, dy = y2 - y1;
+			if (!(dx*dx + dy*dy >= 1)) { s_lab[d] = 2; continue; }
+			const int ix0 = jx1, ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+			if (jy1 != py || iy1 != py || abs(ix1 - px) > 30000) { ok = 0; break; }   // a segment off the row: not this kernel's case
+			jx1 = ix1; jy1 = iy1;
+			s_lab[d] = 3 | ((ix1 - px) << 8);
+			// LineIterator on one row: (a..b, y) in ascending x whatever the direction of the segment (lineiter.hpp:96-111)
+			const int sa = (ix0 < ix1 ? ix0 : ix1) - px, sb = (ix0 < ix1 ? ix1 : ix0) - px;
+			if (nS + (sb - sa + 1) > TS_MAXS) { ok = 0; break; }
+			s_seg[nseg][0] = sa; s_seg[nseg][1] = sb; s_seg[nseg][2] = nS;
+			s_seg[nseg][3] = nseg ? ((smin + 32768) | ((smax + 32768) << 16)) : -1;   // columns covered by the earlier segments: one interval (consecutive segments share an end)
+			++nseg;
+			nS += sb - sa + 1;
+			if (sa < smin) smin = sa;
+			if (sb > smax) smax = sb;
+			x1 = x2; y1 = y2;
+		}
+		if (nS == 0) { smin = 0; smax = -1; }
+		if (nS > 0 && smax - smin + 1 > TS_MAXSPAN) ok = 0;
+		s_hdr[0] = ok; s_hdr[1] = nS; s_hdr[2] = nseg; s_hdr[3] = smin; s_hdr[4] = smax;
+		tpl->ok = ok; tpl->nS = nS; tpl->smin = smin; tpl->smax = smax; tpl->x0 = px; tpl->y0 = py; tpl->tabs = tabs; tpl->tmin = tmn; tpl->tmax = tmx;
+	}
+	__syncthreads();
+	// ---- everything else by all lanes: the label words, the candidate entries segment by segment.
+	// Entry = column offset (29 bits) | bit 30: high end of its segment | bit 29: a revisit (a column seen earlier in the
+	// sequence: it can never change the running minimum again; recorded, not used by the scan -- skipping the look-up of
+	// a third of the entries was measured and bought nothing, the flag being uniform but the lanes' work selects).
+	// (Bit 30: the template's columns are FLOOR offsets; the reference truncates towards zero, which moves a negative end
+	// point one column to the right: the in-image part of a segment changes only when its high end is column -1 -- the
+	// reference's segment then ends ON column 0.)
+	const int ok = s_hdr[0], nS = s_hdr[1], nseg = s_hdr[2], smin = s_hdr[3];
+	if (!ok) return;
+	for (int d = tid; d < ((D + 7) & ~7); d += 256) tpl->lab[d] = d < D ? s_lab[d] : 4;
+	for (int k = tid; k < nseg; k += 256) {
+		const int sa = s_seg[k][0], sb = s_seg[k][1], at = s_seg[k][2], cov = s_seg[k][3];
+		const int clo = cov == -1 ? 1 : (cov & 0xffff) - 32768, chi = cov == -1 ? 0 : ((cov >> 16) & 0xffff) - 32768;
+		for (int c = sa; c <= sb; ++c)
+			tpl->S[at + (c - sa)] = (c & 0x1fffffff) | (c == sb ? 0x40000000 : 0) | ((c >= clo && c <= chi) ? 0x20000000 : 0);
+	}
+	for (int j = nS + tid; j < ((nS + 7) & ~7); j += 256) tpl->S[j] = (smin & 0x1fffffff) | 0x20000000;   // (padding: a column whose mask byte exists; never counted)
+}
+
+#define TS_U 8                         // look-ups in flight per lane
+// one tile; returns false when the tile is left to twoview_scan_kernel
+template <bool CERT>
+__device__ __forceinline__
+bool twoview_tscan_tile(const int bid, const ViewDev *__restrict__ views, int ref, int oth, const srh_params &P,
+                        int y0, int nrows, const double *__restrict__ tnum,
+                        const double *__restrict__ cost, int cstride,
+                        Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
+                        uint32_t *__restrict__ cflag, const CertBound &cb, const double *__restrict__ pexact,
+                        const ScanTemplate *__restrict__ tpl, unsigned char *smask, unsigned &n_eval_acc, unsigned &n_pix_acc, unsigned &n_flag_acc)
+{
+	const ViewDev &L = views[ref];
+	const ViewDev &Rv = views[oth];
+	const int W = L.w, OW = Rv.w, OH = Rv.h;
+	const int tiles_per_row = (W + SC_TW - 1)/SC_TW;
+	const int tid = threadIdx.x;
+	const int trow = bid / tiles_per_row;
+	const int xt = (bid % tiles_per_row)*SC_TW, x = xt + tid;
+	const int y = y0 + trow;
+	const int D = P.num_depth_levels;
+#ifdef SRH_EXPERIMENT
+	if (g_exp_scan_mode == 6) return true;                           // timing experiment: the loop alone
+#endif
+	const int nS = tpl->nS, smin = tpl->smin, smax = tpl->smax;
+	const bool active = x < W && L.mask[(size_t)y*W + x] == 1;
+	bool good = true;
+	Ray ray;
+	int lo = 0, hi = -1;
+	if (active) {
+		ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
+		const PixRange pr = prange[(size_t)trow*W + x];
+		lo = pr.lo; hi = pr.hi;
+		// the range the cost rows were made for must be the template's, clipped to the image
+		int wlo = x + smin, whi = x + smax;
+		if (wlo < 0) wlo = 0;
+		if (whi > OW - 1) whi = OW - 1;
+		if (nS > 0 && whi >= wlo) good = lo <= wlo && hi >= whi;       // (every candidate column has its cost)
+		if (y < 0 || y >= OH) good = false;
+		const Vec3 nrm = normalized(load3(L.cam.pdir));
+		const double nd = dot(nrm, ray.dir);
+		if (fabs(nd) < 1e-10) good = false;
+		const SharedDivisor nd_sd = shared_divisor(nd);
+		bool verify = true;
+#ifdef SRH_EXPERIMENT
+		verify = g_exp_scan_mode != 3 && g_exp_scan_mode != 5;        // timing experiment: no verification
+#endif
+		if (verify) {
+		const FastProj fp = fast_proj_setup(ray, Rv.cam, (tpl->tabs/fabs(nd))*1.000001);
+		// ---- one bound for the pixel instead of one per label.  Every label's t = fl(tnum[d] / nd) lies in [tlo, thi] (the
+		// correctly rounded division is monotone; tnum's extremes come with the template).  On that interval k(t) = A + t*B is
+		// linear: |k_x|, |k_y| are largest at an end, |k_z| smallest at an end (same sign at both ends: no pole inside), so
+		// fast_project's bound e(t) <= eU, its formula evaluated with those extremes.  The y coordinate of the fast form is a
+		// Moebius function of t, monotone between the ends: the reference's y2 of EVERY label lies within eU of [ylo, yhi], made
+		// from the two end values -- inside [y, y + 1) means every kept point truncates to row y, and any two labels' y2 differ
+		// by at most dyU = yhi - ylo.  What is left per label is the x coordinate.
+		const double ta = div_by(tpl->tmin, nd_sd), tb = div_by(tpl->tmax, nd_sd);
+		const double tlo = fmin(ta, tb), thi = fmax(ta, tb);
+		const double kzl = __builtin_fma(tlo, fp.B.z, fp.A.z), kzh = __builtin_fma(thi, fp.B.z, fp.A.z);
+		const double kyl = __builtin_fma(tlo, fp.B.y, fp.A.y), kyh = __builtin_fma(thi, fp.B.y, fp.A.y);
+		const double kxm = fmax(fabs(__builtin_fma(tlo, fp.B.x, fp.A.x)), fabs(__builtin_fma(thi, fp.B.x, fp.A.x)));
+		const double kzmin = fmin(fabs(kzl), fabs(kzh));
+		const double rU = (1.0/kzmin)*1.000001;
+		const double amU = fmax(kxm, fmax(fabs(kyl), fabs(kyh)))*rU;
+		const double eU = __builtin_fma(amU*P.image_scale, 0x1p-49, (fp.ek + amU*fp.ekz)*(rU*P.image_scale*1.002))*1.0001;
+		const double yfl = (kyl/kzl)*P.image_scale, yfh = (kyh/kzh)*P.image_scale;
+		const double ylo = fmin(yfl, yfh) - 2*eU, yhi = fmax(yfl, yfh) + 2*eU, dyU = yhi - ylo;
+		good = good && kzl*kzh > 0.0 && fp.ekz*rU <= 0x1p-10 && eU < 0x1p-20 && ylo >= (double)y && yhi < (double)(y + 1);
+		const double se = 2*eU;
+		const double c1 = 2.02*se, c0 = __builtin_fma(2.02*se, se, dyU*dyU);   // |dd_reference - dx^2| <= 2|dx|se + se^2 + dyU^2 (+ roundings)
+		const double rsc = P.image_scale;
+		double x1 = 0.0;
+		for (int d0 = 0; d0 < D; d0 += 8) {
+			// (uniform addresses, whole eights, aligned: two s_load_dwordx4 and two s_load_dwordx8 per eight labels)
+			int lab[8];
+			double tn[8];
+			{
+				const int4 la = reinterpret_cast<const int4 *>(&tpl->lab[d0])[0], lb = reinterpret_cast<const int4 *>(&tpl->lab[d0])[1];
+				lab[0] = la.x; lab[1] = la.y; lab[2] = la.z; lab[3] = la.w; lab[4] = lb.x; lab[5] = lb.y; lab[6] = lb.z; lab[7] = lb.w;
+				const double4 ta4 = reinterpret_cast<const double4 *>(&tnum[d0])[0], tb4 = reinterpret_cast<const double4 *>(&tnum[d0])[1];
+				tn[0] = ta4.x; tn[1] = ta4.y; tn[2] = ta4.z; tn[3] = ta4.w; tn[4] = tb4.x; tn[5] = tb4.y; tn[6] = tb4.z; tn[7] = tb4.w;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int st = lab[u] & 255, off = lab[u] >> 8;
+				if (st == 4) continue;
+				const double t = div_by(tn[u], nd_sd);                     // the reference's own t (pinhole_project_label_sd)
+				const bool tv = !(t < 1e-10);
+				if (st == 0) { good = good && !tv; continue; }
+				// fast_project's x coordinate (srh_walk.hpp): within eU of the reference's
+				const double kx = __builtin_fma(t, fp.B.x, fp.A.x), kz = __builtin_fma(t, fp.B.z, fp.A.z);
+				double r = __builtin_amdgcn_rcp(kz);
+				r = __builtin_fma(r, __builtin_fma(-kz, r, 1.0), r);
+				r = __builtin_fma(r, __builtin_fma(-kz, r, 1.0), r);
+				const double x2 = kx*(r*rsc);
+				const double dx = x2 - x1;
+				const double dd = dx*dx;
+				const bool certain = fabs(dd - 1.0) > __builtin_fma(dd, 0x1p-48, __builtin_fma(c1, fabs(dx), c0));
+				if (st == 2) { good = good && tv && certain && !(dd >= 1); continue; }
+				// first / kept point: x truncates certainly and to the template's column.  The reference truncates towards zero:
+				// left of the image (x2 < 0) its integer is the template's (floor) column + 1, which changes the in-image part of a
+				// segment only when the segment's high end is column -1 (the look-up loop handles that case)
+				const int ti = (int)x2;
+				const bool colok = ti == x + off + (x2 < 0.0 ? 1 : 0);
+				good = good && tv && (st == 1 || (certain && dd >= 1)) && trunc_certain(x2, eU) && colok;
+				x1 = x2;
+			}
+		}
+		}
+	}
+	if (__any(active && !good)) return false;                        // twoview_scan_kernel does this tile
+
+	// mask bytes of row y of the other view, columns [xt + smin, xt + SC_TW + smax)
+	const int mbase = xt + smin, mlen = nS > 0 ? SC_TW + (smax - smin) : 0;
+	for (int k = tid; k < mlen; k += SC_TW) {
+		const int tx = mbase + k;
+		smask[k] = ((unsigned)tx < (unsigned)OW) ? Rv.mask[(size_t)y*OW + tx] : (unsigned char)0;
+	}
+	__syncthreads();
+
+	unsigned n_eval = 0, n_flag = 0;
+	double depth = __builtin_nan("");
+	if (active) {
+		n_pix_acc += 1;
+		const double *crow = cost + ((size_t)trow*((W + DC_TP - 1)/DC_TP) + (x/DC_TP))*(size_t)cstride*DC_TP + (x % DC_TP);
+		double minCost = __builtin_inf(), secondBest = __builtin_inf();
+		int wcol = -1;
+		bool px_sure = false;
+		if (CERT && pexact) { const double *pc = pexact + ((size_t)trow*W + x)*4; px_sure = cert_pixel_exact(cb, pc[2], pc[3]); }
+		const int xm = tid - smin;                                     // smask index of column x + s: tid + (s - smin)
+		const int xlo = x - lo;                                        // cost-row entry of column x + s: s + xlo
+		int nSe = nS;
+#ifdef SRH_EXPERIMENT
+		if (g_exp_scan_mode == 4 || g_exp_scan_mode == 5) nSe = 0;     // timing experiment: no look-ups
+#endif
+		// eight template entries at a time: the entries by two scalar loads, the eight mask bytes by LDS reads in flight
+		// together, the eight costs by loads in flight together, then the reference's running-min rule entry by entry.
+		// LEFT (tile-uniform): a column of the tile may be -1 -- see the template: a segment whose high end is column -1
+		// ends on column 0 in the reference (truncation towards zero)
+		auto lookups = [&](auto left_c) {
+			constexpr bool LEFT = decltype(left_c)::value;
+			for (int j0 = 0; j0 < nSe; j0 += TS_U) {
+				int sv[TS_U], kk[TS_U];
+				unsigned char mb[TS_U];
+				double c[TS_U];
+				{
+					const int4 sa = reinterpret_cast<const int4 *>(&tpl->S[j0])[0], sb = reinterpret_cast<const int4 *>(&tpl->S[j0])[1];
+					sv[0] = sa.x; sv[1] = sa.y; sv[2] = sa.z; sv[3] = sa.w; sv[4] = sb.x; sv[5] = sb.y; sv[6] = sb.z; sv[7] = sb.w;
+				}
+#pragma unroll
+				for (int u = 0; u < TS_U; ++u) {
+					int s = (sv[u] << 3) >> 3;                                 // (sign-extended 29-bit offset; the padding behind the last entry is smin)
+					if (LEFT) s += ((sv[u] & 0x40000000) && x + s == -1) ? 1 : 0;
+					sv[u] = s;
+					mb[u] = smask[xm + s];
+				}
+#pragma unroll
+				for (int u = 0; u < TS_U; ++u) {
+					const bool white = j0 + u < nSe && mb[u] == 1;             // (off-image columns hold 0)
+					n_eval += white ? 1u : 0u;
+					kk[u] = white ? xlo + sv[u] : -1;
+					c[u] = crow[(unsigned)(white ? kk[u] : 0)*(unsigned)DC_TP];   // (unconditional: no branch around a load; entry 0 exists)
+				}
+#pragma unroll
+				for (int u = 0; u < TS_U; ++u) {
+					const bool on = kk[u] >= 0;
+					const double cv = c[u];
+					const double t = on ? cv + P.wta_margin : __builtin_inf();
+					if (CERT) {
+						// (twoview_scan_kernel<true, false>'s test; the comparison is decided beyond the bound almost always: the rest
+						// of the test only when some lane's is not)
+						const bool nearby = on && !(fabs(t - minCost) > 2.5*cb.e0);
+						if (__any(nearby)) {
+							if (nearby && kk[u] != wcol &&
+							    !(cert_sure(cv, P.max_color_diff, cb.m_hi) && cert_sure(minCost, P.max_color_diff, cb.m_hi)) &&
+							    !(px_sure && cv == cv)) n_flag = 1;
+						}
+					}
+					if (t < minCost) { secondBest = minCost; minCost = cv; wcol = kk[u]; }   // twoviewstereo.cpp:293-301
+				}
+			}
+		};
+		if (xt + smin < 0) lookups(std::true_type()); else lookups(std::false_type());
+		if (wcol >= 0) depth = candidate_depth(L.cam, Rv.cam, P, ray, lo + wcol, y);
+		if (minCost > P.second_best_factor*secondBest) depth = __builtin_inf();
+		if (CERT && wcol >= 0) {
+			const double rhs = P.second_best_factor*secondBest;
+			const double tol = __builtin_fma(fmin(fabs(rhs), 1e300), 1e-15, (1.0 + fabs(P.second_best_factor))*cb.e0);
+			if (!(fabs(minCost - rhs) > tol) && !px_sure &&
+			    !(cert_sure(minCost, P.max_color_diff, cb.m_hi) && cert_sure(secondBest, P.max_color_diff, cb.m_hi))) n_flag = 1;
+		}
+		if (CERT && n_flag) cflag[1 + atomicAdd(&cflag[0], 1u)] = (uint32_t)((size_t)trow*W + x);
+	}
+	if (x < W) L.depth[(size_t)y*W + x] = depth;
+	n_eval_acc += n_eval; n_flag_acc += n_flag;
+	return true;
+}
+
+// PERSISTENT: a few thousand one-wave workgroups share the band's tiles in a grid-stride loop (one workgroup per tile --
+// 32 400 of them on C3 -- costs 0.8 ms of workgroup launches whatever the tiles do: the fixed part of twoview_scan_kernel);
+// the counters travel in registers and are added once per workgroup.  A tile that does not verify goes on `tilelist`
+// = [count | tile indices] for twoview_scan_kernel.
+template <bool CERT>
+__global__ __launch_bounds__(SC_TW, 4)
+void twoview_tscan_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
+                          int y0, int nrows, const double *__restrict__ tnum,
+                          const double *__restrict__ cost, int cstride,
+                          Counters *__restrict__ cnt, const PixRange *__restrict__ prange,
+                          uint32_t *__restrict__ cflag, CertBound cb, const double *__restrict__ pexact,
+                          const ScanTemplate *__restrict__ tpl, uint32_t *__restrict__ tilelist)
+{
+	__shared__ unsigned char smask[SC_TW + TS_MAXSPAN + 16];
+	const int W = views[ref].w;
+	const int ntiles = ((W + SC_TW - 1)/SC_TW)*nrows;
+	const int tid = threadIdx.x;
+	const bool tok = tpl->ok != 0;
+	unsigned n_eval = 0, n_pix = 0, n_flag = 0, n_tpl = 0, n_walk = 0;
+	for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+		const bool done = tok && twoview_tscan_tile<CERT>(bid, views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, cb, pexact,
+		                                                 tpl, smask, n_eval, n_pix, n_flag);
+		if (!done) { if (tid == 0) tilelist[1 + atomicAdd(&tilelist[0], 1u)] = (uint32_t)bid; ++n_walk; } else ++n_tpl;
+		__syncthreads();                                              // (smask is reused)
+	}
+	if (!cnt) return;
+	n_eval = wave_sum_u32(n_eval); n_pix = wave_sum_u32(n_pix); n_flag = wave_sum_u32(n_flag);
+	if (tid == 0) {
+		if (n_eval) atomicAdd(&cnt->n_eval, (unsigned long long)n_eval);
+		if (n_pix) atomicAdd(&cnt->n_pixels, (unsigned long long)n_pix);
+		if (CERT && n_pix) atomicAdd(&cnt->n_certified, (unsigned long long)n_pix);
+		if (CERT && n_flag) atomicAdd(&cnt->n_flagged, (unsigned long long)n_flag);
+		if (n_tpl) atomicAdd(&cnt->scan_tiles_template, (unsigned long long)n_tpl);
+		if (n_walk) atomicAdd(&cnt->scan_tiles_walked, (unsigned long long)n_walk);
 	}
 }
 
@@ -1528,25 +1915,42 @@ void twoview_rescan_wave_kernel(const ViewDev *__restrict__ views, int ref, int 
 
 // cflag == nullptr: the exact scan.  cflag, nlist < 0: the certified scan (flags into cflag).  cflag, nlist >= 0: the
 // exact scan of the nlist pixels listed in cflag[1..].
+void launch_scan_template(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0, int nrows,
+                          const double *tnum, void *tpl)
+{
+	hipLaunchKernelGGL(twoview_template_kernel, dim3(1), dim3(256), 0, st, views, ref, oth, P, y0, nrows, tnum, (ScanTemplate *)tpl);
+}
+
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
-                         Counters *cnt, const PixRange *prange, uint32_t *cflag, int nlist, const double *pexact)
+                         Counters *cnt, const PixRange *prange, uint32_t *cflag, int nlist, const double *pexact,
+                         const void *tpl, uint32_t *tilelist, int num_cus)
 {
 	const int tiles = (width + SC_TW - 1)/SC_TW;
 	const CertBound cb = cert_bound(P);
-	if (!cflag)
-		hipLaunchKernelGGL((twoview_scan_kernel<false, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, nullptr, 0, cb, nullptr);
-	else if (nlist < 0)
-		hipLaunchKernelGGL((twoview_scan_kernel<true, false>), dim3((unsigned)(tiles*nrows)), dim3(SC_TW), 0, st,
-		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, 0, cb, pexact);
-	else if (nlist > 0 && P.num_depth_levels <= RSW_MAXD && cstride <= 4096)
+	const ScanTemplate *tp = (const ScanTemplate *)tpl;
+	if (!tp) tilelist = nullptr;
+	// template scan: persistent one-wave workgroups (eight per SIMD); the tiles it leaves: a grid-stride launch over its list
+	const unsigned pgrid = (unsigned)std::min<long long>((long long)tiles*nrows, (long long)num_cus*4*8);
+	const unsigned wgrid = tp ? (unsigned)std::min<long long>((long long)tiles*nrows, (long long)num_cus*4*4) : (unsigned)(tiles*nrows);
+	if (tp) (void)hipMemsetAsync(tilelist, 0, sizeof(uint32_t), st);
+	if (!cflag) {
+		if (tp) hipLaunchKernelGGL((twoview_tscan_kernel<false>), dim3(pgrid), dim3(SC_TW), 0, st,
+		                           views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, nullptr, cb, nullptr, tp, tilelist);
+		hipLaunchKernelGGL((twoview_scan_kernel<false, false>), dim3(wgrid), dim3(SC_TW), 0, st,
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, nullptr, 0, cb, nullptr, tilelist);
+	} else if (nlist < 0) {
+		if (tp) hipLaunchKernelGGL((twoview_tscan_kernel<true>), dim3(pgrid), dim3(SC_TW), 0, st,
+		                           views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, cb, pexact, tp, tilelist);
+		hipLaunchKernelGGL((twoview_scan_kernel<true, false>), dim3(wgrid), dim3(SC_TW), 0, st,
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, 0, cb, pexact, tilelist);
+	} else if (nlist > 0 && P.num_depth_levels <= RSW_MAXD && cstride <= 4096)
 		// (the list may hold up to the band's pixels: workgroups share it in a grid-stride loop, the count is read on the device)
 		hipLaunchKernelGGL(twoview_rescan_wave_kernel, dim3((unsigned)(nlist < 2048 ? nlist : 2048)), dim3(64), 0, st,
 		                   views, ref, oth, P, y0, tnum, cost, cstride, prange, cflag, nlist, cnt);
 	else if (nlist > 0)
 		hipLaunchKernelGGL((twoview_scan_kernel<false, true>), dim3((unsigned)((nlist + SC_TW - 1)/SC_TW)), dim3(SC_TW), 0, st,
-		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb, nullptr);
+		                   views, ref, oth, P, y0, nrows, tnum, cost, cstride, cnt, prange, cflag, nlist, cb, nullptr, nullptr);
 }
 
 } // namespace srh

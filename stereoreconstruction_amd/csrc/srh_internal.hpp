@@ -148,6 +148,7 @@ struct Counters {
 	unsigned long long strip_overflow;    // strip kernel: tiles whose candidate range does not fit one LDS chunk
 	unsigned long long n_certified, n_flagged;   // certified scan: reference pixels scanned on fused costs / flagged for the exact redo
 	unsigned long long cert_overflow;     // certified redo: a flagged pixel with more candidates than the wave rescan holds (the pass is repeated in mode 0)
+	unsigned long long scan_tiles_template, scan_tiles_walked;   // dense TwoView scan: 64-pixel tiles settled by the template scan / left to the per-pixel walk
 	unsigned long long mvs_waves_staged, mvs_waves_listed;   // MultiViewStereo walk kernel: waves (with candidates) left to the staged / the gathering cost kernel
 	unsigned int strip_ticket, strip_pad; // strip kernel: work-item counter of the current launch
 	unsigned long long dbg_cycles, dbg_blocks, dbg_total_cycles, dbg_waves;   // SRH_DENSE_DBG=2 instrumentation
@@ -208,7 +209,13 @@ bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, in
 void launch_twoview_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, const double *tnum, const double *cost, int cstride,
                          Counters *cnt, const PixRange *prange, uint32_t *cflag = nullptr, int nlist = -1,
-                         const double *pexact = nullptr);   // certified scan: the band's pconst when the cost kernel applies cert_pixel_exact
+                         const double *pexact = nullptr,    // certified scan: the band's pconst when the cost kernel applies cert_pixel_exact
+                         const void *tpl = nullptr, uint32_t *tilelist = nullptr,   // template scan (launch_scan_template) + the tiles it leaves: [count | tile indices]
+                         int num_cus = 256);
+// the pass's candidate template (twoview_template_kernel) into `tpl` (scan_template_bytes() bytes)
+size_t scan_template_bytes();
+void launch_scan_template(hipStream_t st, const ViewDev *views, int ref, int oth, const srh_params &P, int y0, int nrows,
+                          const double *tnum, void *tpl);
 // the cost rows of the flagged pixels in the reference's arithmetic; `cap` workgroups (the count is read on the device;
 // a count above cap is reported in Counters::cert_overflow); wimg: LDS-image windows, else tile-major
 bool launch_twoview_refill(hipStream_t st, int width, const srh_params &P, int y0, const PixRange *prange, const uint32_t *cflag, int cap,

@@ -1,0 +1,91 @@
+"""The template scan of the dense TwoView path (twoview_tscan_kernel, srh_dense.hip): the candidate sequence made once per
+pass by the reference's operations at one pixel, every pixel verifying label by label (certified projections)
+that its own curve is that one, the look-ups running over the shared sequence.  Against the per-pixel curve walk
+(twoview_scan_kernel, option tscan = 0): the same depth bits, the same reference-evaluation counts, in both arithmetics;
+the statistics say which of the two settled the tiles; a rig the template cannot serve is walked entirely."""
+import numpy as np
+import pytest
+
+import cases
+from stereoreconstruction_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("geodesic_rect", dict()), ("adaptive_rect", dict()), ("geodesic_masks", dict()), ("adaptive_masks", dict(w=97, h=53, D=24)),
+         ("geodesic_r2", dict()), ("geodesic_rect", dict(w=200, h=70, D=48)), ("adaptive_rect", dict(w=161, h=37, D=130)),
+         ("geodesic_scaled", dict())]
+
+
+def _both(ctx, p, arith):
+    out = {}
+    for ts in (1, 0):
+        ctx.set_option("tscan", ts)
+        ctx.set_option("arith", arith)
+        try:
+            res = []
+            for a, b in ((0, 1), (1, 0)):
+                ctx.twoview_wta(a, b, p)
+                res.append((ctx.download_depth(a), ctx.stats()))
+            out[ts] = res
+        finally:
+            ctx.set_option("tscan", 1)
+            ctx.set_option("arith", capi.ARITH_DEFAULT)
+    return out
+
+
+@pytest.mark.parametrize("name,over", CASES)
+@pytest.mark.parametrize("arith", [capi.ARITH_CERTIFIED, capi.ARITH_EXACT], ids=["certified", "exact"])
+def test_template_scan_equals_the_curve_walk(hip_ctx, name, over, arith):
+    case = cases.get_twoview(name, **over)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    out = _both(hip_ctx, p, arith)
+    for d in range(2):
+        (m1, s1), (m0, s0) = out[1][d], out[0][d]
+        assert s1["used_dense_path"] and s0["used_dense_path"]
+        assert np.array_equal(m1.view(np.uint64), m0.view(np.uint64)), (name, over, d)
+        assert s1["n_eval"] == s0["n_eval"] and s1["n_pixels"] == s0["n_pixels"], (name, d, s1["n_eval"], s0["n_eval"])
+        assert s0["scan_tiles_template"] == 0 and s0["scan_tiles_walked"] == 0
+        assert s1["scan_tiles_template"] > 0, (name, d, s1)
+        # (pixels whose range is cut by the image border verify like any other: the template's columns are clipped per pixel)
+        assert s1["scan_tiles_walked"] <= s1["scan_tiles_template"] // 8, (name, d, s1)
+
+
+def test_a_rig_the_template_cannot_serve_is_walked(hip_ctx):
+    """force_dense proposes the dense plan for a verged pair: the template's segments leave the row, every tile goes to the
+    curve walk, which refutes the plan (candidates off their row) -- the pass is redone on the general kernels as before."""
+    case = cases.get_twoview("adaptive_verged", w=72, h=44, D=20, radius=5)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    hip_ctx.twoview_wta(0, 1, p)
+    want = hip_ctx.download_depth(0)
+    hip_ctx.set_option("force_dense", 1)
+    try:
+        hip_ctx.twoview_wta(0, 1, p)
+        st = hip_ctx.stats()
+        got = hip_ctx.download_depth(0)
+    finally:
+        hip_ctx.set_option("force_dense", 0)
+    assert not st["used_dense_path"]
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_template_scan_at_c3_size_with_a_narrow_mask(hip_ctx):
+    """C3 size, left -> right and back, a mask that keeps a band of columns next to the left border (where the reference's
+    truncation towards zero moves off-image end points) and a diagonal stripe: template scan == curve walk, bit for bit."""
+    W, H, D = 1920, 1080, 256
+    L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, 0x5EED0003)
+    yy, xx = np.mgrid[0:H, 0:W]
+    keep = (xx < 300) | (np.abs(xx - 2 * yy) < 150)
+    ml = np.where(keep, ml, 0).astype(np.uint8)
+    mr = np.where(keep | (xx > W - 280), mr, 0).astype(np.uint8)
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D)
+    hip_ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl))
+    hip_ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr))
+    p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
+    out = _both(hip_ctx, p, capi.ARITH_CERTIFIED)
+    for d in range(2):
+        (m1, s1), (m0, s0) = out[1][d], out[0][d]
+        assert np.array_equal(m1.view(np.uint64), m0.view(np.uint64)), d
+        assert s1["n_eval"] == s0["n_eval"] and s1["scan_tiles_template"] > 0 and s1["scan_tiles_walked"] == 0, (d, s1)
