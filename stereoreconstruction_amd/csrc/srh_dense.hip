@@ -1521,14 +1521,16 @@ void twoview_template_kernel(const ViewDev *__restrict__ views, int ref, int oth
 			if (d + 1 < D) { nx = sx[d + 1]; ny = sy[d + 1]; }
 			if (isnan_d(x2)) { s_lab[d] = 0; continue; }                  // (a projection that succeeds is never NaN: finite cameras, t >= 1e-10)
 			if (isnan_d(x1)) {
-				x1 = x2; y1 = y2; jx1 = trunc_sat(x2); jy1 = trunc_sat(y2);
+				// (FLOOR columns: the template pixel's own coordinates may be negative, where the reference's truncation towards
+				// zero is one column off the floor; the scan applies the truncation per pixel, see the entries' bit 30)
+				x1 = x2; y1 = y2; jx1 = fabs(x2) < 0x1p28 ? (int)floor(x2) : 1 << 30; jy1 = trunc_sat(y2);
 				if (jy1 != py || abs(jx1 - px) > 30000) ok = 0;
 				s_lab[d] = 1 | ((jx1 - px) << 8);
 				continue;
 			}
 			const double dx = x2 - x1, dy = y2 - y1;
 			if (!(dx*dx + dy*dy >= 1)) { s_lab[d] = 2; continue; }
-			const int ix0 = jx1, ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);
+			const int ix0 = jx1, ix1 = fabs(x2) < 0x1p28 ? (int)floor(x2) : 1 << 30, iy1 = trunc_sat(y2);
 			if (jy1 != py || iy1 != py || abs(ix1 - px) > 30000) { ok = 0; break; }   // a segment off the row: not this kernel's case
 			jx1 = ix1; jy1 = iy1;
 			s_lab[d] = 3 | ((ix1 - px) << 8);
