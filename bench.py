@@ -444,6 +444,22 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         # (the last pass of the timed steps: right -> left)
         certified = {"pixels_scanned_on_fused_costs": stats["n_certified"], "flagged_and_redone_exactly": stats["n_flagged"],
                      "flagged_frac": round(stats["n_flagged"] / stats["n_certified"], 8)}
+    # both passes, one untimed run each: which path every direction took and what its certified scan flagged (C1: the real
+    # photographs of the example project -- the flagged fraction on natural texture)
+    passes = []
+    if not rows_shard and rank == 0:
+        for a, b in ((0, 1), (1, 0)):
+            ctx.twoview_wta(a, b, p)
+            st = ctx.stats()
+            passes.append({"direction": "left->right" if a == 0 else "right->left",
+                           "path": "dense" if st["used_dense_path"] else "candidate lists",
+                           "pixels": st["n_pixels"], "scanned_on_fused_costs": st["n_certified"], "flagged": st["n_flagged"],
+                           "flagged_frac": round(st["n_flagged"] / st["n_certified"], 8) if st["n_certified"] else None,
+                           "scan_tiles_template": st["scan_tiles_template"], "scan_tiles_walked": st["scan_tiles_walked"]})
+        if certified is None and any(q["scanned_on_fused_costs"] for q in passes):
+            certified = {}
+        if certified is not None:
+            certified["passes"] = passes
     hyp_per_step_per_gpu = 2 * W * H * D
     value = (1 if rows_shard else world) * hyp_per_step_per_gpu * args.steps / dt / 1e6
 
