@@ -557,7 +557,10 @@ static int quartic_root_0r(double a, double b, double c, double d, double e, dou
 		if (f > 0.0) lo = x; else hi = x;
 		const double df = ((4.0*a*x + 3.0*b)*x + 2.0*c)*x + d;
 		double xn = x - f/df;
-		if (!(xn > lo && xn < hi)) xn = 0.5*(lo + hi);
+		/* (closed bracket: a step that rounds to nothing leaves xn ON the end point x has just become -- that is convergence,
+		 * caught by the step test below; with the open test it sent the iteration to the bracket's mid-point, often r/2, to
+		 * converge all over again: 6 % of the roots of the C5 configuration took that detour) */
+		if (!(xn >= lo && xn <= hi)) xn = 0.5*(lo + hi);
 		const double dx = fabs(xn - x);
 		x = xn;
 		if (dx <= 1e-15*(fabs(x) + r)) break;

@@ -688,6 +688,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "exp_lds_pad")) { exp_set(-1, (int)value); return SRH_OK; }
 	if (!strcmp(name, "exp_scan_mode")) { exp_set_scan((int)value); return SRH_OK; }
 	if (!strcmp(name, "exp_walk_mode")) { exp_set_walk((int)value); return SRH_OK; }
+	if (!strcmp(name, "exp_rows_mode")) { exp_set_rows((int)value); return SRH_OK; }
 #endif
 	return fail(SRH_E_INVALID, "unknown option '%s'", name);
 }

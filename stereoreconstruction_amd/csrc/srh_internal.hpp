@@ -248,6 +248,7 @@ void geodesic_phases_fetch(unsigned long long out[5]);
 void exp_set(int repeat, int lds_pad);
 void exp_set_scan(int mode);
 void exp_set_walk(int mode);
+void exp_set_rows(int mode);
 #endif
 
 // Fused row-aligned TwoView kernel (geometry + cost + WTA per 16-pixel tile), srh_fused.hip.

@@ -17,7 +17,26 @@
 #include "srh_geom.hpp"
 #include "srh_walk.hpp"
 
+#include <cstdio>
+
 namespace srh {
+
+#ifdef SRH_EXPERIMENT
+__device__ int g_exp_rows_mode = 0;   // timing experiments of the list kernel: 1 no raster / visitor, 2 no Newton (root = guess), 3 no refraction
+__device__ unsigned long long g_exp_rl[4];
+void exp_set_rows(int mode) {
+	if (mode == -1) {                                              // print and clear the lockstep statistics
+		unsigned long long h[4] = {0, 0, 0, 0};
+		(void)hipDeviceSynchronize();
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_exp_rl), sizeof(h));
+		fprintf(stderr, "[srh exp] lockstep Newton: %llu roots, %.2f iterations each, %llu fell back to the loop (%.3g)\n", h[0], h[0] ? (double)h[1]/h[0] : 0.0, h[2], h[0] ? (double)h[2]/h[0] : 0.0);
+		unsigned long long z[4] = {0, 0, 0, 0};
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_rl), z, sizeof(z));
+		return;
+	}
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_rows_mode), &mode, sizeof(int));
+}
+#endif
 
 #define RW_NR 32                   // image rows a pixel's curve may cross (else: plain list path); a power of two
 #define RW_LT 128                  // threads of the list / scan kernels
@@ -45,6 +64,154 @@ struct RowsListVisitor {
 		if (cx > hi[r]) hi[r] = (short)cx;
 	}
 };
+
+// walk_curve<false> (srh_walk.hpp) for this kernel, the same operations in the same order with the redundant ones taken out:
+//   * the three quotients of a normalisation (dirv / r) and the two image coordinates (p.x / z, p.y / z) share their
+//     divisor's half of the division (shared_divisor / div_by: the same quotient bits); p.z / z is never used;
+//   * a segment with both end points inside the image needs none of LineWalk's bounds work (the closed-form skip of an
+//     off-image prefix, its 64-bit arithmetic);
+//   * the other camera's flags are read once.
+// Results are bit-identical to walk_curve<false>: tests/test_gpu_parity.py compares the lists, entry for entry.
+// quartic_root_0r (srh_geom.hpp; the oracle's quartic_root_0r) with the wave in LOCKSTEP.  The safeguarded Newton loop as
+// written -- a data-dependent trip count per lane, its bracket bookkeeping and three exits in branches -- was two thirds of
+// this kernel on C5 (11.4 of 16.9 ms: profiles/r05_c5_list_parts.txt): every lane waits for the wave's slowest, and the
+// loop's control flow costs as much as its arithmetic.  Here every lane takes the same RL_K Newton steps, the loop's
+// decisions made by selects: the iterates, the bracket [lo, hi] and the exits are the loop's own, operation for operation
+// (f == 0 -> that x; a step of at most 1e-15 (|x| + r) -> the new x), so the root is the same number -- as long as no step
+// leaves the bracket (the loop would bisect) and an exit is reached within RL_K steps.  A lane for which that does not
+// hold takes the loop itself, from the start.  The wave leaves as soon as every lane has its root.
+#define RL_K 8
+__device__ __forceinline__ bool quartic_root_0r_lockstep(double a, double b, double c, double d, double e, double r, double guess, double &root) {
+	const double f0 = e;
+	const double fr = (((a*r + b)*r + c)*r + d)*r + e;
+	if (!(r > 0.0) || !(f0 > 0.0) || !(fr < 0.0)) return quartic_root_0r(a, b, c, d, e, r, guess, root);   // (the degenerate entries: as written)
+	double lo = 0.0, hi = r, x = guess, res = 0.0;
+	if (!(x > lo && x < hi)) x = 0.5*(lo + hi);
+	const double a4 = 4.0*a, b3 = 3.0*b, c2 = 2.0*c;
+	bool done = false, bad = false;
+#pragma unroll 1
+	for (int it = 0; it < RL_K; ++it) {
+		const double f = (((a*x + b)*x + c)*x + d)*x + e;
+		const bool live = !done && !bad;
+		if (live && f == 0.0) { done = true; res = x; }
+		const bool act = live && !(f == 0.0);
+		lo = (act && f > 0.0) ? x : lo;
+		hi = (act && !(f > 0.0)) ? x : hi;
+		const double df = ((a4*x + b3)*x + c2)*x + d;
+		const double xn = x - f/df;
+		const bool inb = xn >= lo && xn <= hi;
+		bad = bad || (act && !inb);                              // the loop would bisect here: not this routine's case
+		const double dx = fabs(xn - x);
+		if (act && inb) {
+			x = xn;
+			if (dx <= 1e-15*(fabs(x) + r)) { done = true; res = x; }
+		}
+#ifdef SRH_EXPERIMENT
+		if (live) atomicAdd(&g_exp_rl[1], 1ull);
+#endif
+		if (__all(done || bad)) break;
+	}
+#ifdef SRH_EXPERIMENT
+	atomicAdd(&g_exp_rl[0], 1ull);
+	if (!done) atomicAdd(&g_exp_rl[2], 1ull);
+#endif
+	if (!done) return quartic_root_0r(a, b, c, d, e, r, guess, root);
+	root = res;
+	return true;
+}
+
+__device__ __forceinline__ bool project_refraction_sd(Vec3 &p, Vec3 pn, double pdist, double n, const Vec3 &bn) {
+	const Vec3 proj = dot(bn, p)*bn;
+	Vec3 dir = p - proj;
+	const double y = dir.y;
+	const double z = norm(proj);
+	const double r = norm(dir);
+	const double d = pdist;
+	const double rr = r*r, nn = n*n, dd = d*d;
+	{ const SharedDivisor rs = shared_divisor(r); dir = v3(div_by(dir.x, rs), div_by(dir.y, rs), div_by(dir.z, rs)); }   // normalized(dir)
+	if (isnan_d(dir.x) || isnan_d(dir.y) || isnan_d(dir.z)) return false;
+	const double qa = nn - 1;
+	const double qb = -2*r*(nn - 1);
+	const double qc = rr*(nn - 1) + dd*nn - (z - d)*(z - d);
+	const double qd = -2*dd*nn*r;
+	const double qe = dd*nn*rr;
+	double root;
+#ifdef SRH_EXPERIMENT
+	if (g_exp_rows_mode == 2) root = r*d/z; else
+#endif
+	if (!quartic_root_0r_lockstep(qa, qb, qc, qd, qe, r, r*d/z, root)) return false;
+	const Vec3 pp = root*dir;
+	const double py = pp.y;
+	bool ok = false;
+	if (py > -1e-3 && y > -1e-3) { if (py < y + 1e-3) ok = true; }
+	else if (py < 1e-3 && y < 1e-3) { if (y < py + 1e-3) ok = true; }
+	if (!ok) return false;
+	p = pp + pdist*pn;
+	return true;
+}
+
+template <class Visitor>
+__device__ __forceinline__ void walk_curve_rows(const Ray &ray, const srh_camera &refcam, const ViewDev &oth,
+                                                const srh_params &P, Visitor &vis, const double *__restrict__ tdist)
+{
+	const int OW = oth.w, OH = oth.h;
+	const bool refr = oth.cam.is_refractive != 0, distorted = oth.cam.is_distorted != 0;
+	double x1 = __builtin_nan(""), y1 = __builtin_nan("");
+	int jx1 = 0, jy1 = 0;
+	const Vec3 pn = normalized(load3(refcam.pdir));
+	const double nd = dot(pn, ray.dir);
+	if (fabs(nd) < 1e-10) return;                               // intersect() fails for every label
+	const Vec3 oth_pn = load3(oth.cam.plane_normal);
+	const Vec3 oth_bn = normalized(oth_pn);
+	const double cx = oth.cam.K[2], cy = oth.cam.K[5], fx = oth.cam.K[0], fy = oth.cam.K[4];
+	for (int d = 0; d < P.num_depth_levels; ++d) {
+		// intersect_plane(ray, pn, tdist[d], point) with n . dir taken out of the loop (walk_curve)
+		const Vec3 x0 = tdist[d]*pn;
+		const double t = dot(pn, x0 - ray.src) / nd;
+		if (t < 1e-10) continue;
+		const Vec3 point = ray.src + t*ray.dir;
+		// cam_project (camera.cpp:380-419)
+		Vec3 pl = matvec(oth.cam.R, point) + load3(oth.cam.t);
+#ifdef SRH_EXPERIMENT
+		if (g_exp_rows_mode != 3)
+#endif
+		if (refr && !project_refraction_sd(pl, oth_pn, oth.cam.plane_dist, oth.cam.refr_index, oth_bn)) continue;
+		const Vec3 pk = matvec(oth.cam.K, pl);
+		const SharedDivisor zd = shared_divisor(pk.z);
+		double px = div_by(pk.x, zd), py = div_by(pk.y, zd);
+		if (distorted) {
+			const double *k = oth.cam.dist;
+			double x = (px - cx) / fx, y = (py - cy) / fy;
+			const double r2 = x*x + y*y;
+			const double cdist = 1 + ((k[4]*r2 + k[1])*r2 + k[0])*r2;
+			x = x*cdist + 2*k[2]*x*y + k[3]*(r2 + 2*x*x);
+			y = y*cdist + k[2]*(r2 + 2*y*y) + 2*k[3]*x*y;       // updated x, as the reference
+			px = fx*x + cx;
+			py = fy*y + cy;
+		}
+		const double x2 = px*P.image_scale;
+		const double y2 = py*P.image_scale;
+		if (isnan_d(x1)) { x1 = x2; y1 = y2; jx1 = trunc_sat(x2); jy1 = trunc_sat(y2); continue; }
+		const double dx = x2 - x1, dy = y2 - y1;
+		if (!(dx*dx + dy*dy >= 1)) continue;
+		const int ix0 = jx1, iy0 = jy1, ix1 = trunc_sat(x2), iy1 = trunc_sat(y2);   // (the kept point's truncations travel with it)
+		jx1 = ix1; jy1 = iy1;
+		const bool inside = (unsigned)ix0 < (unsigned)OW && (unsigned)iy0 < (unsigned)OH && (unsigned)ix1 < (unsigned)OW && (unsigned)iy1 < (unsigned)OH;
+#ifdef SRH_EXPERIMENT
+		if (g_exp_rows_mode == 1) { vis.visited += (unsigned)(ix0 + iy1); x1 = x2; y1 = y2; continue; }
+#endif
+		LineWalk lw;
+		if (inside) lw.begin(ix0, iy0, ix1, iy1, 0, 0);          // every point of the segment is in the image
+		else lw.begin(ix0, iy0, ix1, iy1, OW, OH);               // 4-arg LineIterator, twoviewstereo.cpp:1028 (off-image points are dropped below)
+		while (lw.has_next()) {
+			int tx, ty;
+			lw.current(tx, ty);
+			if ((inside || ((unsigned)tx < (unsigned)OW && (unsigned)ty < (unsigned)OH)) && oth.mask[(size_t)ty*OW + tx] == 1) vis(tx, ty);
+			lw.next();
+		}
+		x1 = x2; y1 = y2;
+	}
+}
 
 // rowinfo(q, r) = xlo | width<<16 of image row ymin+r;  meta[q] = ymin | nrows<<16 (nrows 0: no candidates).
 // Per-pixel arrays are wave-tiled so that the 64 pixels of a wave read and write them coalesced:
@@ -74,7 +241,7 @@ void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			uint32_t *mine = cand + (q >> 6)*(size_t)cmax*64 + (q & 63);
 			for (int r = 0; r < RW_NR; ++r) { s_lo[r][threadIdx.x] = 32767; s_hi[r][threadIdx.x] = -1; }
 			RowsListVisitor vis = { mine, cmax, 0, 0, 0xffffffffu, 2147483647, -1, &s_lo[0][threadIdx.x], &s_hi[0][threadIdx.x] };
-			walk_curve<false>(ray, L.cam, views[oth], P, vis, tdist);
+			walk_curve_rows(ray, L.cam, views[oth], P, vis, tdist);
 			n_eval = vis.visited;
 			n_kept = vis.n;
 			const int nr = vis.n > 0 ? vis.ymax - vis.ymin + 1 : 0;
