@@ -146,7 +146,8 @@ SRH_HD bool project_refraction(Vec3 &p, Vec3 pn, double pdist, double n, const V
 	const double qd = -2*dd*nn*r;
 	const double qe = dd*nn*rr;
 	double root;
-	if (!quartic_root_0r(qa, qb, qc, qd, qe, r, r*d/z, root)) return false;
+	// (Newton's start: the paraxial Snell point, see the oracle's project_refraction)
+	if (!quartic_root_0r(qa, qb, qc, qd, qe, r, r*d/(d + (z - d)/n), root)) return false;
 
 	const Vec3 pp = root*dir;
 	const double py = pp.y;

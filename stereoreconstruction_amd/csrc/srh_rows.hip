@@ -80,7 +80,7 @@ struct RowsListVisitor {
 // (f == 0 -> that x; a step of at most 1e-15 (|x| + r) -> the new x), so the root is the same number -- as long as no step
 // leaves the bracket (the loop would bisect) and an exit is reached within RL_K steps.  A lane for which that does not
 // hold takes the loop itself, from the start.  The wave leaves as soon as every lane has its root.
-#define RL_K 8
+#define RL_K 7
 __device__ __forceinline__ bool quartic_root_0r_lockstep(double a, double b, double c, double d, double e, double r, double guess, double &root) {
 	const double f0 = e;
 	const double fr = (((a*r + b)*r + c)*r + d)*r + e;
@@ -137,9 +137,9 @@ __device__ __forceinline__ bool project_refraction_sd(Vec3 &p, Vec3 pn, double p
 	const double qe = dd*nn*rr;
 	double root;
 #ifdef SRH_EXPERIMENT
-	if (g_exp_rows_mode == 2) root = r*d/z; else
+	if (g_exp_rows_mode == 2) root = r*d/(d + (z - d)/n); else
 #endif
-	if (!quartic_root_0r_lockstep(qa, qb, qc, qd, qe, r, r*d/z, root)) return false;
+	if (!quartic_root_0r_lockstep(qa, qb, qc, qd, qe, r, r*d/(d + (z - d)/n), root)) return false;   // (the paraxial Snell point: srh_geom.hpp)
 	const Vec3 pp = root*dir;
 	const double py = pp.y;
 	bool ok = false;
