@@ -431,6 +431,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
     if TV_OVERLAP and not rows_shard:
         psteps = min(args.steps, 2)
         ctx.set_option("tv_overlap", 0)
+        ctx.set_option("side_weights", 0)                         # (row-run path: the windows kernel behind the list kernel, not beside it)
         ctx.profile_reset()
         ctx.profile_enable(True)
         for _ in range(psteps):
@@ -438,6 +439,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         fence()
         ctx.profile_enable(False)
         ctx.set_option("tv_overlap", 1)
+        ctx.set_option("side_weights", 1)
     prof = ctx.profile()
     certified = None
     if stats["n_certified"]:

@@ -195,13 +195,21 @@ int  srh_synchronize(srh_context *ctx);
  *   "tv_overlap"      1 (default): srh_twoview_compute queues its second pass on a stream and band buffers of its own beside
  *                     the first (the passes share only the views; the cross-check waits for both); 0: one after the other
  *                     on the context's stream.  Identical bits; the second set of band buffers counts against the budget.
+ *   "tscan"           1 (default): on the dense path the scan makes the candidate sequence once per pass and every pixel verifies
+ *                     its own curve against it (template scan; a tile with a pixel that does not verify is walked per pixel);
+ *                     0: every tile by the per-pixel curve walk.  Identical bits (srh_stats.scan_tiles_template / _walked).
+ *   "side_weights"    1 (default): the row-run path computes a band's support windows on a side stream beside its list kernel;
+ *                     0: behind it on the pass's own stream (profiling: every kernel's own duration).  Identical bits.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order
  *   "band_budget_mb"  device scratch per row band the caller asks for (default 32768: a 1920x1080x256 refractive pair
  *                     in one band).  A run never plans with more than a quarter of the device memory that is free at
  *                     that moment (hipMemGetInfo), and a run whose band buffers still do not fit is repeated with the
  *                     budget halved (srh_stats.band_retries) instead of failing: results do not depend on the split.
  *   "mem_limit_mb"    pretend the device has at most this much memory to give (0 = off; tests of the above)
- *   "debug_alloc_limit_mb"  refuse band buffers above this size as if the device were out of memory (0 = off; tests) */
+ *   "debug_alloc_limit_mb"  refuse band buffers above this size as if the device were out of memory (0 = off; tests)
+ *   "debug_mvs_cmax_hint"   the list capacity the next MultiViewStereo estimate is queued with (0 = forget; test of the redo of a
+ *                     view whose lists were cut)
+ * The library reads no environment variable: what a host runs is what it set here. */
 int  srh_set_option(srh_context *ctx, const char *name, long value);
 
 /* ---- views: what VectorImage::fromQImage + the mask test hold (util/vectorimage.cpp:48-64) ----

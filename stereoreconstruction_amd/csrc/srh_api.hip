@@ -174,6 +174,7 @@ struct srh_context {
 		       lcount_cap = 0, lmeta_cap = 0, stpl_cap = 0, tileflag_cap = 0;
 	} tv_slot;
 	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
+	int side_weights = 1;                               // option "side_weights": 0 = the row-run path computes its support windows on the pass's own stream, behind the list kernel (profiling: every kernel's own duration)
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
 	// srh_twoview_cost_rows (diagnostic): the dense plan stops after the cost kernel of its one band and hands the rows out
@@ -681,6 +682,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	}
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
 	if (!strcmp(name, "tscan")) { c->tscan = value != 0; return SRH_OK; }
+	if (!strcmp(name, "side_weights")) { c->side_weights = value != 0; return SRH_OK; }
 	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
 	if (!strcmp(name, "debug_mvs_cmax_hint")) { c->mvs_cmax_hint = value > 0 ? (int)((value + 7) & ~7L) : 0; return SRH_OK; }
 #ifdef SRH_EXPERIMENT
@@ -1148,12 +1150,14 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						{ Scope s(c, "twoview_rows_list_kernel");
 						  launch_twoview_rows_list(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->lcand, cmax,
 						                           cnt_band, c->lrowinfo, c->lmeta, smax, c->d_cnt, c->d_span, c->tnum); }
-						HIP_TRY(hipStreamWaitEvent(c->side_stream, c->side_go, 0));
-						std::swap(c->stream, c->side_stream);
-						run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
-						std::swap(c->stream, c->side_stream);
-						HIP_TRY(hipEventRecord(c->side_done, c->side_stream));
-						HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
+						if (c->side_weights) {
+							HIP_TRY(hipStreamWaitEvent(c->side_stream, c->side_go, 0));
+							std::swap(c->stream, c->side_stream);
+							run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+							std::swap(c->stream, c->side_stream);
+							HIP_TRY(hipEventRecord(c->side_done, c->side_stream));
+							HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
+						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
 						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
