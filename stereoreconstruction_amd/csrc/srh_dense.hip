@@ -1465,13 +1465,18 @@ void twoview_scan_kernel(const ViewDev *__restrict__ views, int ref, int oth, sr
 #define TS_MAXS 6144                   // candidate entries
 #define TS_MAXSPAN 1024                // smax - smin + 1
 struct ScanTemplate {
-	int32_t ok, nS, smin, smax, x0, y0;
+	int32_t ok, nS, smin, smax, x0, y0, nF, pad_;
 	double tabs, tmin, tmax;            // max |tnum[d]| (bound of |t| for fast_proj_setup), smallest and largest tnum[d]
 	// (32-bit entries: a wave reads them with SCALAR loads -- the index is uniform -- eight at a time; bytes and shorts
 	// would come through the vector memory path, a dependent round trip per label)
 	alignas(32) int32_t lab[TS_MAXD + 8];   // per label: state | offset << 8; state 0 not projectable, 1 first point, 2 dropped
 	                                    // (step < 1 pixel), 3 kept, 4 padding behind the last label; offset (first / kept): trunc(x2) - x
 	alignas(32) int32_t S[TS_MAXS + 8]; // candidate columns in visiting order, relative to x
+	// the FIRST visits only, in visiting order: column offset (24 bits) | how often the sequence visits the column << 24.
+	// A column seen earlier in the sequence can never change the running minimum again -- its cost was not below
+	// minCost - margin then, and minCost only falls (with the certified scan: the reference makes that comparison on its own
+	// exact numbers, for which the argument holds, so it need not be replayed) -- its later visits only count as evaluations.
+	alignas(32) int32_t F[TS_MAXSPAN + 8];
 };
 size_t scan_template_bytes() { return sizeof(ScanTemplate); }
 
@@ -1553,8 +1558,7 @@ void twoview_template_kernel(const ViewDev *__restrict__ views, int ref, int oth
 	__syncthreads();
 	// ---- everything else by all lanes: the label words, the candidate entries segment by segment.
 	// Entry = column offset (29 bits) | bit 30: high end of its segment | bit 29: a revisit (a column seen earlier in the
-	// sequence: it can never change the running minimum again; recorded, not used by the scan -- skipping the look-up of
-	// a third of the entries was measured and bought nothing, the flag being uniform but the lanes' work selects).
+	// sequence; the first visits alone are listed in F below).
 	// (Bit 30: the template's columns are FLOOR offsets; the reference truncates towards zero, which moves a negative end
 	// point one column to the right: the in-image part of a segment changes only when its high end is column -1 -- the
 	// reference's segment then ends ON column 0.)
@@ -1568,6 +1572,44 @@ void twoview_template_kernel(const ViewDev *__restrict__ views, int ref, int oth
 			tpl->S[at + (c - sa)] = (c & 0x1fffffff) | (c == sb ? 0x40000000 : 0) | ((c >= clo && c <= chi) ? 0x20000000 : 0);
 	}
 	for (int j = nS + tid; j < ((nS + 7) & ~7); j += 256) tpl->S[j] = (smin & 0x1fffffff) | 0x20000000;   // (padding: a column whose mask byte exists; never counted)
+	// first visits: of segment k the columns outside what the earlier segments cover -- at most two runs, [sa, clo) and
+	// (chi, sb] -- ; their places by a running count over the segments (one lane), the columns' multiplicities by counting
+	// the segments that contain them
+	__shared__ int s_fat[TS_MAXD];
+	__shared__ int s_cnt[TS_MAXSPAN + 8];                             // per column of the span: how many segments contain it
+	for (int k = tid; k < TS_MAXSPAN + 8; k += 256) s_cnt[k] = 0;
+	__syncthreads();
+	for (int k = tid; k < nseg; k += 256) { atomicAdd(&s_cnt[s_seg[k][0] - smin], 1); atomicAdd(&s_cnt[s_seg[k][1] + 1 - smin], -1); }
+	__syncthreads();
+	if (tid == 0) {
+		int nF = 0;
+		for (int k = 0; k < nseg; ++k) {
+			const int sa = s_seg[k][0], sb = s_seg[k][1], cov = s_seg[k][3];
+			const int clo = cov == -1 ? 1 << 20 : (cov & 0xffff) - 32768, chi = cov == -1 ? -(1 << 20) : ((cov >> 16) & 0xffff) - 32768;
+			s_fat[k] = nF;
+			const int l1 = clo - 1 < sb ? clo - 1 : sb, h2 = chi + 1 > sa ? chi + 1 : sa;
+			nF += (l1 >= sa ? l1 - sa + 1 : 0) + (sb >= h2 && cov != -1 ? sb - h2 + 1 : 0);
+		}
+		s_hdr[5] = nF;
+		tpl->nF = nF;
+	} else if (tid == 64) {
+		int run = 0;                                                   // (another wave: the running sum of the difference array)
+		const int span = s_hdr[4] - smin + 1;
+		for (int k = 0; k < span; ++k) { run += s_cnt[k]; s_cnt[k] = run; }
+	}
+	__syncthreads();
+	const int nF = s_hdr[5];
+	for (int k = tid; k < nseg; k += 256) {
+		const int sa = s_seg[k][0], sb = s_seg[k][1], cov = s_seg[k][3];
+		const int clo = cov == -1 ? 1 << 20 : (cov & 0xffff) - 32768, chi = cov == -1 ? -(1 << 20) : ((cov >> 16) & 0xffff) - 32768;
+		int at = s_fat[k];
+		for (int c = sa; c <= sb; ++c) {
+			if (c >= clo && c <= chi) continue;                        // a revisit
+			const int mult = s_cnt[c - smin];
+			tpl->F[at++] = (c & 0xffffff) | ((mult < 127 ? mult : 127) << 24);
+		}
+	}
+	for (int j = nF + tid; j < ((nF + 7) & ~7); j += 256) tpl->F[j] = smin & 0xffffff;   // (padding: multiplicity 0)
 }
 
 #define TS_U 8                         // look-ups in flight per lane
@@ -1708,27 +1750,38 @@ bool twoview_tscan_tile(const int bid, const ViewDev *__restrict__ views, int re
 		// together, the eight costs by loads in flight together, then the reference's running-min rule entry by entry.
 		// LEFT (tile-uniform): a column of the tile may be -1 -- see the template: a segment whose high end is column -1
 		// ends on column 0 in the reference (truncation towards zero)
+		// LEFT tiles walk the whole sequence S (every visit evaluated: the shifted entry may be a column's first visit);
+		// every other tile the first visits F, a later visit of a column counted with its first
 		auto lookups = [&](auto left_c) {
 			constexpr bool LEFT = decltype(left_c)::value;
-			for (int j0 = 0; j0 < nSe; j0 += TS_U) {
-				int sv[TS_U], kk[TS_U];
+			const int32_t *seq = LEFT ? tpl->S : tpl->F;
+			const int nE = nSe == 0 ? 0 : (LEFT ? nS : tpl->nF);
+			for (int j0 = 0; j0 < nE; j0 += TS_U) {
+				int sv[TS_U], kk[TS_U], mu[TS_U];
 				unsigned char mb[TS_U];
 				double c[TS_U];
 				{
-					const int4 sa = reinterpret_cast<const int4 *>(&tpl->S[j0])[0], sb = reinterpret_cast<const int4 *>(&tpl->S[j0])[1];
+					const int4 sa = reinterpret_cast<const int4 *>(&seq[j0])[0], sb = reinterpret_cast<const int4 *>(&seq[j0])[1];
 					sv[0] = sa.x; sv[1] = sa.y; sv[2] = sa.z; sv[3] = sa.w; sv[4] = sb.x; sv[5] = sb.y; sv[6] = sb.z; sv[7] = sb.w;
 				}
 #pragma unroll
 				for (int u = 0; u < TS_U; ++u) {
-					int s = (sv[u] << 3) >> 3;                                 // (sign-extended 29-bit offset; the padding behind the last entry is smin)
-					if (LEFT) s += ((sv[u] & 0x40000000) && x + s == -1) ? 1 : 0;
+					int s;
+					if (LEFT) {
+						s = (sv[u] << 3) >> 3;                                 // (sign-extended 29-bit offset; the padding behind the last entry is smin)
+						s += ((sv[u] & 0x40000000) && x + s == -1) ? 1 : 0;
+						mu[u] = 1;
+					} else {
+						s = (sv[u] << 8) >> 8;                                 // (24-bit offset)
+						mu[u] = sv[u] >> 24;                                   // (uniform: how often the reference evaluates this column)
+					}
 					sv[u] = s;
 					mb[u] = smask[xm + s];
 				}
 #pragma unroll
 				for (int u = 0; u < TS_U; ++u) {
-					const bool white = j0 + u < nSe && mb[u] == 1;             // (off-image columns hold 0)
-					n_eval += white ? 1u : 0u;
+					const bool white = j0 + u < nE && mb[u] == 1;              // (off-image columns hold 0)
+					n_eval += white ? (unsigned)mu[u] : 0u;
 					kk[u] = white ? xlo + sv[u] : -1;
 					c[u] = crow[(unsigned)(white ? kk[u] : 0)*(unsigned)DC_TP];   // (unconditional: no branch around a load; entry 0 exists)
 				}
