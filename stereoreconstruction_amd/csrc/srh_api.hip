@@ -157,7 +157,9 @@ struct srh_context {
 	int arith = 3;
 	// srh_twoview_compute queues both passes and the cross-check and verifies the passes' counters with ONE wait at the end
 	// (the plans are refuted once in a blue moon; a wait per pass leaves the GPU idle while the host launches the next one)
-	struct TvDefer { Counters *host = nullptr; bool queued = false, strip = false, cert = false; };
+	// (lists: the pass took the row-run candidate lists with the capacities learnt from earlier runs -- span = the kernels'
+	// maxima: longest list, most cost slots, a curve over too many rows -- to be compared with cmax / smax)
+	struct TvDefer { Counters *host = nullptr; int *span = nullptr; bool queued = false, strip = false, cert = false, lists = false; int cmax = 0, smax = 0; };
 	TvDefer tv_defer[2];
 	TvDefer *defer = nullptr;
 	// ... and runs the second pass on a stream of its own with its own band buffers (swapped into the context for its
@@ -591,7 +593,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->cflag) hipFree(c->cflag);
 	if (c->stpl) hipFree(c->stpl);
 	if (c->tileflag) hipFree(c->tileflag);
-	for (auto &d : c->tv_defer) if (d.host) hipHostFree(d.host);
+	for (auto &d : c->tv_defer) { if (d.host) hipHostFree(d.host); if (d.span) hipHostFree(d.span); }
 	{
 		srh_context::TvSlot &T = c->tv_slot;
 		if (T.stream) { hipStreamSynchronize(T.stream); hipStreamDestroy(T.stream); }
@@ -1188,6 +1190,20 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					{ Scope s(c, "twoview_list_scan_kernel");
 					  launch_twoview_list_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, c->cost, cmax); }
 				}
+				if (c->defer && attempt == 0 && pass == 0 && rows_mode && c->list_cmax_hint > 0 && c->list_smax_hint > 0 &&
+				    c->views[ref].list_mode[oth] == 1) {
+					// optimistic (srh_twoview_compute): capacities and path are those earlier runs of this pair learnt; the maxima
+					// and counters travel to pinned memory behind the kernels, the caller verifies both passes with one wait (a
+					// pass that does not stand -- a longer list after a re-upload, say -- is redone with the wait per pass)
+					HIP_TRY(hipMemcpyAsync(c->defer->host, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+					HIP_TRY(hipMemcpyAsync(c->defer->span, c->d_span, 4*sizeof(int), hipMemcpyDeviceToHost, c->stream));
+					c->defer->queued = true; c->defer->lists = true; c->defer->strip = false; c->defer->cert = rows_cert;
+					c->defer->cmax = cmax; c->defer->smax = smax;
+					c->stats.used_strip_kernel = 0;
+					c->stats.used_dense_path = 0;
+					HIP_TRY(hipGetLastError());
+					return SRH_OK;
+				}
 				int mx[4] = { 0, 0, 0, 0 };
 				HIP_TRY(hipMemcpyAsync(mx, c->d_span, 4*sizeof(int), hipMemcpyDeviceToHost, c->stream));
 				HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1444,6 +1460,8 @@ static void tv_slot_swap(srh_context *c) {
 
 static bool tv_pass_stands(const srh_context::TvDefer &d) {
 	const Counters &h = *d.host;
+	if (d.lists)                                                   // every list and every pixel's cost slots fitted, no curve over too many rows
+		return d.span[0] <= d.cmax && ((d.span[1] + 7) & ~7) <= d.smax && d.span[2] == 0 && h.cert_overflow == 0;
 	return !(d.strip && h.strip_overflow != 0) && h.cert_overflow == 0 && h.not_row_aligned == 0;
 }
 
@@ -1455,7 +1473,8 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 	HIP_TRY(hipSetDevice(c->device));
 	for (auto &d : c->tv_defer) {
 		if (!d.host) HIP_TRY(hipHostMalloc((void **)&d.host, sizeof(Counters)));
-		d.queued = false;
+		if (!d.span) HIP_TRY(hipHostMalloc((void **)&d.span, 4*sizeof(int)));
+		d.queued = false; d.lists = false;
 	}
 	if (c->tv_overlap) {
 		srh_context::TvSlot &T = c->tv_slot;
@@ -1527,7 +1546,7 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 			c->stats.n_eval_device = (int64_t)d1.host->n_eval_device;
 			c->stats.n_certified = (int64_t)d1.host->n_certified;
 			c->stats.n_flagged = (int64_t)d1.host->n_flagged;
-			c->stats.used_dense_path = 1;
+			c->stats.used_dense_path = d1.lists ? 0 : 1;
 			c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 			progress(c, 8, "Finished!");
 			return SRH_OK;
