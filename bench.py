@@ -563,14 +563,16 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
 
 
 def other_configs(args, rank, world, dev, dev_index, backend):
-    """Short legs (3 timed steps after 1 warm-up) of the other BASELINE configurations, run after the headline so that
+    """Short legs (3 timed steps after 2 warm-ups) of the other BASELINE configurations, run after the headline so that
     every config's number is timed by the same driver run: C5 (refractive pair), C4 (8-view MultiViewStereo), C2, C1.
     Each leg carries its own CPU-oracle band (parity spot check at full size + baseline rate)."""
     import copy
     out = {}
     for w, rows in (("c5", 2), ("c4", 8), ("c2", 4), ("c1", 24), ("c1m", 16)):
         a = copy.copy(args)
-        a.steps, a.warmup, a.cpu_rows, a.workload, a.cpu_all_cores = 3, 1, rows, w, False
+        # (two warm-up steps: the first learns the candidate-list capacities of a pair, the second is the first to queue both
+        # passes side by side and allocates the second pass's band buffers)
+        a.steps, a.warmup, a.cpu_rows, a.workload, a.cpu_all_cores = 3, 2, rows, w, False
         t0 = time.perf_counter()
         try:
             r = run_c4(a, rank, world, dev, dev_index, backend) if w in ("c4", "c1m") else run_twoview(a, w, rank, world, dev, dev_index, backend)
