@@ -1,0 +1,63 @@
+#!/bin/bash
+# profiles/collect_r05.sh -- everything profiles/ holds for round 5, in one go on the GPU box:
+#   the default bench line (C3 headline + driver-style legs of C5, C4, C2, C1), per-workload bench lines with their CPU
+#   baselines (default = certified arithmetic) and the same in the reference's arithmetic (--arith exact), rocprofv3 kernel
+#   stats, PMC traffic and instruction mix of one step of C3 / C4 / C5, phase stamps and the loop-repeat experiment of the
+#   fused strip kernel.
+# usage (from the repo root on the GPU box):  bash profiles/collect_r05.sh gpurun_out/r05
+# PMC passes run on their own (never with --kernel-trace --stats in one rocprofv3 command), one counter set per pass.
+set -u
+OUT=${1:-gpurun_out/r05}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+B="python3 bench.py"
+timeout -k 10 400 $B --steps 20 --warmup 3 > "$OUT/default_bench.json" 2> "$OUT/default_bench.err"
+for w in c1 c2 c3 c4 c5 c1m; do
+	timeout -k 10 300 $B --workload $w --steps 5 --warmup 2 --no-configs > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"
+	timeout -k 10 300 $B --workload $w --steps 5 --warmup 2 --no-configs --arith exact --cpu-rows 0 > "$OUT/${w}_exact_bench.json" 2>/dev/null
+done
+timeout -k 10 300 $B --workload c3 --arith fma --steps 5 --warmup 2 --cpu-rows 0 --no-configs > "$OUT/c3_fma_bench.json" 2>/dev/null
+echo "bench lines done"
+# per-kernel time (C4: one view in flight, SRH_MVS_ASYNC=0: bench.py takes its kernels_ms from such a pass as well)
+export SRH_MVS_ASYNC=0
+# (and the two TwoView passes one after the other: side by side, a kernel's duration includes the other pass's share of the GPU)
+export SRH_BENCH_TV_OVERLAP=0
+for w in c3 c4 c5 c2 c1; do
+	rocprofv3 --kernel-trace --stats -d "$OUT/stats_$w" --output-format csv -- $B --workload $w --steps 3 --warmup 1 --cpu-rows 0 --no-configs --no-exact-check > "$OUT/stats_$w.log" 2>&1
+	cp "$(find "$OUT/stats_$w" -name '*kernel_stats.csv' | head -1)" "$OUT/${w}_kernel_stats.csv" 2>/dev/null
+	rm -rf "$OUT/stats_$w"
+done
+echo "kernel stats done"
+pmc() { # tag workload counters...
+	local tag=$1 w=$2; shift 2
+	rocprofv3 --pmc "$@" -d "$OUT/pmc_$tag" --output-format csv -- $B --workload $w --steps 1 --warmup 0 --cpu-rows 0 --no-configs --no-exact-check > "$OUT/pmc_$tag.log" 2>&1
+	cp "$(find "$OUT/pmc_$tag" -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$tag.csv" 2>/dev/null
+	grep -o '"build_id": "[0-9a-f]*"' "$OUT/pmc_$tag.log" | head -1 > "$OUT/pmc_$tag.build"
+	rm -rf "$OUT/pmc_$tag"
+	echo "pass $tag done"
+}
+for w in c3 c4 c5 c2 c1; do
+	pmc ${w}_fetch $w FETCH_SIZE
+	pmc ${w}_write $w WRITE_SIZE
+	pmc ${w}_mix1 $w SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_MFMA
+	pmc ${w}_mix2 $w SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS
+done
+unset SRH_MVS_ASYNC SRH_BENCH_TV_OVERLAP
+for w in c3 c4 c5 c2 c1; do python3 profiles/pmc_table.py $(ls "$OUT"/pmc_${w}_mix*.csv 2>/dev/null) > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
+# this round's experiments: the certified arithmetic on flat / saturated areas, the template scan against the curve walk and its
+# parts, the C5 list kernel's parts, the bunny views through MultiViewStereo (experiment build where the script says so)
+timeout -k 10 300 python3 profiles/cert_flat_sweep.py > "$OUT/cert_flat_sweep.json" 2>/dev/null
+timeout -k 10 300 python3 profiles/exp_r05_tscan.py 2>&1 | grep -v amdgpu.ids > "$OUT/c3_tscan.txt"
+timeout -k 10 300 python3 profiles/exp_r05_bunny_mvs.py 2>&1 | grep -v amdgpu.ids > "$OUT/c1m_modes.txt"
+if [ -f profiles/lib/libstereo_recon_hip_exp.so ]; then
+	timeout -k 10 300 python3 profiles/exp_r05_tscan_parts.py 2>&1 | grep -v amdgpu.ids > "$OUT/c3_tscan_parts.txt"
+	timeout -k 10 300 python3 profiles/exp_r05_rows_list.py 2>&1 | grep -v amdgpu.ids > "$OUT/c5_list_parts.txt"
+fi
+# phase stamps of the strip kernel, the staged cost kernel and the geodesic kernel (diagnostic build), device busy time
+if [ -f profiles/lib/libstereo_recon_hip_prof.so ]; then
+	bash profiles/exp_r04_phases_busy.sh "$OUT" > /dev/null 2>&1
+	SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_prof.so timeout -k 10 200 $B --workload c3 --steps 2 --warmup 1 --cpu-rows 0 --no-configs > /dev/null 2> "$OUT/phases_c3.err"
+	grep "srh dbg" "$OUT/phases_c3.err" | grep -v rows | tail -9 > "$OUT/c3_strip8_phases_certified.txt"
+fi
+rm -f "$OUT"/pmc_*.log "$OUT"/stats_*.log "$OUT"/phases_*.json "$OUT"/phases_*.err
+ls "$OUT"

@@ -14,10 +14,10 @@ with capi.Context(0) as ctx:
     ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl, None, *plane))
     ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr, None, *plane))
     ctx.twoview_wta(0, 1, p); ctx.synchronize()
-    ctx.set_option("exp_rows_mode", -1)
+    ctx.set_option("exp_rows_mode", 9)                             # Newton statistics of one pass (printed on stderr by mode -1)
     ctx.twoview_wta(0, 1, p); ctx.synchronize()
     ctx.set_option("exp_rows_mode", -1)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         ctx.set_option("exp_rows_mode", mode)
         ctx.profile_reset(); ctx.profile_enable(True)
         try:

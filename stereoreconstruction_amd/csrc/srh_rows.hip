@@ -22,7 +22,7 @@
 namespace srh {
 
 #ifdef SRH_EXPERIMENT
-__device__ int g_exp_rows_mode = 0;   // timing experiments of the list kernel: 1 no raster / visitor, 2 no Newton (root = guess), 3 no refraction
+__device__ int g_exp_rows_mode = 0;   // timing experiments of the list kernel: 1 no raster / visitor, 2 no Newton (root = guess), 3 no refraction; 9: count Newton's steps (slow: atomics), -1 prints the counts
 __device__ unsigned long long g_exp_rl[4];
 void exp_set_rows(int mode) {
 	if (mode == -1) {                                              // print and clear the lockstep statistics
@@ -107,13 +107,12 @@ __device__ __forceinline__ bool quartic_root_0r_lockstep(double a, double b, dou
 			if (dx <= 1e-15*(fabs(x) + r)) { done = true; res = x; }
 		}
 #ifdef SRH_EXPERIMENT
-		if (live) atomicAdd(&g_exp_rl[1], 1ull);
+		if (g_exp_rows_mode == 9 && live) atomicAdd(&g_exp_rl[1], 1ull);
 #endif
 		if (__all(done || bad)) break;
 	}
 #ifdef SRH_EXPERIMENT
-	atomicAdd(&g_exp_rl[0], 1ull);
-	if (!done) atomicAdd(&g_exp_rl[2], 1ull);
+	if (g_exp_rows_mode == 9) { atomicAdd(&g_exp_rl[0], 1ull); if (!done) atomicAdd(&g_exp_rl[2], 1ull); }
 #endif
 	if (!done) return quartic_root_0r(a, b, c, d, e, r, guess, root);
 	root = res;
