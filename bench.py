@@ -360,6 +360,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         mismatch = float((exact_l.view(np.uint64) != ctx.download_depth(0).view(np.uint64)).mean())
     ctx.set_option("arith", arith_code)
     ctx.set_option("tv_overlap", 1 if TV_OVERLAP else 0)
+    ctx.set_option("side_weights", 1 if TV_OVERLAP else 0)        # (SRH_BENCH_TV_OVERLAP=0, the rocprofv3 passes: every kernel by itself)
     # Depth hand-over: both maps are copied device-to-device into a staging tensor; with N > 1 ranks they are
     # gathered on rank 0 (RCCL over xGMI).  The gather of step k runs while step k+1 computes (two staging
     # buffers, async collective); everything is drained inside the timed region by fence().

@@ -8,9 +8,11 @@
 # PMC passes run on their own (never with --kernel-trace --stats in one rocprofv3 command), one counter set per pass.
 set -u
 OUT=${1:-gpurun_out/r05}
+PART=${2:-all}        # all | a (bench lines, kernel stats, experiments, phase stamps) | b (the PMC passes): one gpurun call each
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 B="python3 bench.py"
+if [ "$PART" != b ]; then
 timeout -k 10 400 $B --steps 20 --warmup 3 > "$OUT/default_bench.json" 2> "$OUT/default_bench.err"
 for w in c1 c2 c3 c4 c5 c1m; do
 	timeout -k 10 300 $B --workload $w --steps 5 --warmup 2 --no-configs > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"
@@ -28,6 +30,8 @@ for w in c3 c4 c5 c2 c1; do
 	rm -rf "$OUT/stats_$w"
 done
 echo "kernel stats done"
+unset SRH_MVS_ASYNC SRH_BENCH_TV_OVERLAP
+fi
 pmc() { # tag workload counters...
 	local tag=$1 w=$2; shift 2
 	rocprofv3 --pmc "$@" -d "$OUT/pmc_$tag" --output-format csv -- $B --workload $w --steps 1 --warmup 0 --cpu-rows 0 --no-configs --no-exact-check > "$OUT/pmc_$tag.log" 2>&1
@@ -36,6 +40,9 @@ pmc() { # tag workload counters...
 	rm -rf "$OUT/pmc_$tag"
 	echo "pass $tag done"
 }
+if [ "$PART" != a ]; then
+export SRH_MVS_ASYNC=0
+export SRH_BENCH_TV_OVERLAP=0
 for w in c3 c4 c5 c2 c1; do
 	pmc ${w}_fetch $w FETCH_SIZE
 	pmc ${w}_write $w WRITE_SIZE
@@ -44,6 +51,8 @@ for w in c3 c4 c5 c2 c1; do
 done
 unset SRH_MVS_ASYNC SRH_BENCH_TV_OVERLAP
 for w in c3 c4 c5 c2 c1; do python3 profiles/pmc_table.py $(ls "$OUT"/pmc_${w}_mix*.csv 2>/dev/null) > "$OUT/${w}_instruction_mix.txt" 2>/dev/null; done
+fi
+if [ "$PART" != b ]; then
 # this round's experiments: the certified arithmetic on flat / saturated areas, the template scan against the curve walk and its
 # parts, the C5 list kernel's parts, the bunny views through MultiViewStereo (experiment build where the script says so)
 timeout -k 10 300 python3 profiles/cert_flat_sweep.py > "$OUT/cert_flat_sweep.json" 2>/dev/null
@@ -58,6 +67,7 @@ if [ -f profiles/lib/libstereo_recon_hip_prof.so ]; then
 	bash profiles/exp_r04_phases_busy.sh "$OUT" > /dev/null 2>&1
 	SRH_LIBRARY=$PWD/profiles/lib/libstereo_recon_hip_prof.so timeout -k 10 200 $B --workload c3 --steps 2 --warmup 1 --cpu-rows 0 --no-configs > /dev/null 2> "$OUT/phases_c3.err"
 	grep "srh dbg" "$OUT/phases_c3.err" | grep -v rows | tail -9 > "$OUT/c3_strip8_phases_certified.txt"
+fi
 fi
 rm -f "$OUT"/pmc_*.log "$OUT"/stats_*.log "$OUT"/phases_*.json "$OUT"/phases_*.err
 ls "$OUT"
