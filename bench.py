@@ -150,6 +150,7 @@ def run_c4(args, rank, world, dev, dev_index, backend):
     if args.arith in ("fma", "f32"):
         sys.exit("--arith fma / f32 apply to the dense row-aligned TwoView path (c2, c3, small)")
     ctx.set_option("arith", capi.ARITH_EXACT if args.arith == "exact" else capi.ARITH_CERTIFIED)
+    ctx.set_option("mvs_async", int(os.environ.get("SRH_MVS_ASYNC", "1")))   # (0: the rocprofv3 passes, one view in flight; the library itself reads no environment)
     for v in range(C4_VIEWS):                                  # every rank holds all views (a few MB): any neighbour
         ctx.upload_view(v, rgba[v], masks[v], cams[v])
     eng = HipMultiViewEngine(ctx, list(range(C4_VIEWS)), neigh, p, dev if backend == "nccl" else "cpu")
