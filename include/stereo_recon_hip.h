@@ -74,7 +74,7 @@ typedef struct srh_params {
 	double  bad_ret;              /* 1000 */
 	double  max_color_diff;       /* 120 */
 	double  second_best_factor;   /* 0.95 */
-	double  wta_margin;           /* 1e-10 */
+	double  wta_margin;           /* 1e-10 (the reference's constant; a negative value is honoured by visiting every curve point: slow paths) */
 	double  inconsistency_thresh; /* 1 */
 	double  peak_threshold;       /* 0.95 */
 	double  cross_check_threshold;

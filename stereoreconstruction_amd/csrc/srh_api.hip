@@ -1075,7 +1075,10 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 	for (int attempt = 0; attempt < 4; ++attempt) {
 		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 		// ---- arbitrary geometry: candidate lists (the one-thread-per-pixel walk kernel is the last resort)
-		if (!dense && !c->force_walk && R <= 5 && W < 65536 && H < 65536) {
+		// (a negative wta_margin -- not the reference's: its margin is the constant +1e-10, twoviewstereo.cpp:293 -- makes a
+		// revisited winner beat itself, so the candidate lists' dropped joint duplicates would matter: the walk kernel, which
+		// visits every point, takes such a run)
+		if (!dense && !c->force_walk && R <= 5 && W < 65536 && H < 65536 && p->wta_margin >= 0) {
 			const size_t npix = (size_t)(y1 - y0)*W;
 			if ((rc = ensure(c->lcount, c->lcount_cap, npix))) return rc;
 			ViewHost &O = c->views[oth];

@@ -1804,7 +1804,9 @@ bool twoview_tscan_tile(const int bid, const ViewDev *__restrict__ views, int re
 				}
 			}
 		};
-		if (xt + smin < 0) lookups(std::true_type()); else lookups(std::false_type());
+		// (first visits only: sound while wta_margin >= 0 -- with a negative margin a revisited winner would "beat" itself and
+		// move secondBest -- so a negative margin walks every visit like the left-border tiles)
+		if (xt + smin < 0 || !(P.wta_margin >= 0.0)) lookups(std::true_type()); else lookups(std::false_type());
 		if (wcol >= 0) depth = candidate_depth(L.cam, Rv.cam, P, ray, lo + wcol, y);
 		if (minCost > P.second_best_factor*secondBest) depth = __builtin_inf();
 		if (CERT && wcol >= 0) {

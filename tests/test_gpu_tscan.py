@@ -89,3 +89,43 @@ def test_template_scan_at_c3_size_with_a_narrow_mask(hip_ctx):
         (m1, s1), (m0, s0) = out[1][d], out[0][d]
         assert np.array_equal(m1.view(np.uint64), m0.view(np.uint64)), d
         assert s1["n_eval"] == s0["n_eval"] and s1["scan_tiles_template"] > 0 and s1["scan_tiles_walked"] == 0, (d, s1)
+
+
+def test_negative_margin_walks_every_visit(hip_ctx):
+    """With wta_margin < 0 a revisited winner beats itself (cost + margin < cost) and moves secondBest: the first-visit
+    sequence would be wrong there, so the template scan walks every visit -- against the oracle and the curve walk."""
+    import oracle_ffi as O
+    case = cases.get_twoview("geodesic_rect", w=120, h=40, D=40)
+    case["params"] = dict(case["params"], wta_margin=-0.5)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    assert p.wta_margin == -0.5 and op.wta_margin == -0.5
+    cases.upload_case(hip_ctx, case, cams)
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
+    out = _both(hip_ctx, p, capi.ARITH_CERTIFIED)                 # (a negative margin switches the certified arithmetic off: mode 0)
+    (m1, s1), (m0, s0) = out[1][0], out[0][0]
+    assert s1["scan_tiles_template"] > 0 and s1["n_certified"] == 0
+    assert np.array_equal(m1.view(np.uint64), m0.view(np.uint64)) and s1["n_eval"] == s0["n_eval"]
+    ok, msg, _ = cases.compare_depth(m1, want, 1e-9)
+    assert ok, msg
+    # the margin matters on this input: the same pair with the default margin gives another map
+    case2 = cases.get_twoview("geodesic_rect", w=120, h=40, D=40)
+    cams2, p2 = cases.hip_inputs(case2)
+    hip_ctx.twoview_wta(0, 1, p2)
+    assert not np.array_equal(hip_ctx.download_depth(0).view(np.uint64), m1.view(np.uint64))
+
+
+def test_negative_margin_on_general_geometry_takes_the_walk_kernel(hip_ctx):
+    """The candidate lists drop joint duplicates, which a negative margin would make matter: such a run goes through the
+    one-thread-per-pixel walk kernel -- against the oracle."""
+    import oracle_ffi as O
+    case = cases.get_twoview("adaptive_verged", w=72, h=44, D=20, radius=5)
+    case["params"] = dict(case["params"], wta_margin=-0.25)
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    want = O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op)
+    hip_ctx.twoview_wta(0, 1, p)
+    assert not hip_ctx.stats()["used_dense_path"]
+    ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(0), want, 1e-9)
+    assert ok, msg
