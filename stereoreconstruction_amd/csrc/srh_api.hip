@@ -904,11 +904,11 @@ static int fetch_counters(srh_context *c, int used_dense) {
 	c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
 #ifdef SRH_PROFILE_PHASES
 	{
-		unsigned long long g[5];
+		unsigned long long g[8];
 		geodesic_phases_fetch(g);
-		if (g[4])
-			fprintf(stderr, "[srh prof] geodesic kernel: %llu waves, cycles per wave: staging %.0f  sweeps %.0f  exp + stores %.0f  pconst %.0f\n",
-			        g[4], (double)g[0]/g[4], (double)g[1]/g[4], (double)g[2]/g[4], (double)g[3]/g[4]);
+		if (g[7])
+			fprintf(stderr, "[srh prof] geodesic kernel: %llu waves, cycles per wave: staging %.0f  sweeps %.0f  exp %.0f  rows out %.0f  pconst: first sweep %.0f  second sweep %.0f  rest %.0f\n",
+			        g[7], (double)g[0]/g[7], (double)g[1]/g[7], (double)g[2]/g[7], (double)g[4]/g[7], (double)g[5]/g[7], (double)g[6]/g[7], (double)g[3]/g[7]);
 	}
 	if (h.dbg_waves && h.dbg_blocks && h.dbg_phase[3] && h.strip_ticket) {
 		const double nw = (double)h.dbg_waves, nt = (double)h.dbg_blocks/nw;

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 namespace srh {
 
@@ -57,21 +58,232 @@ void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, doub
 // (2R+1)^2 window lives in registers (fully unrolled sweeps).  Cells outside the
 // image keep geodesic_init because all their edges are +inf.
 #define GW_TW 64
+#ifndef GEO_AHEAD
+#define GEO_AHEAD 8                // cell steps between the request of a cell's edges and their use (geodesic_reg_kernel)
+#endif
+#ifndef GEO_EXPN
+#define GEO_EXPN 6                 // exponentials evaluated side by side (geo_exp_n)
+#endif
 #define GW_ROWS 2                  // image rows per workgroup, one wave each: the waves share the staged tile (2R+GW_ROWS rows
                                    // instead of 2R+1 per wave), which is what lets two waves per SIMD fit the LDS
 
 #ifdef SRH_PROFILE_PHASES
-// diagnostic build: wave clocks of the geodesic kernel's phases (0 staging, 1 sweeps, 2 exp + stores, 3 pconst), [4] = waves
-__device__ unsigned long long g_geo_phase[5];
-void geodesic_phases_fetch(unsigned long long out[5]) {
-	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_geo_phase), sizeof(unsigned long long)*5);
-	unsigned long long z[5] = {0, 0, 0, 0, 0};
+// diagnostic build: wave clocks of the geodesic kernel's phases (0 staging, 1 sweeps, 2 exp, 3 pconst, 4 window rows through
+// the staging row and out), [5] = waves
+__device__ unsigned long long g_geo_phase[8];
+void geodesic_phases_fetch(unsigned long long out[8]) {
+	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_geo_phase), sizeof(unsigned long long)*8);
+	unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_geo_phase), z, sizeof(z));
 }
 #define GEO_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); gph[i] += now_ - gph_t; gph_t = now_; }
 #else
 #define GEO_STAMP(i)
 #endif
+
+// The relaxations of one iteration as ONE sequence of cell steps: forward raster (geodesicweight.cpp:73-97, K1 = (-1,-1)
+// (0,-1) (1,-1) (-1,0)), then backward raster (99-125, K2 = (-1,1) (0,1) (1,1) (1,0)).  std::min(weight, cost + diff): no
+// operand is ever NaN (finite or +inf sums), so v_min_f64 returns exactly what the compare-and-select does.  A cell outside
+// the image is never relaxed because every edge that touches it is +inf.
+// The wave is alone on its SIMD (the window fills the register file): it issues one instruction of ANY kind every 4.5 - 5
+// cycles and nothing hides an LDS round trip but its own arithmetic.  So a cell's four edges are requested GEO_AHEAD cell
+// steps before they are used, into the registers the step just done has freed (a ring of GEO_AHEAD x 4 values instead of a
+// whole window row's 44 at once: a third of the AGPR moves, no address arithmetic -- every read is `lane base + constant`),
+// as single ds_read_b64 (volatile: not merged into ds_read2_b64, which takes four times the LDS-array cycles per byte, not
+// hoisted out of the iteration loop, kept in program order); the scheduling barriers keep them where they are put.
+// (Tried: the three relaxations from the row before done WS - 2 cells ahead of the raster's chain, so that no instruction
+// follows its producer by less than three others -- a dependent FP64 instruction issues 12.6 cycles after its producer on a
+// lone wave, profiles/microbench/fp64_chain_latency -- : 46.7 against 46.2 thousand cycles per wave; the sweeps are bound by
+// the lone wave's issue rate, 13 instructions per cell, not by their chains.)
+// Planes of the tile (PL doubles each, rows of TWD): 0 E, 1 S, 2 SE, 3 SW; `tb` = the lane's cell (window row 0, column 0).
+typedef const volatile __attribute__((address_space(3))) double *GeoLds;    // (an LDS pointer by type: a volatile access through a generic pointer stays a flat load)
+template <int R, int S> struct GeoCell {
+	static constexpr int WS = 2*R + 1;
+	static constexpr bool fwd = S < WS*WS;
+	static constexpr int q = fwd ? S : S - WS*WS;
+	static constexpr int yy = fwd ? q / WS : WS - 1 - q / WS;
+	static constexpr int xx = fwd ? q % WS : WS - 1 - q % WS;
+	// which of the four relaxations exist (an edge over the window's border is no load and no operation)
+	static constexpr bool c0 = fwd ? (yy > 0 && xx > 0)      : (yy < WS - 1 && xx > 0);
+	static constexpr bool c1 = fwd ? (yy > 0)                : (yy < WS - 1);
+	static constexpr bool c2 = fwd ? (yy > 0 && xx < WS - 1) : (yy < WS - 1 && xx < WS - 1);
+	static constexpr bool c3 = fwd ? (xx > 0)                : (xx < WS - 1);
+};
+// min of two doubles that are never NaN: the instruction itself (the builtin first canonicalises an operand the compiler
+// cannot prove quiet -- every tap coming round the iteration loop: one more FP64 instruction per cell)
+__device__ __forceinline__ double geo_min(double a, double b) {
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+// exp of N numbers at once, the device library's own sequence for double (ocml exp: n = rint(x / ln 2), r = x - n ln 2 in
+// two pieces, a degree-11 polynomial by Horner, ldexp, the two range selects) written STEP-MAJOR: every step for all N
+// before the next step for any.  One exp is one chain of 22 dependent instructions; a lone wave issues a dependent FP64
+// instruction 12.6 cycles after its producer (profiles/microbench/fp64_chain_latency) and the compiler, short of registers,
+// emits the 121 exponentials of a window one after the other: 220 cycles each.  Same operations on the same constants:
+// the same bits as exp() of this ROCm (checked on the device against the build before: identical depth maps and cost rows).
+#define GEO_D(bits) __builtin_bit_cast(double, (unsigned long long)(bits))
+template <int N, bool RANGE>
+__device__ __forceinline__ void geo_exp_n(double (&x)[N]) {
+	double n[N], r[N], p[N];
+#define GEO_EACH(stmt) { _Pragma("unroll") for (int j = 0; j < N; ++j) { stmt; } __builtin_amdgcn_sched_barrier(0); }
+	GEO_EACH(n[j] = x[j]*GEO_D(0x3ff71547652b82fe))
+	GEO_EACH(n[j] = __builtin_rint(n[j]))
+	GEO_EACH(r[j] = __builtin_fma(GEO_D(0xbfe62e42fefa39ef), n[j], x[j]))
+	GEO_EACH(r[j] = __builtin_fma(GEO_D(0xbc7abc9e3b39803f), n[j], r[j]))
+	GEO_EACH(p[j] = __builtin_fma(GEO_D(0x3e5ade156a5dcb37), r[j], GEO_D(0x3e928af3fca7ab0c)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3ec71dee623fde64)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3efa01997c89e6b0)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3f2a01a014761f6e)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3f56c16c1852b7b0)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3f81111111122322)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3fa55555555502a1)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3fc5555555555511)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], GEO_D(0x3fe000000000000b)))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], 1.0))
+	GEO_EACH(p[j] = __builtin_fma(r[j], p[j], 1.0))
+	GEO_EACH(p[j] = __builtin_ldexp(p[j], (int)n[j]))
+	if constexpr (RANGE) {
+		// (the empty statement pins the polynomial HERE: left to itself the compiler turns the selects below into branches and
+		// sinks each exponential's whole chain into its own innermost branch, one after the other again)
+		GEO_EACH(asm volatile("" : "+v"(p[j])))
+		GEO_EACH(p[j] = x[j] < -1075.0 ? 0.0 : p[j])
+		GEO_EACH(x[j] = x[j] > 1024.0 ? __builtin_inf() : p[j])
+	} else {
+		// x in [-2^30, 0]: the library's two selects (+inf above 1024, 0 below -1075) change nothing -- the first never fires, and
+		// below -1075 ldexp has already returned 0 (n < -1550) -- and are four v_cndmask_b32 and two compares, 100 cycles of a
+		// lone wave per exponential
+		GEO_EACH(x[j] = p[j])
+	}
+}
+// w[0..WS) <- exp(-w / sigma), GEO_EXPN at a time (fast: the shared-divisor quotient, also step-major)
+template <int WS, int B0, int N>
+__device__ __forceinline__ void geo_exp_chunk(double (&w)[WS], const SharedDivisor &sg, bool fast, double sigma) {
+	double x[N];
+	if (fast) {
+		double m[N];
+		GEO_EACH(x[j] = -w[B0 + j])
+		GEO_EACH(m[j] = x[j]*sg.r)
+		GEO_EACH(x[j] = __builtin_fma(-sg.b, m[j], x[j]))
+		GEO_EACH(x[j] = __builtin_fma(x[j], sg.r, m[j]))
+		geo_exp_n<N, false>(x);
+	} else {
+		GEO_EACH(x[j] = -w[B0 + j] / sigma)
+		geo_exp_n<N, true>(x);
+	}
+	GEO_EACH(w[B0 + j] = x[j])
+}
+#undef GEO_EACH
+template <int WS, int B0 = 0>
+__device__ __forceinline__ void geo_exp_row(double (&w)[WS], const SharedDivisor &sg, bool fast, double sigma) {
+	if constexpr (B0 < WS) {
+		constexpr int N = WS - B0 < GEO_EXPN ? WS - B0 : ((WS - B0 > GEO_EXPN && WS - B0 < 2*GEO_EXPN) ? (WS - B0 + 1)/2 : GEO_EXPN);
+		geo_exp_chunk<WS, B0, N>(w, sg, fast, sigma);
+		geo_exp_row<WS, B0 + N>(w, sg, fast, sigma);
+	}
+}
+template <int R, int TWD, int PL, int S>
+__device__ __forceinline__ void geo_edges(GeoLds tb, double &e0, double &e1, double &e2, double &e3) {
+	using C = GeoCell<R, S>;
+	constexpr int yy = C::yy, xx = C::xx;
+	if constexpr (C::fwd) {
+		if constexpr (C::c0) e0 = tb[2*PL + (yy-1)*TWD + xx - 1];
+		if constexpr (C::c1) e1 = tb[1*PL + (yy-1)*TWD + xx];
+		if constexpr (C::c2) e2 = tb[3*PL + (yy-1)*TWD + xx + 1];
+		if constexpr (C::c3) e3 = tb[0*PL + yy*TWD + xx - 1];
+	} else {
+		if constexpr (C::c0) e0 = tb[3*PL + yy*TWD + xx];
+		if constexpr (C::c1) e1 = tb[1*PL + yy*TWD + xx];
+		if constexpr (C::c2) e2 = tb[2*PL + yy*TWD + xx];
+		if constexpr (C::c3) e3 = tb[0*PL + yy*TWD + xx];
+	}
+}
+template <int R, int TWD, int PL, int KA, int NS, int S>
+__device__ __forceinline__ void geo_step(double (&w)[2*R+1][2*R+1], double (&er)[KA][4], GeoLds tb) {
+	using C = GeoCell<R, S>;
+	constexpr int yy = C::yy, xx = C::xx, dy = C::fwd ? -1 : 1, dx = C::fwd ? -1 : 1;
+	double (&e)[4] = er[S % KA];
+	double wt = w[yy][xx];
+	if constexpr (C::c0) wt = geo_min(w[yy+dy][xx-1] + e[0], wt);
+	if constexpr (C::c1) wt = geo_min(w[yy+dy][xx]   + e[1], wt);
+	if constexpr (C::c2) wt = geo_min(w[yy+dy][xx+1] + e[2], wt);
+	if constexpr (C::c3) wt = geo_min(w[yy][xx+dx]   + e[3], wt);
+	w[yy][xx] = wt;
+	__builtin_amdgcn_sched_barrier(0);
+	// (the four requests in a row: one after each relaxation instead ran the sweeps at 56 400 cycles per wave against 48 700)
+	if constexpr (S + KA < NS) {
+		geo_edges<R, TWD, PL, S + KA>(tb, e[0], e[1], e[2], e[3]);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+template <int R, int TWD, int PL, int KA, int... S>
+__device__ __forceinline__ void geo_prologue(double (&er)[KA][4], GeoLds tb, std::integer_sequence<int, S...>) {
+	(geo_edges<R, TWD, PL, S>(tb, er[S][0], er[S][1], er[S][2], er[S][3]), ...);
+}
+template <int R, int TWD, int PL, int KA, int NS, int... S>
+__device__ __forceinline__ void geo_iteration(double (&w)[2*R+1][2*R+1], double (&er)[KA][4], GeoLds tb, std::integer_sequence<int, S...>) {
+	(geo_step<R, TWD, PL, KA, NS, S>(w, er, tb), ...);
+}
+template <int R, int TWD, int TH>
+__device__ __forceinline__ void geodesic_sweeps(double (&w)[2*R+1][2*R+1], GeoLds tb, int iters) {
+	constexpr int WS = 2*R + 1, NS = 2*WS*WS, KA = GEO_AHEAD < NS ? GEO_AHEAD : NS, PL = TH*TWD;
+	double er[KA][4];
+#pragma unroll 1
+	for (int iter = 0; iter < iters; ++iter) {
+		geo_prologue<R, TWD, PL, KA>(er, tb, std::make_integer_sequence<int, KA>{});
+		__builtin_amdgcn_sched_barrier(0);
+		geo_iteration<R, TWD, PL, KA, NS>(w, er, tb, std::make_integer_sequence<int, NS>{});
+	}
+}
+
+// Per-pixel constants of the dense kernel's fast cost form from the window in registers (see the kernel): two sums over the
+// 121 taps, each ONE chain of dependent additions in the reference's tap order -- on a lone wave 12.6 cycles per link if the
+// links follow each other.  Software-pipelined over the taps: a tap's product is made two steps before it joins its chain, the
+// second sweep's product, difference and square one step apart each, the tap values (LDS, plane 4 of the tile) requested
+// GEO_AHEAD steps ahead like the sweeps' edges.  Same operations on the same operands in the same order per chain.
+template <int R, int TWD, int KG, int J>
+__device__ __forceinline__ void geo_pc1_step(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double (&pr)[4],
+                                             double &mL, double &tw, double &wmin) {
+	constexpr int WS = 2*R + 1, NT = WS*WS, LAG = 2;
+	if constexpr (J < NT) {
+		pr[J % 4] = w[J / WS][J % WS]*g[J % KG];
+		wmin = geo_min(wmin, w[J / WS][J % WS]);
+	}
+	if constexpr (J >= LAG) {
+		mL += pr[(J - LAG) % 4];
+		tw += w[(J - LAG) / WS][(J - LAG) % WS];
+	}
+	__builtin_amdgcn_sched_barrier(0);
+	if constexpr (J + KG < NT) { g[J % KG] = tg[((J + KG) / WS)*TWD + (J + KG) % WS]; __builtin_amdgcn_sched_barrier(0); }
+}
+template <int R, int TWD, int KG, int J>
+__device__ __forceinline__ void geo_pc2_step(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double (&pr)[4],
+                                             double mL, double &s2) {
+	constexpr int WS = 2*R + 1, NT = WS*WS;
+	if constexpr (J < NT) pr[J % 4] = w[J / WS][J % WS]*g[J % KG];
+	if constexpr (J >= 1 && J - 1 < NT) pr[(J - 1) % 4] = pr[(J - 1) % 4] - mL;
+	if constexpr (J >= 2 && J - 2 < NT) pr[(J - 2) % 4] = pr[(J - 2) % 4]*pr[(J - 2) % 4];
+	if constexpr (J >= 3) s2 += pr[(J - 3) % 4];
+	__builtin_amdgcn_sched_barrier(0);
+	if constexpr (J + KG < NT) { g[J % KG] = tg[((J + KG) / WS)*TWD + (J + KG) % WS]; __builtin_amdgcn_sched_barrier(0); }
+}
+template <int R, int TWD, int KG, int... J>
+__device__ __forceinline__ void geo_pc_fill(GeoLds tg, double (&g)[KG], std::integer_sequence<int, J...>) {
+	((g[J] = tg[(J / (2*R+1))*TWD + J % (2*R+1)]), ...);
+	__builtin_amdgcn_sched_barrier(0);
+}
+template <int R, int TWD, int KG, int... J>
+__device__ __forceinline__ void geo_pc1(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double &mL, double &tw, double &wmin,
+                                        std::integer_sequence<int, J...>) {
+	double pr[4];
+	(geo_pc1_step<R, TWD, KG, J>(w, tg, g, pr, mL, tw, wmin), ...);
+}
+template <int R, int TWD, int KG, int... J>
+__device__ __forceinline__ void geo_pc2(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double mL, double &s2,
+                                        std::integer_sequence<int, J...>) {
+	double pr[4];
+	(geo_pc2_step<R, TWD, KG, J>(w, tg, g, pr, mL, s2), ...);
+}
 
 template <int R, bool WIMG>
 __global__ __launch_bounds__(GW_TW*GW_ROWS)
@@ -95,23 +307,27 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 	const int cy = cy0 + wv;
 	const bool rowok = trow < nrows;
 #ifdef SRH_PROFILE_PHASES
-	unsigned long long gph_t = __builtin_amdgcn_s_memtime(), gph[4] = {0, 0, 0, 0};
+	unsigned long long gph_t = __builtin_amdgcn_s_memtime(), gph[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
 
-	__shared__ double eE[TH][TWD], eS[TH][TWD], eSE[TH][TWD], eSW[TH][TWD];
-	__shared__ double gt[TH][TWD];                           // the view's TwoView tap values (NaN = unusable), for pconst
+	// planes of the staged tile: 0 E, 1 S, 2 SE, 3 SW edges, 4 the view's TwoView tap values (NaN = unusable) for pconst.
+	// ONE array: every read of the sweeps is `lane base + a constant`, the constant in the instruction's offset field
+	__shared__ double tile[5][TH][TWD];
 	const double inf = __builtin_inf();
-	// a workgroup without a masked-in pixel has nothing to compute or store: it leaves before it stages its 35 KB tile
-	// (MultiViewStereo's views are mostly mask: four fifths of the workgroups of C4)
-	{
-		const int cx_ = x0 + (int)(threadIdx.x % GW_TW);
-		const bool act_ = rowok && cx_ < W && V.mask[(size_t)cy*W + cx_] == 1;
+	// A workgroup without a masked-in pixel has nothing to compute or store and leaves before it stages its 35 KB tile
+	// (MultiViewStereo's views are mostly mask: four fifths of the workgroups of C4).  The dense TwoView path (WIMG) asks the
+	// same question AFTER it has requested its tile: its images are mostly masked in, and the lone wave would sit through one
+	// more memory round trip before the first request of the tile.
+	const int cxm = x0 + (int)(threadIdx.x % GW_TW);
+	if constexpr (!WIMG) {
+		const bool act_ = rowok && cxm < W && V.mask[(size_t)cy*W + cxm] == 1;
 		if (!__syncthreads_or(act_)) return;
 	}
 	{
 		// all global loads of the thread first, LDS stores after: one memory latency per tile
 		constexpr int NB = (TH*TWD + NT - 1)/NT;
 		double t0[NB], t1[NB], t2[NB], t3[NB], t4[NB];
+		const uint8_t mk = (WIMG && rowok && cxm < W) ? V.mask[(size_t)cy*W + cxm] : (uint8_t)0;
 #pragma unroll
 		for (int k = 0; k < NB; ++k) {
 			const int idx = threadIdx.x + k*NT;
@@ -125,13 +341,16 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			t3[k] = in ? edges[3*n + gi] : inf;
 			t4[k] = (pconst && in) ? V.gray_tv[gi] : __builtin_nan("");
 		}
+		if constexpr (WIMG) {
+			if (!__syncthreads_or(mk == 1)) return;
+		}
 #pragma unroll
 		for (int k = 0; k < NB; ++k) {
 			const int idx = threadIdx.x + k*NT;
 			if (idx < TH*TWD) {
 				const int ty = idx / TWD, tx = idx % TWD;
-				eE[ty][tx] = t0[k]; eS[ty][tx] = t1[k]; eSE[ty][tx] = t2[k]; eSW[ty][tx] = t3[k];
-				gt[ty][tx] = t4[k];
+				tile[0][ty][tx] = t0[k]; tile[1][ty][tx] = t1[k]; tile[2][ty][tx] = t2[k]; tile[3][ty][tx] = t3[k];
+				tile[4][ty][tx] = t4[k];
 			}
 		}
 	}
@@ -155,62 +374,15 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		for (int b = 0; b < WS; ++b) w[a][b] = P.geodesic_init;
 	w[R][R] = 0.0;
 
-#pragma unroll 1
-	for (int iter = 0; iter < P.geodesic_iters; ++iter) {
-		// forward pass, K1 = (-1,-1) (0,-1) (1,-1) (-1,0)   (geodesicweight.cpp:73-97).
-		// std::min(weight, cost + diff): no operand is ever NaN (finite or +inf sums), so v_min_f64
-		// returns exactly what the compare-and-select does.  A cell outside the image is never
-		// relaxed because every edge that touches it is +inf.  The edges of one window row are
-		// fetched from LDS in one batch (the asm barrier keeps the loop-invariant reads from being
-		// hoisted out of the sweep, which would spill).
-#pragma unroll
-		for (int yy = 0; yy < WS; ++yy) {
-			asm volatile("" ::: "memory");
-			double se[WS], s_[WS], sw[WS], ee[WS];
-#pragma unroll
-			for (int xx = 0; xx < WS; ++xx) {
-				const int tx = i + xx;
-				se[xx] = (yy > 0 && xx > 0)      ? eSE[wv+yy-1][tx-1] : inf;
-				s_[xx] = (yy > 0)                ? eS[wv+yy-1][tx]    : inf;
-				sw[xx] = (yy > 0 && xx < WS - 1) ? eSW[wv+yy-1][tx+1] : inf;
-				ee[xx] = (xx > 0)                ? eE[wv+yy][tx-1]    : inf;
-			}
-#pragma unroll
-			for (int xx = 0; xx < WS; ++xx) {
-				double wt = w[yy][xx];
-				if (yy > 0 && xx > 0)      wt = __builtin_fmin(w[yy-1][xx-1] + se[xx], wt);
-				if (yy > 0)                wt = __builtin_fmin(w[yy-1][xx]   + s_[xx], wt);
-				if (yy > 0 && xx < WS - 1) wt = __builtin_fmin(w[yy-1][xx+1] + sw[xx], wt);
-				if (xx > 0)                wt = __builtin_fmin(w[yy][xx-1]   + ee[xx], wt);
-				w[yy][xx] = wt;
-			}
-		}
-		// backward pass, K2 = (-1,1) (0,1) (1,1) (1,0)      (geodesicweight.cpp:99-125)
-#pragma unroll
-		for (int yy = WS - 1; yy >= 0; --yy) {
-			asm volatile("" ::: "memory");
-			double se[WS], s_[WS], sw[WS], ee[WS];
-#pragma unroll
-			for (int xx = 0; xx < WS; ++xx) {
-				const int tx = i + xx;
-				sw[xx] = (yy < WS - 1 && xx > 0)      ? eSW[wv+yy][tx] : inf;
-				s_[xx] = (yy < WS - 1)                ? eS[wv+yy][tx]  : inf;
-				se[xx] = (yy < WS - 1 && xx < WS - 1) ? eSE[wv+yy][tx] : inf;
-				ee[xx] = (xx < WS - 1)                ? eE[wv+yy][tx]  : inf;
-			}
-#pragma unroll
-			for (int xx = WS - 1; xx >= 0; --xx) {
-				double wt = w[yy][xx];
-				if (yy < WS - 1 && xx > 0)      wt = __builtin_fmin(w[yy+1][xx-1] + sw[xx], wt);
-				if (yy < WS - 1)                wt = __builtin_fmin(w[yy+1][xx]   + s_[xx], wt);
-				if (yy < WS - 1 && xx < WS - 1) wt = __builtin_fmin(w[yy+1][xx+1] + se[xx], wt);
-				if (xx < WS - 1)                wt = __builtin_fmin(w[yy][xx+1]   + ee[xx], wt);
-				w[yy][xx] = wt;
-			}
-		}
-	}
+	geodesic_sweeps<R, TWD, TH>(w, (GeoLds)&tile[0][wv][i], P.geodesic_iters);
 	GEO_STAMP(1)
-	// exponential weighting (geodesicweight.cpp:128-130)
+	// exponential weighting (geodesicweight.cpp:128-130): exp(-w / sigma), 121 quotients by one divisor.  Every w is 0 or a sum
+	// of edges that are 0 or >= 1 (square roots of integers), capped by the initial value: with sigma and the initial value far
+	// from the exponent limits every quotient takes the shared-divisor form (srh_walk.hpp: the same bits; a zero comes out as
+	// +0 where the division gives -0, and exp of either is 1); with sigma > 0 and initial value / sigma < 2^30 the exponential's
+	// argument lies in [-2^30, 0], where its range selects are idle (geo_exp_n)
+	const SharedDivisor sg = shared_divisor(P.geodesic_sigma);
+	const bool sdiv = sg.ok && P.geodesic_sigma > 0 && P.geodesic_init > 0x1p-300 && P.geodesic_init < 0x1p300 && P.geodesic_init < 0x1p30*P.geodesic_sigma;
 	if constexpr (WIMG) {
 		// the strip kernel's LDS-image layout [tile][row][pixel][WP]: the 32 pixels' taps of one window row are 3 KB of
 		// contiguous bytes.  Stored as they stand (a lane's 96 bytes, 16 at a time) every store instruction touches 64
@@ -224,12 +396,25 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		double *stage = stage_buf[wv];
 		double *wt = wbuf + wimg_offset(W, R, rowok ? trow : 0, x0);   // first of the two window-buffer tiles of this wave's row
 		constexpr size_t TILE_D = (size_t)SRH_WTILE*WS*WP;   // doubles per tile
+		// 16-byte pieces of a staged row: piece q = doubles 2q, 2q+1 of pixel 2q / WP.  Which pieces this lane stores (its
+		// pixel masked in) and where they go is the same for every window row: made once
+		constexpr int NPIECE = GW_TW*WP/2, NK = (NPIECE + GW_TW - 1)/GW_TW;
+		bool st[NK];
+		unsigned goff[NK];
+#pragma unroll
+		for (int k = 0; k < NK; ++k) {
+			const int q = i + k*GW_TW;
+			const int pix = (2*q)/WP;
+			const int half = pix/SRH_WTILE;             // which of the two tiles
+			st[k] = q < NPIECE && ((amask >> pix) & 1ull);
+			goff[k] = (unsigned)(half*(int)TILE_D + (2*q - half*SRH_WTILE*WP));
+		}
 #pragma unroll
 		for (int a = 0; a < WS; ++a) {
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int b = 0; b < WS; ++b) w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
+			geo_exp_row<WS>(w[a], sg, sdiv, P.geodesic_sigma);
+			GEO_STAMP(2)
 #pragma unroll
 			for (int b = 0; b + 1 < WS; b += 2) {
 				double2 v; v.x = w[a][b]; v.y = w[a][b + 1];
@@ -238,27 +423,26 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			stage[i*WP + WS - 1] = w[a][WS - 1];
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			// 16-byte pieces of the staged row: piece q = doubles 2q, 2q+1 of pixel 2q / WP
+			// all pieces read back before the first leaves (one LDS round trip per row, not one per piece: the lone wave has
+			// nothing else to do meanwhile; the empty statement keeps the compiler from sinking each read into its store's branch)
+			double2 v[NK];
 #pragma unroll
-			for (int k = 0; k < (GW_TW*WP/2 + GW_TW - 1)/GW_TW; ++k) {
-				const int q = i + k*GW_TW;
-				const int pix = (2*q)/WP;
-				if (q < GW_TW*WP/2 && ((amask >> pix) & 1ull)) {
-					const double2 v = *reinterpret_cast<const double2 *>(stage + 2*q);
-					const int half = pix/SRH_WTILE;          // which of the two tiles
-					*reinterpret_cast<double2 *>(wt + half*TILE_D + (size_t)a*(SRH_WTILE*WP) + (2*q - half*SRH_WTILE*WP)) = v;
-				}
-			}
+			for (int k = 0; k < NK; ++k) v[k] = *reinterpret_cast<const double2 *>(stage + 2*((i + k*GW_TW) < NPIECE ? (i + k*GW_TW) : 0));
+#pragma unroll
+			for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+			double *wrow = wt + (size_t)a*(SRH_WTILE*WP);
+#pragma unroll
+			for (int k = 0; k < NK; ++k)
+				if (st[k]) { typedef double d2v __attribute__((ext_vector_type(2))); d2v t; t.x = v[k].x; t.y = v[k].y; __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(wrow + goff[k])); }
+			GEO_STAMP(4)
 		}
 	} else {
 		double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);         // (active lanes only: inside the band)
 #pragma unroll
 		for (int a = 0; a < WS; ++a) {
+			geo_exp_row<WS>(w[a], sg, sdiv, P.geodesic_sigma);
 #pragma unroll
-			for (int b = 0; b < WS; ++b) {
-				w[a][b] = exp(-w[a][b] / P.geodesic_sigma);
-				wb[(size_t)(a*WS + b)*wstride] = w[a][b];
-			}
+			for (int b = 0; b < WS; ++b) __builtin_nontemporal_store(w[a][b], &wb[(size_t)(a*WS + b)*wstride]);
 			asm volatile("" ::: "memory");
 		}
 	}
@@ -267,24 +451,23 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		// Per-pixel constants of the dense kernel's fast cost form, while the window is in registers: when every tap
 		// is usable (gray value valid, weight above the cut-off), meanL, totalWeight and sum2 of
 		// twoviewstereo.cpp:917-976 do not depend on the candidate.  Same tap order, same operations.
-		bool all = true;
-		double mL = 0, tw = 0;
-#pragma unroll
-		for (int a = 0; a < WS; ++a)
-#pragma unroll
-			for (int b = 0; b < WS; ++b) {
-				const double gl = gt[wv + a][i + b];
-				if (!(gl == gl && w[a][b] > P.weight_cutoff)) all = false;
-				mL += w[a][b]*gl;
-				tw += w[a][b];
-			}
+		constexpr int NT = WS*WS, KG = GEO_AHEAD < NT ? GEO_AHEAD : NT;
+		const GeoLds tg = (GeoLds)&tile[4][wv][i];
+		double g[KG];
+		// every tap usable = every gray value valid (finite; NaN otherwise, and one NaN makes the sum meanL NaN: the weights are
+		// finite) and every weight above the cut-off (the smallest is): one v_min_f64 per tap instead of two compares and the
+		// mask arithmetic (which the compiler kept as 121 lane masks parked in VGPR lanes until the end)
+		double mL = 0, tw = 0, wmin = __builtin_inf();
+		geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
+		geo_pc1<R, TWD, KG>(w, tg, g, mL, tw, wmin, std::make_integer_sequence<int, NT + 2>{});
+		bool all = mL == mL && wmin > P.weight_cutoff;
+		GEO_STAMP(5)
 		double s2 = 0;
 		if (all && !(tw < 1e-10)) {
 			mL /= tw;
-#pragma unroll
-			for (int a = 0; a < WS; ++a)
-#pragma unroll
-				for (int b = 0; b < WS; ++b) { const double t = w[a][b]*gt[wv + a][i + b] - mL; s2 += t*t; }
+			geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
+			geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, std::make_integer_sequence<int, NT + 3>{});
+			GEO_STAMP(6)
 		} else all = false;
 		double *pc = pconst + ((size_t)trow*W + cx)*4;
 		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
@@ -292,8 +475,8 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 #ifdef SRH_PROFILE_PHASES
 	GEO_STAMP(3)
 	if (i == 0 && rowok) {
-		for (int k = 0; k < 4; ++k) atomicAdd(&g_geo_phase[k], gph[k]);
-		atomicAdd(&g_geo_phase[4], 1ull);
+		for (int k = 0; k < 7; ++k) atomicAdd(&g_geo_phase[k], gph[k]);
+		atomicAdd(&g_geo_phase[7], 1ull);
 	}
 #endif
 }

@@ -242,7 +242,7 @@ bool launch_twoview_strip_cost(hipStream_t st, const ViewDev *views, int ref, in
                                int lanes, bool raw = false);   // raw (diagnostics): certified forms without the in-kernel exact redo
 
 #ifdef SRH_PROFILE_PHASES
-void geodesic_phases_fetch(unsigned long long out[5]);
+void geodesic_phases_fetch(unsigned long long out[8]);
 #endif
 #ifdef SRH_EXPERIMENT
 void exp_set(int repeat, int lds_pad);
