@@ -47,6 +47,13 @@ void k(double *out, const double *seed, int iters, unsigned long long *ticks) {
 #define SAL(j)  asm volatile("s_and_b64 s[20:21], s[22:23], s[24:25]" ::: "s20", "s21", "scc");
 #define E32(j)  asm volatile("v_exp_f32 %0, %1" : "=v"(ia[j]) : "v"(ia[(j + 1) & 7]));
 #define WAIT    asm volatile("s_waitcnt lgkmcnt(0)");
+// a 64-bit select as the compiler writes it (compare into VCC, two v_cndmask_b32 reading VCC back to back), the same with the
+// mask in an SGPR pair, and with two other instructions between the two VCC readers
+#define CPV(j)  asm volatile("v_cmp_gt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(ia[j]) : "v"(a[j]), "v"(b[j]), "v"(ia[(j + 1) & 7]), "v"(ia[(j + 2) & 7]) : "vcc");
+#define CPS(j)  asm volatile("v_cmp_gt_f64_e64 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %3, %4, s[20:21]" : "=v"(ia[j]) : "v"(a[j]), "v"(b[j]), "v"(ia[(j + 1) & 7]), "v"(ia[(j + 2) & 7]) : "s20", "s21");
+#define CPD(j)  asm volatile("v_cmp_gt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %5, vcc\n\tv_cndmask_b32 %1, %5, %4, vcc" : "=v"(ia[j]), "=v"(ia[(j + 3) & 7]) : "v"(a[j]), "v"(b[j]), "v"(ia[(j + 1) & 7]), "v"(ia[(j + 2) & 7]) : "vcc");
+#define CSD(j)  asm volatile("v_cmp_gt_f64_e64 s[20:21], %2, %3\n\tv_cndmask_b32_e64 %0, %4, %5, s[20:21]\n\tv_cndmask_b32_e64 %1, %5, %4, s[20:21]" : "=v"(ia[j]), "=v"(ia[(j + 3) & 7]) : "v"(a[j]), "v"(b[j]), "v"(ia[(j + 1) & 7]), "v"(ia[(j + 2) & 7]) : "s20", "s21");
+#define CPX(j)  asm volatile("v_cmp_gt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %5, vcc\n\tv_add_f64 %2, %2, %3\n\tv_add_f64 %3, %3, %3\n\tv_cndmask_b32 %1, %5, %4, vcc" : "=v"(ia[j]), "=v"(ia[(j + 3) & 7]), "+v"(a[j]), "+v"(b[j]) : "v"(ia[(j + 1) & 7]), "v"(ia[(j + 2) & 7]) : "vcc");
 #define CN3(j)  asm volatile("v_cndmask_b32_e64 %0, %1, %2, s[22:23]" : "=v"(ia[j]) : "v"(ia[(j + 1) & 7]), "v"(ia[(j + 2) & 7]));
 #define CN0(j)  asm volatile("v_cndmask_b32 %0, 0, %1, vcc" : "=v"(ia[j]) : "v"(ia[(j + 1) & 7]) : "vcc");
 #define MAX(j)  asm volatile("v_max_f64 %0, %0, %1" : "+v"(a[j]) : "v"(b[j]));
@@ -92,6 +99,11 @@ void k(double *out, const double *seed, int iters, unsigned long long *ticks) {
 		                            ADD(0) MIN(0) ADD(1) MIN(1) ADD(2) MIN(2) ADD(3) MIN(3) ADD(4) MIN(4) ADD(5) MIN(5) ADD(6) MIN(6) ADD(7) MIN(7) }
 		if constexpr (KIND == 22) { R8(DS2) WAIT R8(DS2) WAIT R8(DS2) WAIT R8(DS2) WAIT }
 		if constexpr (KIND == 23) { R32(CN3) }
+		if constexpr (KIND == 40) { R32(CPV) }
+		if constexpr (KIND == 41) { R32(CPS) }
+		if constexpr (KIND == 42) { R32(CPD) }
+		if constexpr (KIND == 43) { R32(CSD) }
+		if constexpr (KIND == 44) { R32(CPX) }
 		if constexpr (KIND == 24) { R32(CN0) }
 		if constexpr (KIND == 25) { R32(MAX) }
 		if constexpr (KIND == 26) { R8(D16) WAIT R8(D16) WAIT R8(D16) WAIT R8(D16) WAIT }
@@ -148,6 +160,10 @@ int main() {
 	run<22>("ds_read2_b64, a wait after every 8", 32, d, seed, tk);
 	run<18>("s_and_b64", 32, d, seed, tk);  run<19>("v_exp_f32", 32, d, seed, tk);
 	run<23>("v_cndmask_b32_e64 (mask in an SGPR pair)", 32, d, seed, tk); run<24>("v_cndmask_b32 0, v, vcc", 32, d, seed, tk);
+	printf("(the next five: cycles per GROUP of instructions)\n");
+	run<40>("v_cmp_gt_f64 vcc + v_cndmask_b32 vcc", 32, d, seed, tk); run<41>("v_cmp_gt_f64_e64 s[] + v_cndmask_b32_e64 s[]", 32, d, seed, tk);
+	run<42>("v_cmp_gt_f64 vcc + 2 v_cndmask_b32 vcc", 32, d, seed, tk); run<43>("v_cmp_gt_f64_e64 s[] + 2 v_cndmask_b32_e64 s[]", 32, d, seed, tk);
+	run<44>("cmp vcc, cndmask vcc, 2 v_add_f64, cndmask vcc", 32, d, seed, tk);
 	run<25>("v_max_f64", 32, d, seed, tk); run<36>("v_cmp_o_f64 vcc", 32, d, seed, tk); run<37>("v_cmp_gt_f64_e64 -> SGPR pair", 32, d, seed, tk);
 	run<26>("ds_read_b128, a wait after every 8", 32, d, seed, tk);
 	run<27>("ds_write_b64", 32, d, seed, tk); run<28>("ds_write_b128", 32, d, seed, tk);

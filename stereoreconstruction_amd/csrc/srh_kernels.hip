@@ -1425,13 +1425,15 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 				// affected, the square root and the division are skipped.
 				const double den = s2 * s3;
 				const double bound = bestCost > thr0 ? bestCost : thr0;
-				bool hopeless;
-				if (ecur == MQ_PAD) hopeless = true;
-				else if (CERT && !(s3 >= sig3)) { hopeless = false; amb = true; }   // a candidate the bound does not cover: the unit is redone
-				else if (!(den >= 1e-10)) hopeless = P.peak_threshold >= 0.0;        // score 0 (or NaN)
-				else if (s1 < 0.0) hopeless = P.peak_threshold >= 0.0;
+				// (as lane masks side by side, not as a chain of branches: a scalar instruction costs the wave 8.75 cycles, and the
+				// chain was 25 of them around seven compares -- profiles/microbench/lone_wave_issue)
+				const bool pad = ecur == MQ_PAD;
+				const bool unc = CERT && !(s3 >= sig3);                          // a candidate the bound does not cover: the unit is redone
+				const bool nul = !(den >= 1e-10) | (s1 < 0.0);                   // score 0 (or NaN), or negative
 				// (certified: the fused score is within e0 of the reference's; 5e-7*bound covers e0 once bound >= 1e-3)
-				else hopeless = (!CERT || bound >= 1e-3) && s1*s1 < bound*bound*den*0.999999;
+				const bool low = (!CERT || bound >= 1e-3) & (s1*s1 < bound*bound*den*0.999999);
+				const bool hopeless = pad | (!unc & (nul ? P.peak_threshold >= 0.0 : low));
+				if (CERT) amb |= !pad & unc;
 				if (__all(hopeless)) continue;
 				const double c = (den < 1e-10) ? 0.0 : s1 / sqrt(den);
 				if (CERT) {
