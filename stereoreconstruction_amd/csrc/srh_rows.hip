@@ -470,19 +470,22 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					const int gx = gx0 + k;
 					rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
 				}
+				// (no select per tap and candidate: an unusable value becomes 0.0 with a flag 0.0 / 1.0 beside it, a tap whose own
+				// side is unusable gets weight 0.0, and what the reference skips is multiplied by that 0.0 -- strip_select_block,
+				// srh_strip.hip, has the argument)
+				double rv[NR_];
+#pragma unroll
+				for (int k = 0; k < NR_; ++k) { const bool okr = rr[k] == rr[k]; rv[k] = okr ? 1.0 : 0.0; rr[k] = okr ? rr[k] : 0.0; }
 #pragma unroll
 				for (int col = 0; col < WS; ++col) {
 					const double gl = CS.lt[row][pi + col], wt = CS.w[pi][row*WP + col];
 					const bool okl = gl == gl && wt > P.weight_cutoff;
-					const double pl = wt*gl;
+					const double w0 = okl ? wt : 0.0, pl0 = okl ? wt*gl : 0.0;
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
-						const double gr = rr[col + j];
-						const bool ok = okl && gr == gr;
-						const double pr = wt*gr;
-						mLs[j] += ok ? pl : 0.0;
-						mRs[j] += ok ? pr : 0.0;
-						tws[j] += ok ? wt : 0.0;
+						mLs[j] += pl0*rv[col + j];
+						mRs[j] += w0*rr[col + j];
+						tws[j] += w0*rv[col + j];
 					}
 				}
 			}
@@ -502,20 +505,21 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					const int gx = gx0 + k;
 					rr[k] = (rowok && gx >= 0 && gx < OW) ? rp[gx] : nan;
 				}
+				double rv[NR_];
+#pragma unroll
+				for (int k = 0; k < NR_; ++k) { const bool okr = rr[k] == rr[k]; rv[k] = okr ? 1.0 : 0.0; rr[k] = okr ? rr[k] : 0.0; }
 #pragma unroll
 				for (int col = 0; col < WS; ++col) {
 					const double gl = CS.lt[row][pi + col], wt = CS.w[pi][row*WP + col];
 					const bool okl = gl == gl && wt > P.weight_cutoff;
-					const double pl = wt*gl;
+					const double pl = wt*(gl == gl ? gl : 0.0), kl = okl ? 1.0 : 0.0;
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
-						const double gr = rr[col + j];
-						const bool ok = okl && gr == gr;
-						const double a = pl - mLs[j], bq = wt*gr - mRs[j];
-						const double ab = a*bq, aa = a*a, bb = bq*bq;
-						s1[j] += ok ? ab : 0.0;
-						s2v[j] += ok ? aa : 0.0;
-						s3[j] += ok ? bb : 0.0;
+						const double k = kl*rv[col + j];                       // 1.0: the tap counts for this candidate
+						const double a = (pl - mLs[j])*k, bq = (wt*rr[col + j] - mRs[j])*k;
+						s1[j] += a*bq;
+						s2v[j] += a*a;
+						s3[j] += bq*bq;
 					}
 				}
 			}

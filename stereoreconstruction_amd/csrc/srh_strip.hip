@@ -242,29 +242,33 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 {
 	typedef StripSmem<R, NBUF> Smem;
 	constexpr int WS = Smem::WS, NS = Smem::NS, NCB = ST_NCB, NR = NCB + 2*R;
+	// "A skipped tap adds +0.0 to every sum" WITHOUT a select per tap and candidate (six v_cndmask_b32 and a compare for each of
+	// the 968 pairs of a block, twice): the validity of a value is settled once per value -- an unusable gray value becomes 0.0
+	// with a flag 0.0 / 1.0 beside it, a tap whose own side is unusable gets weight 0.0 -- and what the reference skips is
+	// multiplied by that 0.0: x*1.0 is x and x*0.0 a zero for the finite x here, and a sum that starts at +0.0 never is -0.0,
+	// so adding a zero of either sign changes nothing.  The taps that count go through the reference's own operations.
 	double mLs[NCB], mRs[NCB], tws[NCB];
 #pragma unroll
 	for (int j = 0; j < NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
 #pragma unroll 1
 	for (int row = 0; row < WS; ++row) {
 		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
-		double rr[NR];
+		double rr[NR], rv[NR];
 		const double2 *rp = reinterpret_cast<const double2 *>((NBUF == 2 && (rc & 1)) ? &S.rto[sl][rc - 1] : &S.rt[sl][rc]);
 #pragma unroll
 		for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; rr[2*m] = v.x; rr[2*m + 1] = v.y; }
 #pragma unroll
+		for (int m = 0; m < NR; ++m) { const bool okr = rr[m] == rr[m]; rv[m] = okr ? 1.0 : 0.0; rr[m] = okr ? rr[m] : 0.0; }
+#pragma unroll
 		for (int col = 0; col < WS; ++col) {
 			const double gl = S.lt[sl][pi + col], wt = S.w[wb][row][pi][col];
 			const bool okl = gl == gl && wt > weight_cutoff;
-			const double pl = wt*gl;
+			const double w0 = okl ? wt : 0.0, pl0 = okl ? wt*gl : 0.0;
 #pragma unroll
 			for (int j = 0; j < NCB; ++j) {
-				const double gr = rr[col + j];
-				const bool ok = okl && gr == gr;
-				const double pr = wt*gr;
-				mLs[j] += ok ? pl : 0.0;
-				mRs[j] += ok ? pr : 0.0;
-				tws[j] += ok ? wt : 0.0;
+				mLs[j] += pl0*rv[col + j];
+				mRs[j] += w0*rr[col + j];
+				tws[j] += w0*rv[col + j];
 			}
 		}
 	}
@@ -276,24 +280,24 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 #pragma unroll 1
 	for (int row = 0; row < WS; ++row) {
 		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
-		double rr[NR];
+		double rr[NR], rv[NR];
 		const double2 *rp = reinterpret_cast<const double2 *>((NBUF == 2 && (rc & 1)) ? &S.rto[sl][rc - 1] : &S.rt[sl][rc]);
 #pragma unroll
 		for (int m = 0; m < NR/2; ++m) { const double2 v = rp[m]; rr[2*m] = v.x; rr[2*m + 1] = v.y; }
 #pragma unroll
+		for (int m = 0; m < NR; ++m) { const bool okr = rr[m] == rr[m]; rv[m] = okr ? 1.0 : 0.0; rr[m] = okr ? rr[m] : 0.0; }
+#pragma unroll
 		for (int col = 0; col < WS; ++col) {
 			const double gl = S.lt[sl][pi + col], wt = S.w[wb][row][pi][col];
 			const bool okl = gl == gl && wt > weight_cutoff;
-			const double pl = wt*gl;
+			const double pl = wt*(gl == gl ? gl : 0.0), kl = okl ? 1.0 : 0.0;
 #pragma unroll
 			for (int j = 0; j < NCB; ++j) {
-				const double gr = rr[col + j];
-				const bool ok = okl && gr == gr;
-				const double a = pl - mLs[j], bq = wt*gr - mRs[j];
-				const double ab = a*bq, aa = a*a, bb = bq*bq;
-				s1[j] += ok ? ab : 0.0;
-				s2v[j] += ok ? aa : 0.0;
-				s3[j] += ok ? bb : 0.0;
+				const double k = kl*rv[col + j];                       // 1.0: the tap counts for this candidate
+				const double a = (pl - mLs[j])*k, bq = (wt*rr[col + j] - mRs[j])*k;
+				s1[j] += a*bq;
+				s2v[j] += a*a;
+				s3[j] += bq*bq;
 			}
 		}
 	}
