@@ -198,6 +198,10 @@ int  srh_synchronize(srh_context *ctx);
  *   "tscan"           1 (default): on the dense path the scan makes the candidate sequence once per pass and every pixel verifies
  *                     its own curve against it (template scan; a tile with a pixel that does not verify is walked per pixel);
  *                     0: every tile by the per-pixel curve walk.  Identical bits (srh_stats.scan_tiles_template / _walked).
+ *   "geodma"          1 (default): on the dense path (GeodesicWeight, radius 5) the support windows come from the persistent
+ *                     kernel that fetches its tiles by LDS-DMA from a second copy of the view's edge / tap / mask planes with
+ *                     their borders written out (made on first use after an upload: 42 bytes per pixel of device memory; no
+ *                     room for it: the other kernel runs); 0: the register-staged windows kernel.  Identical bits.
  *   "side_weights"    1 (default): the row-run path computes a band's support windows on a side stream beside its list kernel;
  *                     0: behind it on the pass's own stream (profiling: every kernel's own duration).  Identical bits.
  *   "list_rows"       1 (default) candidate lists are costed in row runs; 0 in list order

@@ -9,6 +9,7 @@ L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, 0x5EED0003)
 zmin, zmax = synthetic.rectified_depth_range(W, D)
 p = capi.params_twoview(min_depth=zmin, max_depth=zmax, num_depth_levels=D, weight_kind=capi.WEIGHT_GEODESIC)
 with capi.Context(0) as ctx:
+    if "GEODMA" in os.environ: ctx.set_option("geodma", int(os.environ["GEODMA"]))
     ctx.upload_view(0, L, ml, capi.camera_from_krt(Kl, Rl, tl))
     ctx.upload_view(1, R, mr, capi.camera_from_krt(Kr, Rr, tr))
     h = hashlib.sha256()

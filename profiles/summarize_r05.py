@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = sys.argv[1]
 
 # kernels whose global reads are 16 bytes per lane (LDS-DMA dwordx4 / dwordx4 loads of whole rows)
-WIDE_READERS = {"twoview_strip_cost_kernel", "geodesic_reg_kernel", "padded_plane_kernel", "fill_kernel", "__amd_rocclr_copyBuffer"}   # (the template scan reads 8 bytes per lane: not doubled)
+WIDE_READERS = {"twoview_strip_cost_kernel", "geodesic_reg_kernel", "geodesic_dma_kernel", "padded_plane_kernel", "fill_kernel", "__amd_rocclr_copyBuffer"}   # (the template scan reads 8 bytes per lane: not doubled)
 
 
 def short(name):

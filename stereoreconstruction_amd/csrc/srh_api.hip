@@ -47,6 +47,7 @@ struct ViewHost {
 	int       full_r = 0;
 	// strip kernel (srh_strip.hip): NaN-bordered copy of gray_tv, zero-bordered "window fully usable" plane for radius fullp_r
 	double   *tvp = nullptr;   bool tvp_valid = false;
+	double   *geo5 = nullptr;  bool geo5_valid = false;   // edge + tap planes with their borders written out (geodesic_dma_kernel)
 	uint8_t  *fullp = nullptr; int fullp_r = 0;
 	// how the candidate lists of this view against slot j are best evaluated, learnt from the last run:
 	// 0 unknown, 1 row runs (srh_rows.hip), 2 list order (srh_list.hip: steep curves)
@@ -113,6 +114,7 @@ struct srh_context {
 	uint32_t *cflag = nullptr; size_t cflag_cap = 0;    // certified arithmetic: [count | band pixels whose decisions the bound does not cover]
 	uint8_t *stpl = nullptr; size_t stpl_cap = 0;       // template scan: the pass's candidate template (twoview_template_kernel)
 	uint32_t *tileflag = nullptr; size_t tileflag_cap = 0;  //   and the tiles it leaves to twoview_scan_kernel: [count | tile indices]
+	int geodma = 1;                                     // option "geodma": 1 = the dense path's r = 5 geodesic windows by the persistent LDS-DMA kernel (default), 0 = geodesic_reg_kernel
 	int tscan = 1;                                      // option "tscan": 1 = template scan on the dense path (default), 0 = every tile through twoview_scan_kernel
 	int strip = 1;                                      // option "strip": 1 = persistent strip cost kernel (default), 0 = one workgroup per tile, 4 / 8 = force the 4- / 8-wave form
 	int num_cus = 256;
@@ -546,6 +548,7 @@ static void free_view(ViewHost &v) {
 	if (v.edges) hipFree(v.edges);
 	if (v.full) hipFree(v.full);
 	if (v.tvp) hipFree(v.tvp);
+	if (v.geo5) hipFree(v.geo5);
 	if (v.fullp) hipFree(v.fullp);
 	if (v.peaks) hipFree(v.peaks);
 	if (v.mrf) hipFree(v.mrf);
@@ -684,6 +687,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	}
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
 	if (!strcmp(name, "tscan")) { c->tscan = value != 0; return SRH_OK; }
+	if (!strcmp(name, "geodma")) { c->geodma = value != 0; return SRH_OK; }
 	if (!strcmp(name, "side_weights")) { c->side_weights = value != 0; return SRH_OK; }
 	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
 	if (!strcmp(name, "debug_mvs_cmax_hint")) { c->mvs_cmax_hint = value > 0 ? (int)((value + 7) & ~7L) : 0; return SRH_OK; }
@@ -729,7 +733,7 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	}
 	v.cam = *cam;
 	v.full_r = 0;                                               // recomputed on demand for the new pixels
-	v.tvp_valid = false; v.fullp_r = 0;
+	v.tvp_valid = false; v.fullp_r = 0; v.geo5_valid = false;
 	v.peaks_k = 0;                                              // the top-K peaks belonged to the previous image
 	if (c->mrf_w == w && c->mrf_h == h) c->mrf_w = c->mrf_h = c->mrf_k = 0;
 	for (int j = 0; j < SRH_MAX_VIEWS; ++j) { v.list_mode[j] = 0; c->views[j].list_mode[slot] = 0; }   // new geometry
@@ -952,6 +956,24 @@ static int fetch_counters(srh_context *c, int used_dense) {
 // support windows of rows [by, by+nr) of view `ref` into c->wbuf
 static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int by, int nr, size_t wstride,
                         double *pconst = nullptr, bool wimg = false) {
+	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic && wimg && c->geodma && p.window_radius == 5) {
+		// the dense path's windows: tiles by LDS-DMA from planes with their borders written out (made once per uploaded view)
+		ViewHost &v = c->views[ref];
+		bool ok = true;
+		if (!v.geo5) {
+			if (hipMalloc((void **)&v.geo5, geo5_doubles(v.w, v.h)*sizeof(double)) != hipSuccess) { (void)hipGetLastError(); v.geo5 = nullptr; ok = false; }   // (no room: the register-staged kernel needs no second copy)
+			v.geo5_valid = false;
+		}
+		if (ok && !v.geo5_valid) {
+			Scope s(c, "geo5_planes_kernel");
+			launch_geo5_planes(c->stream, v.edges, v.gray_tv, v.mask, v.w, v.h, v.geo5);
+			v.geo5_valid = true;
+		}
+		if (ok) {
+			Scope s(c, "geodesic_dma_kernel");
+			if (launch_geodesic_dma(c->stream, c->d_views, ref, W, v.geo5, p, by, nr, c->wbuf, pconst, c->num_cus)) return;
+		}
+	}
 	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic) {
 		Scope s(c, "geodesic_reg_kernel");
 		if (launch_geodesic_reg(c->stream, c->d_views, ref, W, c->views[ref].edges, p, by, nr, c->wbuf, wstride, pconst, wimg)) return;

@@ -482,6 +482,210 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 }
 #undef GEO_STAMP
 
+// ------------------------------------------------------------------ geodesic windows, the tile by LDS-DMA (dense TwoView path, r = 5)
+// The kernel above stages its tile through registers at its start, and a wave alone on its SIMD sits through that memory
+// round trip with nothing else to run: 14 % of its life.  Here a workgroup is PERSISTENT (one per compute unit: four waves =
+// four consecutive image rows of 64 columns, one tile of 14 x 74 cells x 5 planes = 41 KB) and keeps TWO tiles in LDS: while it
+// works on one, the next arrives by LDS-DMA (global_load_lds, 16 bytes per lane, no registers), requested right after the
+// barrier that hands the buffer over.  LDS-DMA copies bytes, it cannot put +inf where the image ends: the four edge planes and
+// the tap plane are kept a second time with their borders written out (geo5: +inf / NaN margins of GD_PAD* cells, rows of even
+// length starting 16-byte aligned at every tile's first column), made once per uploaded view.  The arithmetic is the kernel's
+// above, statement for statement (the same helpers); four rows per tile also fetch 14 tile rows per 4 image rows instead of
+// 12 per 2.
+#define GD_ROWS 4
+#define GD_PADL 5                  // = R of the one instantiation: column x0 - R of a tile is padded column x0, x0 a multiple of 64
+#define GD_PADR 70
+#define GD_PADT 5
+#define GD_PADB (5 + GD_ROWS - 1)
+static inline __host__ __device__ int geo5_stride(int w) { return (w + GD_PADL + GD_PADR + 1) & ~1; }
+static inline __host__ __device__ int geo5_rows(int h) { return h + GD_PADT + GD_PADB; }
+// (behind the five planes: the mask bytes, rows of a multiple of four bytes reaching 63 columns and 3 rows past the image,
+// zero there -- a tile's 4 x 64 mask bytes are ONE dword request of 16 lanes per wave)
+static inline __host__ __device__ int geo5_mstride(int w) { return (w + 64 + 3) & ~3; }
+static inline __host__ __device__ size_t geo5_plane_doubles(int w, int h) { return (size_t)5*geo5_stride(w)*geo5_rows(h); }
+size_t geo5_doubles(int w, int h) { return geo5_plane_doubles(w, h) + ((size_t)geo5_mstride(w)*(h + 4) + 7)/8; }
+
+__global__ void geo5_planes_kernel(const double *__restrict__ edges, const double *__restrict__ gray_tv,
+                                   const uint8_t *__restrict__ mask, int W, int H, double *__restrict__ out)
+{
+	{
+		uint8_t *mo = (uint8_t *)(out + geo5_plane_doubles(W, H));
+		const int MS = geo5_mstride(W);
+		const size_t mt = (size_t)MS*(H + 4);
+		for (size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x; q < mt; q += (size_t)gridDim.x*blockDim.x) {
+			const int y = (int)(q / MS), x = (int)(q % MS);
+			mo[q] = (x < W && y < H) ? mask[(size_t)y*W + x] : (uint8_t)0;
+		}
+	}
+	const int GS = geo5_stride(W), GR = geo5_rows(H);
+	const size_t n = (size_t)W*H, pl = (size_t)GS*GR, tot = 5*pl;
+	for (size_t q = (size_t)blockIdx.x*blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x*blockDim.x) {
+		const int k = (int)(q / pl);
+		const size_t r = q - (size_t)k*pl;
+		const int y = (int)(r / GS) - GD_PADT, x = (int)(r % GS) - GD_PADL;
+		const bool in = x >= 0 && y >= 0 && x < W && y < H;
+		out[q] = k < 4 ? (in ? edges[(size_t)k*n + (size_t)y*W + x] : __builtin_inf())
+		               : (in ? gray_tv[(size_t)y*W + x] : __builtin_nan(""));
+	}
+}
+void launch_geo5_planes(hipStream_t st, const double *edges, const double *gray_tv, const uint8_t *mask, int w, int h, double *out) {
+	hipLaunchKernelGGL(geo5_planes_kernel, dim3(4096), dim3(256), 0, st, edges, gray_tv, mask, w, h, out);
+}
+
+template <int R>
+__global__ __launch_bounds__(GW_TW*GD_ROWS)
+void geodesic_dma_kernel(const ViewDev *__restrict__ views, int ref, const double *__restrict__ geo5,
+                         srh_params P, int y0, int nrows, double *__restrict__ wbuf, double *__restrict__ pconst)
+{
+	static_assert(R == GD_PADL, "the padded planes are laid out for this radius");
+	constexpr int WS = 2*R + 1, TWD = GW_TW + 2*R, TH = WS + GD_ROWS - 1, PL = TH*TWD;
+	constexpr int TILE_BYTES = 5*PL*8, NPC = (TILE_BYTES + 1023)/1024;
+	constexpr int WP = (WS + 1) & ~1;
+	static_assert((TWD*8) % 16 == 0 && GW_TW == 2*SRH_WTILE, "tile rows are whole 16-byte pieces; a wave covers two window-buffer tiles");
+	const ViewDev &V = views[ref];
+	const int W = V.w, H = V.h;
+	const int GS = geo5_stride(W);
+	const size_t GPL = (size_t)GS*geo5_rows(H);
+	const int tiles_per_row = (W + GW_TW - 1)/GW_TW;
+	const int total_tiles = tiles_per_row*((nrows + GD_ROWS - 1)/GD_ROWS);
+	const int wv = threadIdx.x / GW_TW, i = threadIdx.x % GW_TW;
+	__shared__ __align__(16) double tile[2][5][TH][TWD];
+	__shared__ __align__(16) double stage_buf[GD_ROWS][GW_TW*WP];
+	__shared__ __align__(16) unsigned mtile[2][GD_ROWS][GW_TW/4];   // the tile's mask bytes, row by row
+	double *stage = stage_buf[wv];
+	typedef __attribute__((address_space(3))) void lvoid;
+	const int MS = geo5_mstride(W);
+	const char *gm5 = (const char *)(geo5 + geo5_plane_doubles(W, H));
+
+	// the tile of index tl into buffer `buf`: piece p (1 KB of the tile's LDS image) by wave p % 4
+	auto request = [&](int tl, int buf) {
+		const int tg = tl / tiles_per_row, xa = (tl % tiles_per_row)*GW_TW, ya = y0 + tg*GD_ROWS;
+		const char *org = (const char *)geo5 + ((size_t)(ya - R + GD_PADT)*GS + (size_t)(xa - R + GD_PADL))*8;
+#pragma unroll
+		for (int p = wv; p < NPC; p += GD_ROWS) {
+			const int o = p*1024 + i*16;
+			if (o < TILE_BYTES) {
+				const int plane = o / (PL*8), rem = o - plane*(PL*8), row = rem / (TWD*8), colb = rem - row*(TWD*8);
+				// (as an assembler statement: the builtin tells the compiler that LDS is being written behind its back, and it
+				// then parks the wave at a vmcnt(0) before the first LDS read that might alias -- the sweeps' volatile reads of
+				// the OTHER buffer, a few instructions after the request; the waits this kernel needs are written out below)
+				const char *src = org + ((size_t)plane*GPL + (size_t)row*GS)*8 + colb;
+				const unsigned dst = (unsigned)(size_t)(lvoid *)((char *)&tile[buf][0][0][0] + p*1024);
+				asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "m0", "memory");
+			}
+		}
+		// the wave's own row of mask bytes (no register is loaded for the next tile: a loaded register is a value the compiler
+		// may move -- behind a wait of its own -- long before this kernel's wait)
+		if (i < GW_TW/4) {
+			const char *src = gm5 + (size_t)(ya + wv)*MS + xa + 4*i;
+			const unsigned dst = (unsigned)(size_t)(lvoid *)&mtile[buf][wv][0];
+			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "m0", "memory");
+		}
+	};
+	int tl = blockIdx.x;
+	if (tl >= total_tiles) return;
+	request(tl, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the first tile: the one round trip nothing hides
+	const SharedDivisor sg = shared_divisor(P.geodesic_sigma);
+	const bool sdiv = sg.ok && P.geodesic_sigma > 0 && P.geodesic_init > 0x1p-300 && P.geodesic_init < 0x1p300 && P.geodesic_init < 0x1p30*P.geodesic_sigma;
+#pragma unroll 1
+	for (int kt = 0; tl < total_tiles; ++kt, tl += gridDim.x) {
+		const int buf = kt & 1;
+		const int tgrp = tl / tiles_per_row, x0 = (tl % tiles_per_row)*GW_TW;
+		const int trow = tgrp*GD_ROWS + wv;
+		const bool rowok = trow < nrows;
+		const int cx = x0 + i;
+		// this tile has landed (every wave waited for its own requests before it came here: after the sweeps of the tile before;
+		// the barrier collects them), and everybody has left the tile of the round before: its buffer is free for the tile after
+		// this one
+		__syncthreads();
+		const bool active = rowok && cx < W && ((const volatile __attribute__((address_space(3))) uint8_t *)&mtile[buf][wv][0])[i] == 1;   // (the wave's own request)
+		if (tl + (int)gridDim.x < total_tiles) request(tl + gridDim.x, buf ^ 1);
+		const unsigned long long amask = __ballot(active);
+		// (a wave without a masked-in pixel in its row has nothing to compute or store; it still takes its share of the requests)
+		if (amask == 0ull) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }
+
+		double w[WS][WS];
+#pragma unroll
+		for (int a = 0; a < WS; ++a)
+#pragma unroll
+			for (int b = 0; b < WS; ++b) w[a][b] = P.geodesic_init;
+		w[R][R] = 0.0;
+		geodesic_sweeps<R, TWD, TH>(w, (GeoLds)&tile[buf][0][wv][i], P.geodesic_iters);
+		// the next tile has been on its way for the length of the sweeps: the wait is free HERE -- at the
+		// loop's top it would also sit out this tile's own window stores
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+		// exponential weighting, rows out (see geodesic_reg_kernel)
+		{
+			double *wt = wbuf + wimg_offset(W, R, rowok ? trow : 0, x0);
+			constexpr size_t TILE_D = (size_t)SRH_WTILE*WS*WP;
+			constexpr int NPIECE = GW_TW*WP/2, NK = (NPIECE + GW_TW - 1)/GW_TW;
+			bool st[NK];
+			unsigned goff[NK];
+#pragma unroll
+			for (int k = 0; k < NK; ++k) {
+				const int q = i + k*GW_TW;
+				const int pix = (2*q)/WP;
+				const int half = pix/SRH_WTILE;
+				st[k] = q < NPIECE && ((amask >> pix) & 1ull);
+				goff[k] = (unsigned)(half*(int)TILE_D + (2*q - half*SRH_WTILE*WP));
+			}
+#pragma unroll
+			for (int a = 0; a < WS; ++a) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				geo_exp_row<WS>(w[a], sg, sdiv, P.geodesic_sigma);
+#pragma unroll
+				for (int b = 0; b + 1 < WS; b += 2) {
+					double2 v; v.x = w[a][b]; v.y = w[a][b + 1];
+					*reinterpret_cast<double2 *>(stage + i*WP + b) = v;
+				}
+				stage[i*WP + WS - 1] = w[a][WS - 1];
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				double2 v[NK];
+#pragma unroll
+				for (int k = 0; k < NK; ++k) v[k] = *reinterpret_cast<const double2 *>(stage + 2*((i + k*GW_TW) < NPIECE ? (i + k*GW_TW) : 0));
+#pragma unroll
+				for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+				double *wrow = wt + (size_t)a*(SRH_WTILE*WP);
+#pragma unroll
+				for (int k = 0; k < NK; ++k)
+					if (st[k]) { typedef double d2v __attribute__((ext_vector_type(2))); d2v t; t.x = v[k].x; t.y = v[k].y; __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(wrow + goff[k])); }
+			}
+		}
+		if (pconst && active) {
+			constexpr int NT = WS*WS, KG = GEO_AHEAD < NT ? GEO_AHEAD : NT;
+			const GeoLds tg = (GeoLds)&tile[buf][4][wv][i];
+			double g[KG];
+			double mL = 0, tw = 0, wmin = __builtin_inf();
+			geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
+			geo_pc1<R, TWD, KG>(w, tg, g, mL, tw, wmin, std::make_integer_sequence<int, NT + 2>{});
+			bool all = mL == mL && wmin > P.weight_cutoff;
+			double s2 = 0;
+			if (all && !(tw < 1e-10)) {
+				mL /= tw;
+				geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
+				geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, std::make_integer_sequence<int, NT + 3>{});
+			} else all = false;
+			double *pc = pconst + ((size_t)trow*W + cx)*4;
+			pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+		}
+	}
+}
+
+// windows of rows [y0, y0 + nrows) in the strip kernel's layout from the padded planes `geo5` (launch_geo5_planes)
+bool launch_geodesic_dma(hipStream_t st, const ViewDev *views, int ref, int width, const double *geo5, const srh_params &P,
+                         int y0, int nrows, double *wbuf, double *pconst, int num_cus)
+{
+	if (P.window_radius != GD_PADL) return false;
+	const int tiles = (width + GW_TW - 1)/GW_TW, total = tiles*((nrows + GD_ROWS - 1)/GD_ROWS);
+	const int grid = total < num_cus ? total : num_cus;
+	hipLaunchKernelGGL((geodesic_dma_kernel<GD_PADL>), dim3((unsigned)grid), dim3(GW_TW*GD_ROWS), 0, st, views, ref, geo5, P, y0, nrows, wbuf, pconst);
+	return true;
+}
+
 // ------------------------------------------------------------------ AdaptiveWeight windows (adaptiveweight.cpp:33-79)
 // One thread per pixel, one wave = 64 consecutive pixels of a row; the colour tile and the tap plane of the wave in
 // LDS; weights leave tile-major (wb[tap*32 + pixel]: 256-byte segments per wave store), the per-pixel constants of

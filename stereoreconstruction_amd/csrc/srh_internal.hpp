@@ -190,6 +190,11 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 
 // Dense (row-aligned) TwoView path, srh_dense.hip
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
+// the dense TwoView path's windows kernel with its tiles by LDS-DMA (r = 5; srh_dense.hip): the padded planes it reads
+size_t geo5_doubles(int w, int h);
+void launch_geo5_planes(hipStream_t st, const double *edges, const double *gray_tv, const uint8_t *mask, int w, int h, double *out);
+bool launch_geodesic_dma(hipStream_t st, const ViewDev *views, int ref, int width, const double *geo5, const srh_params &P,
+                         int y0, int nrows, double *wbuf, double *pconst, int num_cus);
 bool launch_geodesic_reg(hipStream_t st, const ViewDev *views, int ref, int width, const double *edges,
                          const srh_params &P, int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr,
                          bool wimg = false);
