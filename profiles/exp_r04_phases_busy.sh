@@ -10,7 +10,8 @@ for a in certified exact; do
 	SRH_LIBRARY=$PROF timeout -k 10 180 python3 bench.py --workload c4 --steps 1 --warmup 0 --cpu-rows 0 --no-configs --arith $a 2>&1 >/dev/null < /dev/null \
 		| grep "staged MVS cost" | sort | uniq -c | sort -rn | head -4 | sed "s/^/arith $a: /"
 done > "$OUT/c4_staged_phases.txt"
-SRH_LIBRARY=$PROF timeout -k 10 180 python3 bench.py --workload c3 --steps 1 --warmup 0 --cpu-rows 0 --no-configs --no-exact-check 2>&1 >/dev/null < /dev/null \
+# (SRH_BENCH_GEODMA=0: the register-staged windows kernel, the one with the stamps; the default since round 5 is geodesic_dma_kernel)
+SRH_BENCH_GEODMA=0 SRH_LIBRARY=$PROF timeout -k 10 180 python3 bench.py --workload c3 --steps 1 --warmup 0 --cpu-rows 0 --no-configs --no-exact-check 2>&1 >/dev/null < /dev/null \
 	| grep "geodesic kernel" | tail -1 > "$OUT/c3_geodesic_phases.txt"
 : > "$OUT/gpu_busy.txt"
 for spec in "c2 twoview_cross_check 8 10" "c3 twoview_cross_check 8 10" "c4 mvs_cross_check 16 24"; do
