@@ -474,13 +474,22 @@ void twoview_strip_cost_kernel(const StripArgs A)
 				if (x0 + pi >= W) { lo = 0; hi = -1; }
 				if (hi >= lo) hi = dense_cover_hi(lo, hi, NCB, G, PAD);
 				int mn = hi >= lo ? lo : 2147483647, mx = hi >= lo ? hi : -2147483647;
+				// (within each row of 16 lanes by DPP rotations -- four steps, no LDS; the two rows by lane reads.  As five
+				// butterfly steps of ds_bpermute each reduction was five dependent LDS round trips)
+#define ST_ROR(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x120 + (n), 0xf, 0xf, false)
 #pragma unroll
-				for (int d = 1; d < 32; d <<= 1) {
-					const int on = __shfl_xor(mn, d), ox = __shfl_xor(mx, d);
+				for (int d = 8; d >= 1; d >>= 1) {
+					const int on = d == 8 ? ST_ROR(mn, 8) : d == 4 ? ST_ROR(mn, 4) : d == 2 ? ST_ROR(mn, 2) : ST_ROR(mn, 1);
+					const int ox = d == 8 ? ST_ROR(mx, 8) : d == 4 ? ST_ROR(mx, 4) : d == 2 ? ST_ROR(mx, 2) : ST_ROR(mx, 1);
 					mn = on < mn ? on : mn; mx = ox > mx ? ox : mx;
 				}
-				cmin_raw = __builtin_amdgcn_readfirstlane(mn);
-				cmax = __builtin_amdgcn_readfirstlane(mx);
+#undef ST_ROR
+				{
+					const int m0 = __builtin_amdgcn_readlane(mn, 0), m1 = __builtin_amdgcn_readlane(mn, 16);
+					const int x0_ = __builtin_amdgcn_readlane(mx, 0), x1_ = __builtin_amdgcn_readlane(mx, 16);
+					cmin_raw = m0 < m1 ? m0 : m1;
+					cmax = x0_ > x1_ ? x0_ : x1_;
+				}
 				cmin = cmin_raw & ~1;
 			}
 			const bool any = cmin_raw <= cmax;
