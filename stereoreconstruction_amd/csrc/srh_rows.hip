@@ -456,11 +456,14 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			// blocked select form, any validity pattern (image border, masked taps, cut-off weights):
 			// the same sums with every tap guarded; a skipped tap adds +0.0
 			const int gx0 = c0 - R;
+			// (window rows that lie on rows 0 .. H - 2 of the reference image: on the others every tap of the reference side is
+			// unusable -- gray_tv is NaN on the last row as outside -- and every term a zero: left out, as in the strip kernel)
+			const int gra = y < R ? R - y : 0, grb = y + R > H - 2 ? WS - (y + R - (H - 2)) : WS;
 			double mLs[RC_NCB], mRs[RC_NCB], tws[RC_NCB];
 #pragma unroll
 			for (int j = 0; j < RC_NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
 #pragma unroll 1
-			for (int row = 0; row < WS; ++row) {
+			for (int row = gra; row < grb; ++row) {
 				const int gy = cy - R + row;
 				const bool rowok = gy >= 0 && gy < OH;
 				const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;
@@ -495,7 +498,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll
 			for (int j = 0; j < RC_NCB; ++j) { s1[j] = 0.0; s2v[j] = 0.0; s3[j] = 0.0; }
 #pragma unroll 1
-			for (int row = 0; row < WS; ++row) {
+			for (int row = gra; row < grb; ++row) {
 				const int gy = cy - R + row;
 				const bool rowok = gy >= 0 && gy < OH;
 				const double *rp = Rv.gray_tv + (size_t)(rowok ? gy : 0)*OW;

@@ -238,8 +238,13 @@ __device__ __noinline__ double strip_cost_general(const StripSmem<R, NBUF> &S, i
 // (the per-candidate form reads 3 LDS values per tap and candidate).  Candidates whose bit is set in `store` are written.
 template <int R, int NBUF>
 __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int wb, int s0, int pi, int rc, unsigned store,
-                                                double *__restrict__ dst, double weight_cutoff, double bad_ret, double max_color_diff)
+                                                double *__restrict__ dst, double weight_cutoff, double bad_ret, double max_color_diff,
+                                                int ra, int rb)
 {
+	// [ra, rb): the window rows that lie on rows of the reference image with valid tap values at all (rows 0 .. H - 2: the last
+	// row's gray_tv is NaN like everything outside).  On the other window rows every tap of the reference side is unusable and
+	// every term below a zero: they are left out -- a third of this routine's work on the image's first and last rows, whose
+	// every candidate comes here.
 	typedef StripSmem<R, NBUF> Smem;
 	constexpr int WS = Smem::WS, NS = Smem::NS, NCB = ST_NCB, NR = NCB + 2*R;
 	// "A skipped tap adds +0.0 to every sum" WITHOUT a select per tap and candidate (six v_cndmask_b32 and a compare for each of
@@ -251,7 +256,7 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 #pragma unroll
 	for (int j = 0; j < NCB; ++j) { mLs[j] = 0.0; mRs[j] = 0.0; tws[j] = 0.0; }
 #pragma unroll 1
-	for (int row = 0; row < WS; ++row) {
+	for (int row = ra; row < rb; ++row) {
 		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
 		double rr[NR], rv[NR];
 		const double2 *rp = reinterpret_cast<const double2 *>((NBUF == 2 && (rc & 1)) ? &S.rto[sl][rc - 1] : &S.rt[sl][rc]);
@@ -278,7 +283,7 @@ __device__ __noinline__ void strip_select_block(const StripSmem<R, NBUF> &S, int
 #pragma unroll
 	for (int j = 0; j < NCB; ++j) { s1[j] = 0.0; s2v[j] = 0.0; s3[j] = 0.0; }
 #pragma unroll 1
-	for (int row = 0; row < WS; ++row) {
+	for (int row = ra; row < rb; ++row) {
 		const int sl = s0 + row >= NS ? s0 + row - NS : s0 + row;
 		double rr[NR], rv[NR];
 		const double2 *rp = reinterpret_cast<const double2 *>((NBUF == 2 && (rc & 1)) ? &S.rto[sl][rc - 1] : &S.rt[sl][rc]);
@@ -853,7 +858,8 @@ void twoview_strip_cost_kernel(const StripArgs A)
 					}
 					strip_select_block<R, NBUF>(CS, wcur, s0, pi, c0 - cs, store,
 					                            A.cost + (tile*(size_t)A.cstride)*ST_TP + (ptrdiff_t)(c0 - pq.lo)*ST_TP + pi,
-					                            A.weight_cutoff, A.bad_ret, A.max_color_diff);
+					                            A.weight_cutoff, A.bad_ret, A.max_color_diff,
+					                            y < R ? R - y : 0, y + R > A.H - 2 ? WS - (y + R - (A.H - 2)) : WS);
 				}
 				ST_STAMP(6);                           // phase 2: blocked select form
 				for (int q = tid; q < nsingle; q += NT) {
