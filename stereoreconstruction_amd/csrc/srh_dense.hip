@@ -470,7 +470,7 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			GEO_STAMP(6)
 		} else all = false;
 		double *pc = pconst + ((size_t)trow*W + cx)*4;
-		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
 	}
 #ifdef SRH_PROFILE_PHASES
 	GEO_STAMP(3)
@@ -670,7 +670,7 @@ void geodesic_dma_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 				geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, std::make_integer_sequence<int, NT + 3>{});
 			} else all = false;
 			double *pc = pconst + ((size_t)trow*W + cx)*4;
-			pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+			pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
 		}
 	}
 }
@@ -769,7 +769,7 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 			}
 		} else all = false;
 		double *pc = pconst + ((size_t)trow*W + cx)*4;
-		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
 	}
 }
 
@@ -1079,7 +1079,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			mL = pc_[0]; tw = pc_[1]; s2 = pc_[2];
 			all = pc_[3] != 0.0;
 		}
-		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;
+		S.meanL[i] = mL; S.totalW[i] = (ONEPASS && all) ? pc_[3] : tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;   // (one-pass form: 1/totalWeight, pconst slot 3)
 		if (!all && x < W && e.xmax >= e.xmin) s_need_pix = 1;      // this pixel needs the general form
 	}
 	SRH_STAMP(2);
@@ -1162,7 +1162,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #endif
 				if (fast && ONEPASS) {
 					// certified one-pass form (twoview_strip_cost_kernel): P = sum w r, Q = sum ((w l - meanL) w) r, U = sum w^2 r^2
-					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
+					const double mL = CS.meanL[i], itw = CS.totalW[i], s2 = CS.sum2[i];   // (this form keeps 1/totalWeight there)
 					const double sig3 = cb.sigma3(s2);
 					double r[NR], q[NR], wv[WS], lv[WS], P_[DC_NCB], Q_[DC_NCB], U_[DC_NCB], SA = 0.0;
 					{
@@ -1217,12 +1217,8 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 					for (int j = 0; j < DC_NCB; ++j) {
 						const int c = c0 + j;
 						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
-							const double m = P_[j]/tw, p2 = P_[j] + P_[j];
-							const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U_[j]);    // U - m*(2P - T*m)
-							const double s1 = __builtin_fma(-m, SA, Q_[j]);
-							const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
-							const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
-							const bool okc = s3 >= sig3 && s3*cb.zmax2 >= q3;
+							bool okc;
+							const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, cb.zmax2, okc);
 							crow[(size_t)(c - e.xmin)*DC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
 						}
 						__builtin_amdgcn_sched_barrier(0);

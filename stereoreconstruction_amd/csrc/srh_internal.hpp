@@ -89,6 +89,13 @@ struct PixRange { int32_t lo, hi; };
 //     255*1.01*(3*gamma_(T+4)*z + 2.002*gamma_(T+3)*z^2) + 1300u
 // of the real-number cost, the reference's arithmetic within half of k1/B + k2/A + k3: a candidate is
 // certified when sum3 >= sigma3(sum2) (the latter <= e0/2) and Q3 <= zmax2*sum3 (the former <= e0/2).
+// Round 6: the FINISH is free of IEEE divisions and of the IEEE square root as well (onepass_finish below: they were 77 of the
+// ~93 instructions a candidate's finish took, a sixth of a block).  m = P*itw with itw = fl(1/tw) from the weights kernels
+// (one more rounding on m: every gamma index of the derivation goes up by one; the code takes gamma_(T+6) for both terms),
+// 1/sqrt(sum2*sum3) by v_rsq_f64 and ONE third-order Newton step whose own residual e = 1 - x*y0^2 is part of the
+// certificate (|e| <= 2^-20, whatever the seed's accuracy: y1 = y0*(1 + e/2 + 3e^2/8) is then within 2u of 1/sqrt(x)), and
+// v = fma(-255, |sum1|*y1, 255): x, the product and the last fma round once each, so the finish's share of the bound is
+// 255*1.001*(0.5u + 2u + u) + 255u < 1150u; the constant stays at 2600u.
 struct CertBound {
 	double e0, m_hi, k1, k2, room;
 	double zmax2;
@@ -108,6 +115,25 @@ __host__ __device__ inline bool cert_sure(double x, double clamp, double m_hi) {
 __host__ __device__ inline bool cert_pixel_exact(const CertBound &cb, double sum2, double all_taps_usable) {
 	return !(all_taps_usable != 0.0) || !(cb.sigma3(sum2) < __builtin_inf());
 }
+// The finish of a one-pass candidate (strip, per-tile and row-run cost kernels): the sums recovered from P, Q, U, the cost
+// without an IEEE division or square root, and the certificate.  itw = fl(1/totalWeight) (pconst slot 3), TT = T.
+// A non-positive or NaN sum3 gives a NaN residual and fails the certificate; an uncertified value is never used.
+#ifdef __HIPCC__
+__device__ __forceinline__ double onepass_finish(double P, double Q, double U, double SA, double itw, double s2, double TT,
+                                                 double sig3, double zmax2, bool &okc)
+{
+	const double m = P*itw, p2 = P + P;
+	const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U);    // U - m*(2P - T*m)
+	const double s1 = __builtin_fma(-m, SA, Q);
+	const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U);      // U + m*(2P + T*m)
+	const double x = s2*s3;
+	const double y0 = __builtin_amdgcn_rsq(x);                            // v_rsq_f64: a seed, trusted for nothing
+	const double e = __builtin_fma(-(x*y0), y0, 1.0);                     // 1 - x*y0^2
+	const double y1 = __builtin_fma(y0*e, __builtin_fma(0.375, e, 0.5), y0);
+	okc = s3 >= sig3 && s3*zmax2 >= q3 && __builtin_fabs(e) <= 0x1p-20;
+	return __builtin_fma(-255.0, __builtin_fabs(s1)*y1, 255.0);
+}
+#endif
 // mvs: the free cost_ncc of MultiViewStereo (multiviewstereo.cpp:113-189): the score sum1/sqrt(sum2*sum3) itself (no factor
 // 255, no clamp), 25 taps at the reference's radius; e0 = 2^-36 there (scores live in [-1, 1])
 inline CertBound cert_bound(const srh_params &P, bool mvs = false) {
@@ -123,8 +149,8 @@ inline CertBound cert_bound(const srh_params &P, bool mvs = false) {
 	const double k3 = 2*scale*1.01*2*gamma(T) + (mvs ? 40 : 2600)*u;
 	c.room = c.e0 - k3;
 	c.m_hi = P.max_color_diff + c.e0;
-	{	// one-pass form: 255*1.01*g*(3z + 2.002 z^2) + 1300u = e0/2
-		const double g = gamma(T + 4), rhs = (c.e0/2 - 1300*u)/(scale*1.01*g);
+	{	// one-pass form: 255*1.01*g*(3z + 2.002 z^2) + 2600u = e0/2  (g = gamma_(T+6): the finish multiplies by fl(1/tw))
+		const double g = gamma(T + 6), rhs = (c.e0/2 - 2600*u)/(scale*1.01*g);
 		const double z = rhs > 0 ? (-3.0 + sqrt(9.0 + 4*2.002*rhs))/(2*2.002) : 0.0;
 		c.zmax2 = z*z*(1.0 - 0x1p-20);
 	}
@@ -174,7 +200,7 @@ struct Extent { int32_t xmin, xmax; };
 void launch_prep_view(hipStream_t st, const uint32_t *rgba, const uint8_t *mask, int w, int h,
                       double *gray, double *gray_tv);
 void launch_fill(hipStream_t st, double *p, size_t n, double v);
-// pconst (optional): 4 doubles per pixel of the band -- meanL, totalWeight, sum2, all-taps-usable -- the per-pixel
+// pconst (optional): 4 doubles per pixel of the band -- meanL, totalWeight, sum2, all-taps-usable (0, or 1/totalWeight) -- the per-pixel
 // constants of the dense cost kernel's fast form, computed while the window is at hand
 void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
                     int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr, bool wimg = false);

@@ -165,7 +165,7 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 				}
 		} else all = false;
 		double *pc = pconst + ((size_t)(q / W)*W + cx)*4;
-		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0 : 0.0;
+		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
 	}
 #undef WTAP
 }

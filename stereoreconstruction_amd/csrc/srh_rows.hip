@@ -421,7 +421,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					if (ONEPASS) sA += __builtin_fma(S.w[i][row*WP + col], S.lt[row][i + col], -mL);
 				}
 		} else all = false;
-		S.meanL[i] = mL; S.totalW[i] = tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0; S.sumA[i] = sA;
+		S.meanL[i] = mL; S.totalW[i] = (ONEPASS && all) ? 1.0/tw : tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0; S.sumA[i] = sA;   // (one-pass form: fl(1/totalWeight), onepass_finish)
 		const int nr = S.meta[i] >> 16;
 		int nblk = 0;
 		for (int r = 0; r < nr; ++r) {
@@ -632,12 +632,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
 						if (j >= sh) {
-							const double m = P_[j]/tw, p2 = P_[j] + P_[j];
-							const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U_[j]);    // U - m*(2P - T*m)
-							const double s1 = __builtin_fma(-m, SA, Q_[j]);
-							const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
-							const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
-							const bool okc = s3 >= sig3 && s3*cb.zmax2 >= q3;
+							bool okc;
+							const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, tw, s2, TT, sig3, cb.zmax2, okc);   // (tw: 1/totalWeight in this form)
 							dst[(j - sh)*RC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
 						}
 					}

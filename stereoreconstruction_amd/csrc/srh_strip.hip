@@ -711,7 +711,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 					if (fast && ONEPASS && !pix_exact) {
 						// ---- certified ONE-PASS form (srh_internal.hpp, CertBound): P = sum w r, Q = sum ((w l - meanL) w) r,
 						// U = sum w^2 r^2 in one sweep over the window; registers are refilled in place a row ahead, as below
-						const double mL = CS.pc[cur][i][0], tw = CS.pc[cur][i][1], s2 = CS.pc[cur][i][2];
+						const double mL = CS.pc[cur][i][0], itw = CS.pc[cur][i][3], s2 = CS.pc[cur][i][2];   // (slot 3 of a pixel with every tap usable: 1/totalWeight)
 						double r_[NR], q_[NR], w_[WS], l_[WS], P_[NCB], Q_[NCB], U_[NCB], SA = 0.0;
 						{
 							const double2 *rp = reinterpret_cast<const double2 *>(rbase + s0*RW + rc);
@@ -769,12 +769,8 @@ void twoview_strip_cost_kernel(const StripArgs A)
 						for (int j = 0; j < NCB; ++j) {
 							const int c = c0 + j;
 							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
-								const double m = P_[j]/tw, p2 = P_[j] + P_[j];
-								const double s3 = __builtin_fma(-m, __builtin_fma(-TT, m, p2), U_[j]);    // U - m*(2P - T*m)
-								const double s1 = __builtin_fma(-m, SA, Q_[j]);
-								const double q3 = __builtin_fma(m, __builtin_fma(TT, m, p2), U_[j]);      // U + m*(2P + T*m)
-								const double v = 255*(1.0 - fabs(s1) / sqrt(s2 * s3));
-								const bool okc = s3 >= sig3 && s3*A.cb.zmax2 >= q3;
+								bool okc;
+								const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, A.cb.zmax2, okc);
 								if (!okc && A.redo) bad_blk = true;
 								crow[(size_t)(c - e_min)*ST_TP] = !okc ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
 							}
