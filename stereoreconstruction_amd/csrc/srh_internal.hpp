@@ -130,7 +130,8 @@ __device__ __forceinline__ double onepass_finish(double P, double Q, double U, d
 	const double y0 = __builtin_amdgcn_rsq(x);                            // v_rsq_f64: a seed, trusted for nothing
 	const double e = __builtin_fma(-(x*y0), y0, 1.0);                     // 1 - x*y0^2
 	const double y1 = __builtin_fma(y0*e, __builtin_fma(0.375, e, 0.5), y0);
-	okc = s3 >= sig3 && s3*zmax2 >= q3 && __builtin_fabs(e) <= 0x1p-20;
+	const bool c1 = s3 >= sig3, c2 = s3*zmax2 >= q3, c3 = __builtin_fabs(e) <= 0x1p-20;
+	okc = c1 & c2 & c3;                                                   // (no short circuit: three compares, no branch)
 	return __builtin_fma(-255.0, __builtin_fabs(s1)*y1, 255.0);
 }
 #endif

@@ -574,12 +574,15 @@ void twoview_strip_cost_kernel(const StripArgs A)
 					const int rc = c0 - cs;                 // tile column of the window's left edge
 					// 16-byte reads need an even index: an odd edge reads the copy shifted by one column
 					const double *rbase = (!PAD && (rc & 1)) ? &CS.rto[0][0] - 1 : &CS.rt[0][0];
-					bool fast = false;
+					// bit j: candidate c0 + j is inside the pixel's range and its window in the other view is fully usable
+					unsigned vm = 0;
 #pragma unroll
 					for (int j = 0; j < NCB; ++j) {
 						const int c = c0 + j;
-						if (c >= lo && c <= hi && rfull[rc + j] != 0) { fast = true; ++n_dev; }
+						vm |= (c >= lo && c <= hi && rfull[rc + j] != 0) ? 1u << j : 0u;
 					}
+					const bool fast = vm != 0;
+					n_dev += __builtin_popcount(vm);
 					// certified forms: a candidate the bound does not cover is NOT left to the scan (which would flag the whole pixel
 					// for the per-pixel redo): its block is evaluated once more, here and now, in the reference's arithmetic, while the
 					// window and the rows are in LDS.  And a pixel whose own window leaves the bound no room at all (sigma3 = +inf: a
@@ -765,16 +768,17 @@ void twoview_strip_cost_kernel(const StripArgs A)
 							prog_yield(seen);
 						}
 						constexpr double TT = (double)(WS*WS);
+						// every candidate of the block is finished (arithmetic on a column outside the range harms nobody); only the
+						// store looks at the candidate's bit -- no LDS read, wait and branch per candidate
+						const double zmax2 = A.cb.zmax2, mhi = A.cb.m_hi, mcd = A.max_color_diff;
+						const bool redo = A.redo != 0;
 #pragma unroll
 						for (int j = 0; j < NCB; ++j) {
-							const int c = c0 + j;
-							if (c >= lo && c <= hi && rfull[rc + j] != 0) {
-								bool okc;
-								const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, A.cb.zmax2, okc);
-								if (!okc && A.redo) bad_blk = true;
-								crow[(size_t)(c - e_min)*ST_TP] = !okc ? __builtin_nan("") : (v > A.cb.m_hi ? A.max_color_diff : v);
-							}
-							__builtin_amdgcn_sched_barrier(0);
+							bool okc;
+							const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, zmax2, okc);
+							const bool st = (vm >> j) & 1u;
+							bad_blk |= st & !okc & redo;
+							if (st) crow[(size_t)(c0 + j - e_min)*ST_TP] = !okc ? __builtin_nan("") : (v > mhi ? mcd : v);
 						}
 					} else if (fast && !ONEPASS && !pix_exact) two_sweeps(std::integral_constant<bool, FMA>(), std::integral_constant<bool, CERT>());
 					if (fast && CERT && (pix_exact || bad_blk)) two_sweeps(std::false_type(), std::false_type());   // (bad_blk is only raised when A.redo)
