@@ -1151,12 +1151,14 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			for (int b = g; b < (CS.lall[i] ? nblocks : 0); b += DC_G) {
 				const int c0 = lo_e + b*DC_NCB;
 				const int rc = c0 - cs;                 // tile column of the window's left edge (even)
-				bool fast = false;
+				unsigned vm = 0;                        // bit j: candidate c0 + j in the pixel's range, its window in the other view fully usable
 #pragma unroll
 				for (int j = 0; j < DC_NCB; ++j) {
 					const int c = c0 + j;
-					if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) { fast = true; ++n_dev; }
+					vm |= (c >= lo && c <= hi && CS.rfull[rc + j] != 0) ? 1u << j : 0u;
 				}
+				const bool fast = vm != 0;
+				n_dev += __builtin_popcount(vm);
 #ifdef SRH_PROFILE_PHASES
 				const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
@@ -1215,13 +1217,9 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 					constexpr double TT = (double)T;
 #pragma unroll
 					for (int j = 0; j < DC_NCB; ++j) {
-						const int c = c0 + j;
-						if (c >= lo && c <= hi && CS.rfull[rc + j] != 0) {
-							bool okc;
-							const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, cb.zmax2, okc);
-							crow[(size_t)(c - e.xmin)*DC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
-						}
-						__builtin_amdgcn_sched_barrier(0);
+						bool okc;                              // (every candidate finished, only the store masked: as in the strip kernel)
+						const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, cb.zmax2, okc);
+						if ((vm >> j) & 1u) crow[(size_t)(c0 + j - e.xmin)*DC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
 					}
 				} else if (fast) {
 					const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
@@ -2029,6 +2027,9 @@ bool twoview_tscan_tile(const int bid, const ViewDev *__restrict__ views, int re
 		lo = pr.lo; hi = pr.hi;
 		// the range the cost rows were made for must be the template's, clipped to the image
 		int wlo = x + smin, whi = x + smax;
+		// (truncation towards zero: a segment whose high end is column -1 ends ON column 0 in the reference -- the look-ups
+		// below move that entry there -- so a pixel whose template range ends at column -1 needs column 0's cost as well)
+		if (whi == -1) whi = 0;
 		if (wlo < 0) wlo = 0;
 		if (whi > OW - 1) whi = OW - 1;
 		if (nS > 0 && whi >= wlo) good = lo <= wlo && hi >= whi;       // (every candidate column has its cost)
@@ -2106,8 +2107,10 @@ bool twoview_tscan_tile(const int bid, const ViewDev *__restrict__ views, int re
 	}
 	if (__any(active && !good)) return false;                        // twoview_scan_kernel does this tile
 
-	// mask bytes of row y of the other view, columns [xt + smin, xt + SC_TW + smax)
-	const int mbase = xt + smin, mlen = nS > 0 ? SC_TW + (smax - smin) : 0;
+	// mask bytes of row y of the other view, columns [xt + smin, xt + SC_TW + smax] -- one more than the offsets reach: the
+	// left-border look-ups move an entry from column -1 to column 0, which for the tile's last pixel (x + smax = -1) is
+	// the byte behind its range
+	const int mbase = xt + smin, mlen = nS > 0 ? SC_TW + (smax - smin) + 1 : 0;
 	for (int k = tid; k < mlen; k += SC_TW) {
 		const int tx = mbase + k;
 		smask[k] = ((unsigned)tx < (unsigned)OW) ? Rv.mask[(size_t)y*OW + tx] : (unsigned char)0;

@@ -91,6 +91,40 @@ def test_template_scan_at_c3_size_with_a_narrow_mask(hip_ctx):
         assert s1["n_eval"] == s0["n_eval"] and s1["scan_tiles_template"] > 0 and s1["scan_tiles_walked"] == 0, (d, s1)
 
 
+def test_a_template_range_that_ends_on_column_minus_one_at_a_tile_edge(hip_ctx):
+    """d0 = 64 = the scan's tile width: the template's largest offset is -64, so for the LAST pixel of the first tile
+    x + smax = -1.  The reference truncates that end point towards zero -- the segment ends ON column 0 -- and the look-ups
+    move the entry there: its mask byte lies one past the bytes the tile's offsets reach and its cost entry outside the
+    clipped template range (the byte was never loaded, the range never checked).  The other view's column 0 is
+    masked out on every second row so that the byte matters.  Template scan == curve walk == oracle, both directions."""
+    import oracle_ffi as O
+    W, H, D, d0 = 200, 36, 24, 64
+    L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, 0x5EED0A64, d0=d0)
+    mr = mr.copy(); mr[::2, 0] = 0
+    (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
+    zmin, zmax = synthetic.rectified_depth_range(W, D, d0=d0)
+    case = dict(name="d0_64", kind="twoview", gt_disparity=None,
+                views=[(L, ml, (Kl, Rl, tl), None, None), (R, mr, (Kr, Rr, tr), None, None)],
+                params=dict(min_depth=zmin, max_depth=zmax, num_depth_levels=D, window_radius=5, weight_kind=1, image_scale=1.0))
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    # the situation the test is about exists: the curve of pixel x = 63 ends on column 0 of the other view
+    pts = O.epipolar_curve(ocams[0], ocams[1], imgs[1], op, False, 63, 11)      # (row 11: column 0 of the other view is white there)
+    assert len(pts) and int(pts[:, 0].max()) == 0 and int(pts[:, 0].min()) == 0, pts[-4:]
+    assert int(O.epipolar_curve(ocams[0], ocams[1], imgs[1], op, False, 64, 11)[:, 0].max()) == 0
+    want = [O.twoview_wta(imgs[0], imgs[1], ocams[0], ocams[1], op), O.twoview_wta(imgs[1], imgs[0], ocams[1], ocams[0], op)]
+    for arith in (capi.ARITH_CERTIFIED, capi.ARITH_EXACT):
+        out = _both(hip_ctx, p, arith)
+        for d in range(2):
+            (m1, s1), (m0, s0) = out[1][d], out[0][d]
+            assert s1["used_dense_path"] and s1["scan_tiles_template"] > 0, (d, s1)
+            assert np.array_equal(m1.view(np.uint64), m0.view(np.uint64)), (arith, d)
+            assert s1["n_eval"] == s0["n_eval"], (arith, d, s1["n_eval"], s0["n_eval"])
+            ok, msg, _ = cases.compare_depth(m1, want[d], 1e-9)
+            assert ok, (arith, d, msg)
+
+
 def test_negative_margin_walks_every_visit(hip_ctx):
     """With wta_margin < 0 a revisited winner beats itself (cost + margin < cost) and moves secondBest: the first-visit
     sequence would be wrong there, so the template scan walks every visit -- against the oracle and the curve walk."""
