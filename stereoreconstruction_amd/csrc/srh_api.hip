@@ -121,6 +121,7 @@ struct srh_context {
 	int32_t *lcount = nullptr; size_t lcount_cap = 0;   // candidate-list path: candidates per pixel
 	uint32_t *lcand = nullptr; size_t lcand_cap = 0;    //   candidate pixels (cx | cy<<16)
 	bool force_walk = false;                            // option "force_generic" = 2: never use the list path either
+	int list_count_pass = 0;                            // option "list_count_pass": size a pair's first lists by a counting pass (round 5) instead of the host's guess
 	int list_cmax_hint = 0;                             // longest candidate list seen so far (list-path capacity)
 	int list_smax_hint = 0;                             // most cost slots a pixel needed so far (run-blocked lists)
 	int mvs_cmax_hint = 0;                              // longest MultiViewStereo candidate list seen so far
@@ -146,6 +147,7 @@ struct srh_context {
 	size_t budget_cap = 0;                              // 0 = none; set by with_thinner_bands after an out-of-memory run
 	size_t budget_used = 0;                             // what band_budget() returned last
 	size_t mem_limit = 0;                               // option "mem_limit_mb": pretend the device has only this much free (tests)
+	int debug_trace = 0;                                // option "debug_trace": the list path's capacity decisions on stderr (diagnostics)
 	size_t alloc_limit = 0;                             // option "debug_alloc_limit_mb": band buffers above this size are refused (tests)
 	const volatile int *cancel = nullptr;
 	srh_progress_fn progress = nullptr;
@@ -161,7 +163,10 @@ struct srh_context {
 	// (the plans are refuted once in a blue moon; a wait per pass leaves the GPU idle while the host launches the next one)
 	// (lists: the pass took the row-run candidate lists with the capacities learnt from earlier runs -- span = the kernels'
 	// maxima: longest list, most cost slots, a curve over too many rows -- to be compared with cmax / smax)
-	struct TvDefer { Counters *host = nullptr; int *span = nullptr; bool queued = false, strip = false, cert = false, lists = false; int cmax = 0, smax = 0; };
+	// (guessed: the capacities were the host's first guess, estimate_list_capacity -- a pass that stands then teaches the
+	// context what it measured, for reference view `ref` against `oth`)
+	struct TvDefer { Counters *host = nullptr; int *span = nullptr; bool queued = false, strip = false, cert = false, lists = false, guessed = false;
+	                 int cmax = 0, smax = 0, ref = -1, oth = -1; };
 	TvDefer tv_defer[2];
 	TvDefer *defer = nullptr;
 	// ... and runs the second pass on a stream of its own with its own band buffers (swapped into the context for its
@@ -651,6 +656,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!c || !name) return fail(SRH_E_INVALID, "null argument");
 	{ const int rc = mvs_settle_all(c); if (rc) return rc; }       // options apply to work queued from here on
 	if (!strcmp(name, "list_rows")) { c->list_rows = value != 0; return SRH_OK; }
+	if (!strcmp(name, "list_count_pass")) { c->list_count_pass = value != 0; return SRH_OK; }
 	if (!strcmp(name, "force_generic")) { c->force_generic = value != 0; c->force_walk = value == 2; return SRH_OK; }
 	if (!strcmp(name, "fused")) { c->use_fused = value != 0; return SRH_OK; }
 	if (!strcmp(name, "arith")) {
@@ -676,6 +682,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	}
 	// tests of the budget logic: pretend the device has only `value` MB to give / refuse band buffers above `value` MB
 	if (!strcmp(name, "mem_limit_mb")) { c->mem_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
+	if (!strcmp(name, "debug_trace")) { c->debug_trace = (int)value; return SRH_OK; }
 	if (!strcmp(name, "debug_alloc_limit_mb")) {
 		c->alloc_limit = g_alloc_limit = value > 0 ? (size_t)value << 20 : 0;
 		// the band buffers a bigger run left behind would serve every later request without an allocation: start afresh
@@ -1005,6 +1012,58 @@ static bool rig_is_row_aligned(const srh_camera &a, const srh_camera &b, double 
 
 static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1);
 
+// A first guess of a pair's list capacities, before any pass has measured them (the list path of srh_twoview_wta):
+// cmax = candidates per pixel, smax = cost slots per pixel (row runs in 8-column blocks).  A curve's candidates are the
+// raster points of its kept segments with the joints counted once, so at most the Chebyshev length of the polyline through
+// the kept label points + 1, and its slots at most that + 8 per image row it touches.  The host walks a coarse polyline
+// (nine labels) for a grid of reference pixels with the very camera model the kernels use (srh_geom.hpp), takes the longest,
+// and adds a margin for what nine labels do not see.  Too small a guess repeats the pass with the measured maximum.
+static void estimate_list_capacity(const srh_camera &rc, const srh_camera &oc, int W, int H, int OW, int OH,
+                                   const srh_params &p, int y0, int y1, int &cmax, int &smax, bool mvs = false)
+{
+	(void)H;
+	const int D = p.num_depth_levels, NL = D < 9 ? D : 9, GX = 13, GY = 9;   // (the grid includes the band's border rows and columns:
+	                                                                          // distortion and refraction stretch the curves most there)
+	const Vec3 normal = load3(rc.pdir);
+	long best_len = 0, best_rows = 0;
+	for (int gy = 0; gy < GY; ++gy)
+		for (int gx = 0; gx < GX; ++gx) {
+			const int x = (int)((gx*(long)(W - 1))/(GX - 1)), y = y0 + (int)((gy*(long)(y1 - y0 - 1))/(GY - 1));
+			const Ray ray = cam_unproject(rc, (x + 0.5)/p.image_scale, (y + 0.5)/p.image_scale);
+			long len = 0, rows = 0;
+			bool have = false;
+			int px = 0, py = 0;
+			for (int k = 0; k < NL; ++k) {
+				const int d = NL > 1 ? (int)(((long)k*(D - 1))/(NL - 1)) : 0;
+				Vec3 point;
+				if (!point_from_depth(ray, normal, depth_from_label(p, mvs, d), point)) continue;
+				if (!cam_project(oc, point)) continue;
+				// (clamped a little outside the other image: what lies further out is no candidate)
+				const double cxd = fmin(fmax(point.x*p.image_scale, -64.0), (double)OW + 64.0);
+				const double cyd = fmin(fmax(point.y*p.image_scale, -64.0), (double)OH + 64.0);
+				if (!(cxd == cxd) || !(cyd == cyd)) continue;
+				const int ix = (int)cxd, iy = (int)cyd;
+				if (have) {
+					const long dx = labs((long)ix - px), dy = labs((long)iy - py);
+					len += dx > dy ? dx : dy;
+					rows += dy;
+				}
+				have = true; px = ix; py = iy;
+			}
+			if (len > best_len) best_len = len;
+			if (rows > best_rows) best_rows = rows;
+		}
+	if (best_rows > SRH_ROWS_NR) best_rows = SRH_ROWS_NR;
+	// + 12 % for what nine labels do not see, + one entry per kept segment: a list holds a segment's both end points, the
+	// joint of two segments twice (the C5 rig's corner pixel: 379 distinct candidates, 157 joints, a list of 536)
+	long cm = best_len + best_len/8 + (best_len < D - 1 ? best_len : D - 1) + 40;
+	if (cm > 65520) cm = 65520;
+	cmax = (int)((cm + 7) & ~7L);
+	long sm = cmax + 8*(best_rows + 2) + 32;
+	if (sm > 65528) sm = 65528;
+	smax = (int)((sm + 7) & ~7L);
+}
+
 extern "C" int srh_twoview_wta(srh_context *c, int ref, int oth, const srh_params *p, int y0, int y1) {
 	int rc;
 	if ((rc = check_slot(c, ref, true)) || (rc = check_slot(c, oth, true)) || (rc = check_params(p))) return rc;
@@ -1113,10 +1172,14 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 			if ((rc = ensure(c->tnum, c->tnum_cap, (size_t)p->num_depth_levels))) return rc;
 			{ Scope s(c, "label_plane_table_kernel");
 			  launch_label_plane_table(c->stream, c->d_views, ref, *p, false, c->tnum); }
-			// list capacity: the longest list seen so far on this context (hint), or a counting
-			// pass the first time; a run that overflows its capacity is repeated with the true maximum
-			int cmax = c->list_cmax_hint;
-			if (cmax <= 0) {
+			// list capacity: the longest list seen so far on this context (hint); the FIRST time a guess from the geometry
+			// (estimate_list_capacity: a few dozen curves' coarse polylines projected on the host -- round 5 ran a counting pass
+			// there, twoview_count_kernel, 10 ms of a C5 pair's first call, and then sized the slots too tightly, so that the
+			// pass was repeated: 104 ms for a pair whose steady state is 61).  A run that overflows its capacity is repeated
+			// with the true maximum: the guess decides how long a pair's first call takes, never what it computes.
+			int cmax = c->list_cmax_hint, smax_guess = 0;
+			bool guessed = false;
+			if (cmax <= 0 && c->list_count_pass) {
 				HIP_TRY(hipMemsetAsync(c->d_span, 0, sizeof(int), c->stream));
 				{ Scope s(c, "twoview_count_kernel");
 				  launch_twoview_count(c->stream, c->d_views, ref, oth, W, *p, y0, y1 - y0, c->lcount, c->d_cnt, c->d_span, c->tnum); }
@@ -1124,10 +1187,13 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				HIP_TRY(hipMemcpyAsync(&maxc, c->d_span, sizeof(int), hipMemcpyDeviceToHost, c->stream));
 				HIP_TRY(hipStreamSynchronize(c->stream));
 				cmax = std::max(8, (maxc + 7) & ~7);
+			} else if (cmax <= 0) {
+				estimate_list_capacity(c->views[ref].cam, O.cam, W, H, O.w, O.h, *p, y0, y1, cmax, smax_guess);
+				guessed = true;
 			}
 			bool rows_mode = c->list_rows && W < 32768 && H < 32768;       // spans and row origins are stored as 16-bit signed
 			if (c->views[ref].list_mode[oth] == 2) rows_mode = false;      // learnt: steep curves, list order is cheaper
-			int smax = c->list_smax_hint > 0 ? c->list_smax_hint : cmax + 64;
+			int smax = c->list_smax_hint > 0 ? c->list_smax_hint : (guessed ? smax_guess : cmax + 64);
 			for (int pass = 0; pass < 6; ++pass) {
 				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 				HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
@@ -1215,15 +1281,19 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					{ Scope s(c, "twoview_list_scan_kernel");
 					  launch_twoview_list_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, c->cost, cmax); }
 				}
-				if (c->defer && attempt == 0 && pass == 0 && rows_mode && c->list_cmax_hint > 0 && c->list_smax_hint > 0 &&
-				    c->views[ref].list_mode[oth] == 1) {
-					// optimistic (srh_twoview_compute): capacities and path are those earlier runs of this pair learnt; the maxima
+				if (c->defer && attempt == 0 && pass == 0 && rows_mode &&
+				    ((c->list_cmax_hint > 0 && c->list_smax_hint > 0 && c->views[ref].list_mode[oth] == 1) ||
+				     (guessed && c->views[ref].list_mode[oth] == 0))) {
+					// optimistic (srh_twoview_compute): capacities and path are those earlier runs of this pair learnt -- or, for a
+					// pair's FIRST call, the host's guess and the row-run path --; the maxima
 					// and counters travel to pinned memory behind the kernels, the caller verifies both passes with one wait (a
 					// pass that does not stand -- a longer list after a re-upload, say -- is redone with the wait per pass)
 					HIP_TRY(hipMemcpyAsync(c->defer->host, c->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 					HIP_TRY(hipMemcpyAsync(c->defer->span, c->d_span, 4*sizeof(int), hipMemcpyDeviceToHost, c->stream));
 					c->defer->queued = true; c->defer->lists = true; c->defer->strip = false; c->defer->cert = rows_cert;
 					c->defer->cmax = cmax; c->defer->smax = smax;
+					c->defer->guessed = guessed; c->defer->ref = ref; c->defer->oth = oth;
+					if (c->debug_trace) fprintf(stderr, "[srh trace] lists %d>%d queued unverified: cmax %d smax %d guessed %d\n", ref, oth, cmax, smax, (int)guessed);
 					c->stats.used_strip_kernel = 0;
 					c->stats.used_dense_path = 0;
 					HIP_TRY(hipGetLastError());
@@ -1233,6 +1303,8 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				HIP_TRY(hipMemcpyAsync(mx, c->d_span, 4*sizeof(int), hipMemcpyDeviceToHost, c->stream));
 				HIP_TRY(hipStreamSynchronize(c->stream));
 				const int maxc = mx[0];
+				if (c->debug_trace) fprintf(stderr, "[srh trace] lists %d>%d verified pass %d: cmax %d smax %d guessed %d -> longest list %d, slots %d, rows over %d\n",
+				                            ref, oth, pass, cmax, smax, (int)guessed, mx[0], mx[1], mx[2]);
 				if (rows_mode) {
 					// a curve crossing more than SRH_ROWS_NR rows, or more slots than the 16-bit slot base
 					// holds: this pair is evaluated in list order instead
@@ -1243,8 +1315,12 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						continue;
 					}
 					if (maxc <= cmax && need <= smax) {
-						if (cmax > c->list_cmax_hint) c->list_cmax_hint = cmax;
-						if (smax > c->list_smax_hint) c->list_smax_hint = smax;
+						// what later runs of the pair are queued with: the capacities this pass stood on -- or, when they were a
+						// guess, what the pass measured (the tight strides a counting pass would have given)
+						const int cm = guessed ? std::max(8, (maxc + 7) & ~7) : cmax;
+						const int sm = guessed ? std::max(cm + 64, need) : smax;
+						if (cm > c->list_cmax_hint) c->list_cmax_hint = cm;
+						if (sm > c->list_smax_hint) c->list_smax_hint = sm;
 						// short spans (steep curves) fill their 8-column blocks badly: a slot costs ~0.4 of a
 						// candidate evaluated in list order, so beyond 2.2 slots per candidate the other path wins
 						Counters hc;
@@ -1257,10 +1333,16 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					}
 					if (maxc > cmax) { cmax = (maxc + 7) & ~7; if (need <= smax) smax = std::max(smax, cmax + 64); }
 					if (need > smax) smax = need;
+					guessed = false;                                      // (the repeat runs on measured maxima)
 					continue;
 				}
-				if (maxc <= cmax) { if (cmax > c->list_cmax_hint) c->list_cmax_hint = cmax; break; }
+				if (maxc <= cmax) {
+					const int cm = guessed ? std::max(8, (maxc + 7) & ~7) : cmax;
+					if (cm > c->list_cmax_hint) c->list_cmax_hint = cm;
+					break;
+				}
 				cmax = (maxc + 7) & ~7;                               // hint too small: repeat with the true maximum
+				guessed = false;
 			}
 			HIP_TRY(hipGetLastError());
 			break;
@@ -1499,7 +1581,7 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 	for (auto &d : c->tv_defer) {
 		if (!d.host) HIP_TRY(hipHostMalloc((void **)&d.host, sizeof(Counters)));
 		if (!d.span) HIP_TRY(hipHostMalloc((void **)&d.span, 4*sizeof(int)));
-		d.queued = false; d.lists = false;
+		d.queued = false; d.lists = false; d.guessed = false;
 	}
 	if (c->tv_overlap) {
 		srh_context::TvSlot &T = c->tv_slot;
@@ -1563,7 +1645,22 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 		if (left_out) HIP_TRY(hipMemcpyAsync(left_out, L.depth, (size_t)L.w*L.h*sizeof(double), hipMemcpyDeviceToHost, c->stream));
 		if (right_out) HIP_TRY(hipMemcpyAsync(right_out, Rv.depth, (size_t)Rv.w*Rv.h*sizeof(double), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (c->debug_trace)
+			for (srh_context::TvDefer *d : { &d0, &d1 })
+				fprintf(stderr, "[srh trace] unverified pass %d>%d: lists %d cmax %d smax %d guessed %d -> longest %d slots %d rows over %d cert_overflow %llu stands %d\n",
+				        d->ref, d->oth, (int)d->lists, d->cmax, d->smax, (int)d->guessed, d->span[0], d->span[1], d->span[2],
+				        (unsigned long long)d->host->cert_overflow, (int)tv_pass_stands(*d));
 		if (tv_pass_stands(d0) && tv_pass_stands(d1)) {
+			// a first call on guessed capacities: what the passes measured is what later calls are queued with (the tight
+			// strides a verified pass would have recorded), and how the pair's lists are best evaluated
+			for (srh_context::TvDefer *d : { &d0, &d1 })
+				if (d->lists && d->guessed) {
+					const int cm = std::max(8, (d->span[0] + 7) & ~7), sm = std::max(cm + 64, (d->span[1] + 7) & ~7);
+					if (cm > c->list_cmax_hint) c->list_cmax_hint = cm;
+					if (sm > c->list_smax_hint) c->list_smax_hint = sm;
+					c->views[d->ref].list_mode[d->oth] = (d->host->n_slots > 2.2*(double)d->host->n_listed) ? 2 : 1;
+					d->guessed = false;
+				}
 			// (every counter of srh_stats is the LAST pass's -- right -> left -- on this path as on the verified ones and in
 			// srh_get_stats, which reads the context's device counters: the second pass's were copied there above)
 			c->stats.n_pixels = (int64_t)d1.host->n_pixels;
@@ -1815,7 +1912,18 @@ static int mvs_initial_estimate_run(srh_context *c, int view, const int32_t *nei
 	// ---- default: walk kernel -> candidate lists -> cost kernel -> maximum (and merged top-K lists) over the
 	// neighbours.  Other radii stay on the one-thread-per-pixel kernels.
 	if (!c->force_generic && nneigh > 0 && p->window_radius == 2 && W < 65536 && H < 65536) {
-		int cmax = c->mvs_cmax_hint > 0 ? c->mvs_cmax_hint : ((2*p->num_depth_levels + 7) & ~7);
+		// (no hint yet: a guess from the geometry -- the longest coarse curve over the neighbours, estimate_list_capacity;
+		// round 5 started from 2 D, which on the C4 rig cut every view's lists once: its first runTask took twice a later one)
+		int cmax = c->mvs_cmax_hint;
+		if (cmax <= 0) {
+			cmax = 64;
+			for (int i = 0; i < nneigh; ++i) {
+				int cm = 0, sm = 0;
+				const ViewHost &N = c->views[neigh[i]];
+				estimate_list_capacity(c->views[view].cam, N.cam, W, H, N.w, N.h, *p, y0, y1, cm, sm, true);
+				cmax = std::max(cmax, cm);
+			}
+		}
 		if (c->mvs_async && !peaks_dev && !c->in_settle) {
 			// queue the view on the next slot and return
 			const int k = c->mvs_turn;
