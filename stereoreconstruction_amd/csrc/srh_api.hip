@@ -1035,7 +1035,7 @@ static void estimate_list_capacity(const srh_camera &rc, const srh_camera &oc, i
 			int px = 0, py = 0;
 			for (int k = 0; k < NL; ++k) {
 				const int d = NL > 1 ? (int)(((long)k*(D - 1))/(NL - 1)) : 0;
-				Vec3 point;
+				Vec3 point = load3(rc.C);                          // (in: the camera centre, out: the label's point on the ray)
 				if (!point_from_depth(ray, normal, depth_from_label(p, mvs, d), point)) continue;
 				if (!cam_project(oc, point)) continue;
 				// (clamped a little outside the other image: what lies further out is no candidate)
@@ -1056,7 +1056,8 @@ static void estimate_list_capacity(const srh_camera &rc, const srh_camera &oc, i
 	if (best_rows > SRH_ROWS_NR) best_rows = SRH_ROWS_NR;
 	// + 12 % for what nine labels do not see, + one entry per kept segment: a list holds a segment's both end points, the
 	// joint of two segments twice (the C5 rig's corner pixel: 379 distinct candidates, 157 joints, a list of 536)
-	long cm = best_len + best_len/8 + (best_len < D - 1 ? best_len : D - 1) + 40;
+	// (MultiViewStereo's lists drop consecutive duplicates, std::unique: no joint term there)
+	long cm = best_len + best_len/8 + (mvs ? 0 : (best_len < D - 1 ? best_len : D - 1)) + 40;
 	if (cm > 65520) cm = 65520;
 	cmax = (int)((cm + 7) & ~7L);
 	long sm = cmax + 8*(best_rows + 2) + 32;
@@ -1856,6 +1857,7 @@ static int mvs_settle_slot(srh_context *c, int k) {
 	mvs_slot_swap(c, S); mvs_print_phases(c); mvs_slot_swap(c, S);
 #endif
 	const int maxc = *S.h_maxc;
+	if (c->debug_trace) fprintf(stderr, "[srh trace] mvs view %d settled: capacity %d, longest list %d%s\n", S.view, S.cmax, maxc, maxc <= S.cmax ? "" : " -> redone");
 	if (maxc <= S.cmax) { if (S.cmax > c->mvs_cmax_hint) c->mvs_cmax_hint = S.cmax; return SRH_OK; }
 	// a list was cut: redo the view, waiting for it, with the true maximum as the capacity (on the context's own
 	// buffers, which slot 0 shares: nothing may be in flight)
