@@ -64,6 +64,46 @@ def test_bunny_pair_twoview(hip_ctx):
     assert ok, "right cross-check: " + msg
 
 
+def _oracle_map(ri, oi, rc, oc, op, H, workers=16):
+    """The oracle's whole WTA map, its rows spread over a thread pool (the C oracle runs outside the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    step = max(1, (H + 4 * workers - 1) // (4 * workers))
+    bands = [(y, min(H, y + step)) for y in range(0, H, step)]
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        parts = list(ex.map(lambda b: O.twoview_wta(ri, oi, rc, oc, op, b[0], b[1]), bands))
+    out = np.full(parts[0].shape, np.nan)
+    for (a, b), m in zip(bands, parts):
+        out[a:b] = m[a:b]
+    return out
+
+
+def test_bunny_pair_whole_maps_and_cross_check(hip_ctx):
+    """C1 -- a BASELINE configuration -- in full: the whole 256x192x100 pair, both directions, then the
+    ordered cross-check, through srh_twoview_compute (TwoViewStereo::computeDepthMaps) against the oracle's two whole WTA
+    maps and its cross-check of them."""
+    case = _load()
+    imgs, ocams, op = cases.oracle_inputs(case)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    H = imgs[0].h
+    want_l = _oracle_map(imgs[0], imgs[1], ocams[0], ocams[1], op, H)
+    want_r = _oracle_map(imgs[1], imgs[0], ocams[1], ocams[0], op, H)
+    hip_ctx.twoview_wta(0, 1, p)
+    got_l = hip_ctx.download_depth(0)
+    hip_ctx.twoview_wta(1, 0, p)
+    got_r = hip_ctx.download_depth(1)
+    for got, want, tag in ((got_l, want_l, "left"), (got_r, want_r, "right")):
+        ok, msg, _ = cases.compare_depth(got, want, 1e-9)
+        assert ok, tag + ": " + msg
+    assert np.isfinite(want_l).sum() > 3000 and np.isfinite(want_r).sum() > 3000       # the object is there
+    cl, cr = O.twoview_cross_check(ocams[0], ocams[1], op, want_l, want_r)
+    dl, dr = hip_ctx.twoview_compute(0, 1, p)                                        # both passes + cross-check, as the class runs them
+    for got, want, tag in ((dl, cl, "left"), (dr, cr, "right")):
+        ok, msg, _ = cases.compare_depth(got, want, 1e-9)
+        assert ok, "after the cross-check, " + tag + ": " + msg
+    assert (np.isfinite(want_l) & ~np.isfinite(cl)).any()                              # the cross-check rejects something
+
+
 def test_bunny_pair_from_the_project_file(hip_ctx):
     """The same pair with its cameras taken from the project XML fixture through Camera::setP
     (srh_camera_from_p on the product side, sro_camera_set_p on the oracle side): SURVEY 8(f) rank 1."""

@@ -96,9 +96,20 @@ def test_c5_refractive_rows_equal_ordered_lists(hip_ctx):
 def _oracle_rows(li, ri, cl, cr, op, rows):
     """One-row oracle WTA passes on a thread pool (the C oracle runs outside the GIL): {y: row of the map}."""
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(8, len(rows))) as ex:
+    with ThreadPoolExecutor(max_workers=min(16, len(rows))) as ex:       # (the GPU box gives a one-GPU job 16 host threads)
         maps = list(ex.map(lambda y: O.twoview_wta(li, ri, cl, cr, op, y, y + 1)[y], rows))
     return dict(zip(rows, maps))
+
+
+def _stratified_rows(H, R=5):
+    """16 rows of a full-size image: the first and last row, the rows either side of where the window stops
+    crossing the top / bottom border (R - 1 | R, H - R - 1 | H - R), the rows either side of the strip kernel's work-item
+    boundaries (its 16- / 8- / 4-row segments: launch_twoview_strip_cost's n1, n2), the rest spread over the interior."""
+    n1 = ((H * 3 // 4) // 16) * 16
+    n2 = n1 + (((H - n1) * 2 // 3) // 8) * 8
+    rows = [0, R - 1, R, H - R - 1, H - R, H - 1, 15, 16, n1 - 1, n1, n2 - 1, n2, H // 5, H // 3, H // 2 + 7, 2 * H // 3 + 1]
+    assert len(set(rows)) == 16 and all(0 <= y < H for y in rows)
+    return rows
 
 
 def _assert_rows(got, want_rows, tag):
@@ -110,8 +121,9 @@ def _assert_rows(got, want_rows, tag):
 def test_c3_full_size_band_invariance(hip_ctx):
     """C3: 1920x1080, 256 levels, GeodesicWeight r=5: the depth map must not depend on the band
     split (one band at the default 32 GB budget vs ~50 bands at 128 MB), left->right pass.  Then, through the STRIP
-    kernel: an interior row and the border rows 0, 3, H-4, H-1 of both directions against the oracle (rows within R
-    of the top / bottom take the select form and the phase-2 work lists), and the whole left / right cross-check
+    kernel: 16 stratified rows of both directions against the oracle (_stratified_rows: the border rows -- rows within R
+    of the top / bottom take the select form and the phase-2 work lists --, the rows either side of the strip kernel's
+    work-item boundaries, interior rows), and the whole left / right cross-check
     (twoviewstereo.cpp:596-672) against the oracle's pass over the same two maps."""
     W, H, D = 1920, 1080, 256
     (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0003, capi.WEIGHT_GEODESIC)
@@ -133,7 +145,7 @@ def test_c3_full_size_band_invariance(hip_ctx):
     assert hip_ctx.stats()["used_strip_kernel"]
     (Kl, Rl, tl), (Kr, Rr, tr) = cams3
     li, ri, cl, cr = O.OImage(L, ml), O.OImage(R, mr), O.camera_set(Kl, Rl, tl), O.camera_set(Kr, Rr, tr)
-    rows = [0, 3, H // 2 + 7, H - 4, H - 1]
+    rows = _stratified_rows(H)
     _assert_rows(a, _oracle_rows(li, ri, cl, cr, op, rows), "left->right")
     _assert_rows(ar, _oracle_rows(ri, li, cr, cl, op, rows), "right->left")
     assert st_a["n_eval"] == st_b["n_eval"] and st_a["n_pixels"] == W * H
@@ -268,8 +280,8 @@ def _cmp(got, want):
 @pytest.mark.parametrize("seed", [0x5EED0050, 0x5EED0057])
 def test_c5_full_size(hip_ctx, seed):
     """C5 at BASELINE size (1920x1080, 256 levels, refractive interface), first and last pair seed of SURVEY 8(d):
-    row-run evaluation == list-order evaluation bit for bit (both directions), n_eval equal; one full-width row
-    per direction against the oracle."""
+    row-run evaluation == list-order evaluation bit for bit (both directions), n_eval equal; 16 stratified full-width
+    rows per direction against the oracle."""
     W, H, D = 1920, 1080, 256
     L, R, ml, mr, _ = synthetic.rectified_pair(W, H, D, seed)
     (Kl, Rl, tl), (Kr, Rr, tr) = synthetic.rectified_cameras(W, H)
@@ -297,9 +309,10 @@ def test_c5_full_size(hip_ctx, seed):
     op = O.params_twoview(**kw)
     oc = [O.camera_set(Kl, Rl, tl, None, *plane), O.camera_set(Kr, Rr, tr, None, *plane)]
     oi = [O.OImage(L, ml), O.OImage(R, mr)]
-    # an interior row and the border rows (windows cut by the image's top / bottom: the blocked select form)
-    for ref, oth, rows in ((0, 1, [0, 3, H // 2, H - 1]), (1, 0, [0, H // 3, H - 4, H - 1])):
-        _assert_rows(res["rows"][ref][0], _oracle_rows(oi[ref], oi[oth], oc[ref], oc[oth], op, rows), (hex(seed), ref))
+    # 16 stratified rows per direction: border rows (windows cut by the image's top / bottom: the blocked select form), the
+    # rows where that stops, interior rows
+    for ref, oth in ((0, 1), (1, 0)):
+        _assert_rows(res["rows"][ref][0], _oracle_rows(oi[ref], oi[oth], oc[ref], oc[oth], op, _stratified_rows(H)), (hex(seed), ref))
 
 
 def test_c5_full_size_tilted_interface(hip_ctx):
