@@ -632,7 +632,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->lmeta) hipFree(c->lmeta);
 	if (c->mvs_wdesc) hipFree(c->mvs_wdesc);
 	if (c->mvs_nwin) hipFree(c->mvs_nwin);
-	if (c->comm) rccl_comm_destroy(c->comm);
+	if (c->comm) (void)rccl_comm_destroy(c->comm);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -2351,7 +2351,9 @@ extern "C" int srh_comm_init(srh_context *c, int nranks, int rank, const void *i
 	if (!c || !id) return fail(SRH_E_INVALID, "null argument");
 	if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SRH_E_INVALID, "rank %d of %d", rank, nranks);
 	HIP_TRY(hipSetDevice(c->device));
-	if (c->comm) { rccl_comm_destroy(c->comm); c->comm = nullptr; }
+	if (c->comm) { (void)rccl_comm_destroy(c->comm); c->comm = nullptr; }
+	// librccl absent, or without the entry points this file needs: not a device failure (include/stereo_recon_hip.h)
+	if (!rccl_available()) { c->comm_ranks = 0; return fail(SRH_E_UNSUPPORTED, "RCCL: librccl cannot be loaded"); }
 	// (non-blocking communicator: a rank that never arrives is an error after the timeout, not a hang)
 	if (const char *e = rccl_comm_init(&c->comm, nranks, rank, id)) { c->comm = nullptr; c->comm_ranks = 0; return fail(SRH_E_DEVICE, "RCCL: %s", e); }
 	c->comm_ranks = nranks; c->comm_rank = rank;
@@ -2392,6 +2394,9 @@ extern "C" int srh_comm_gather_depth(srh_context *c, int slot, int root, void *r
 	if (const char *e = rccl_gather_f64(c->comm, c->comm_ranks, c->comm_rank, root, v.depth, (double *)recv_dev,
 	                                    (size_t)v.w*v.h, c->stream))
 		return comm_failed(c, "gather", e);
+	// the collective is ON the stream now; its completion is waited for here, with the bound -- a peer that dies inside it
+	// must not leave this rank in a later, unbounded hipStreamSynchronize
+	if (const char *e = rccl_wait_stream(c->comm, c->stream, "the depth-map gather")) return comm_failed(c, "gather", e);
 	return SRH_OK;
 }
 
@@ -2403,6 +2408,7 @@ extern "C" int srh_comm_allgather_depth(srh_context *c, int slot, void *recv_dev
 	const ViewHost &v = c->views[slot];
 	if (const char *e = rccl_allgather_f64(c->comm, v.depth, (double *)recv_dev, (size_t)v.w*v.h, c->stream))
 		return comm_failed(c, "all-gather", e);
+	if (const char *e = rccl_wait_stream(c->comm, c->stream, "the depth-map all-gather")) return comm_failed(c, "all-gather", e);
 	return SRH_OK;
 }
 
@@ -2420,7 +2426,7 @@ extern "C" int srh_comm_allgather_host(srh_context *c, const double *send_host, 
 	if (const char *e = rccl_allgather_f64(c->comm, c->wbuf, c->wbuf + count, count, c->stream))
 		return comm_failed(c, "all-gather", e);
 	HIP_TRY(hipMemcpyAsync(recv_host, c->wbuf + count, count*(size_t)c->comm_ranks*sizeof(double), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (const char *e = rccl_wait_stream(c->comm, c->stream, "the all-gather")) return comm_failed(c, "all-gather", e);   // (bounded: never a bare hipStreamSynchronize behind a collective)
 	return SRH_OK;
 }
 
@@ -2460,12 +2466,17 @@ extern "C" int srh_comm_allgather_views(srh_context *c, const int32_t *slots, in
 			HIP_TRY(hipMemcpyAsync(vh.depth, recv + ((size_t)r*per + (v - rlo))*npix, (size_t)vh.w*vh.h*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
 		}
 	}
+	if (const char *e = rccl_wait_stream(c->comm, c->stream, "the views' all-gather")) return comm_failed(c, "all-gather", e);
 	return SRH_OK;
 }
 
 extern "C" int srh_comm_destroy(srh_context *c) {
 	if (!c) return fail(SRH_E_INVALID, "null context");
-	if (c->comm) { rccl_comm_destroy(c->comm); c->comm = nullptr; c->comm_ranks = 0; }
+	if (c->comm) {
+		const char *e = rccl_comm_destroy(c->comm);
+		c->comm = nullptr; c->comm_ranks = 0;
+		if (e) return fail(SRH_E_DEVICE, "RCCL: the communicator did not finalize: %s", e);
+	}
 	return SRH_OK;
 }
 

@@ -6,13 +6,17 @@
 // librccl is loaded on first use (dlopen): single-GPU users never need it, and a missing
 // library is reported as SRH_E_UNSUPPORTED instead of failing the load of this library.
 #include "srh_internal.hpp"
+#include "srh_wait.hpp"
 
 #include <dlfcn.h>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <thread>
-#include <rccl/rccl.h>                                       // types and the config initialiser only: the library itself is dlopen'ed
+// Build dependency: <rccl/rccl.h> of the ROCm the library is built against -- for ncclConfig_t / NCCL_CONFIG_INITIALIZER (a
+// versioned struct: redeclaring it here would pin one RCCL's layout) and the result codes.  Nothing is LINKED: the library
+// itself is dlopen'ed on first use, and a machine without it gets SRH_E_UNSUPPORTED from srh_comm_*.
+#include <rccl/rccl.h>
 
 namespace srh {
 
@@ -23,7 +27,9 @@ enum { RCCL_FLOAT64 = 8 };                                   // ncclFloat64
 struct RcclApi {
 	void *lib = nullptr;
 	int (*GetUniqueId)(rccl_unique_id *) = nullptr;
-	int (*CommInitRankConfig)(rccl_comm *, int, rccl_unique_id, int, ncclConfig_t *) = nullptr;
+	int (*CommInitRankConfig)(rccl_comm *, int, rccl_unique_id, int, ncclConfig_t *) = nullptr;   // optional (older RCCL: blocking ncclCommInitRank)
+	int (*CommInitRank)(rccl_comm *, int, rccl_unique_id, int) = nullptr;
+	int (*CommFinalize)(rccl_comm) = nullptr;                                                     // optional
 	int (*CommGetAsyncError)(rccl_comm, int *) = nullptr;
 	int (*CommAbort)(rccl_comm) = nullptr;
 	int (*CommCount)(rccl_comm, int *) = nullptr;
@@ -48,7 +54,9 @@ const char *rccl_load() {
 #define SRH_SYM(field, name) \
 	*(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) { dlclose(h); return "librccl lacks " name; }
 	SRH_SYM(GetUniqueId, "ncclGetUniqueId")
-	SRH_SYM(CommInitRankConfig, "ncclCommInitRankConfig")
+	SRH_SYM(CommInitRank, "ncclCommInitRank")
+	*(void **)(&g_rccl.CommInitRankConfig) = dlsym(h, "ncclCommInitRankConfig");   // (absent in old RCCL builds: the blocking rendezvous then)
+	*(void **)(&g_rccl.CommFinalize) = dlsym(h, "ncclCommFinalize");
 	SRH_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
 	SRH_SYM(CommAbort, "ncclCommAbort")
 	SRH_SYM(CommCount, "ncclCommCount")
@@ -82,22 +90,44 @@ static int g_timeout_ms = 120000;
 void rccl_set_timeout_ms(int ms) { g_timeout_ms = ms > 0 ? ms : 120000; }
 
 static const char *rccl_settle(rccl_comm c, int rc, const char *what) {
-	static thread_local char msg[160];
+	static thread_local char msg[200];
 	if (rc == ncclSuccess) return nullptr;
 	if (rc != ncclInProgress) return g_rccl.GetErrorString(rc);
-	const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(g_timeout_ms);
-	for (;;) {
+	int last = ncclSuccess;
+	return bounded_wait([&]() -> int {
 		int st = ncclSuccess;
 		const int q = g_rccl.CommGetAsyncError(c, &st);
-		if (q != ncclSuccess) return g_rccl.GetErrorString(q);
-		if (st == ncclSuccess) return nullptr;
-		if (st != ncclInProgress) return g_rccl.GetErrorString(st);
-		if (std::chrono::steady_clock::now() > t_end) {
-			snprintf(msg, sizeof(msg), "%s still in progress after %d ms (a rank missing or gone?): communicator aborted", what, g_timeout_ms);
-			return msg;
+		last = q != ncclSuccess ? q : st;
+		return last == ncclSuccess ? 0 : last == ncclInProgress ? 1 : 2;
+	}, [&]() { return g_rccl.GetErrorString(last); }, g_timeout_ms, what, msg, sizeof(msg));
+}
+
+// The completion of whatever `st` holds up to now -- a collective included -- with the same bound: an event behind it is
+// polled (hipEventQuery) together with the communicator's asynchronous error state.  A peer that died inside the
+// collective leaves the event unreached: after the timeout the caller aborts the communicator (comm_failed, srh_api.hip)
+// and returns SRH_E_DEVICE; it never sits in hipStreamSynchronize.
+const char *rccl_wait_stream(void *comm, hipStream_t st, const char *what) {
+	static thread_local char msg[200];
+	hipEvent_t ev;
+	if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+	if (hipEventRecord(ev, st) != hipSuccess) { (void)hipEventDestroy(ev); return "hipEventRecord failed"; }
+	int last = ncclSuccess;
+	hipError_t herr = hipSuccess;
+	const char *e = bounded_wait([&]() -> int {
+		const hipError_t q = hipEventQuery(ev);
+		if (q == hipSuccess) return 0;
+		if (q != hipErrorNotReady) { herr = q; return 2; }
+		if (comm && g_rccl.CommGetAsyncError) {
+			int a = ncclSuccess;
+			const int r = g_rccl.CommGetAsyncError((rccl_comm)comm, &a);
+			last = r != ncclSuccess ? r : a;
+			if (last != ncclSuccess && last != ncclInProgress) return 2;
 		}
-		std::this_thread::sleep_for(std::chrono::microseconds(200));
-	}
+		return 1;
+	}, [&]() -> const char * { return herr != hipSuccess ? hipGetErrorString(herr) : g_rccl.GetErrorString(last); },
+	g_timeout_ms, what, msg, sizeof(msg));
+	(void)hipEventDestroy(ev);                                    // (an event that was never reached is released with the aborted work)
+	return e;
 }
 
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128) {
@@ -105,12 +135,19 @@ const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128)
 	rccl_unique_id id;
 	memcpy(&id, id128, sizeof(id));
 	rccl_comm c = nullptr;
-	ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-	cfg.blocking = 0;
-	const int rc = g_rccl.CommInitRankConfig(&c, nranks, id, rank, &cfg);
-	if (const char *e = rccl_settle(c, rc, "ncclCommInitRank")) {
-		if (c) g_rccl.CommAbort(c);
-		return e;
+	if (g_rccl.CommInitRankConfig) {
+		ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+		cfg.blocking = 0;
+		const int rc = g_rccl.CommInitRankConfig(&c, nranks, id, rank, &cfg);
+		if (const char *e = rccl_settle(c, rc, "ncclCommInitRank")) {
+			if (c) g_rccl.CommAbort(c);
+			return e;
+		}
+	} else {
+		// an RCCL without ncclCommInitRankConfig: the blocking rendezvous (what round 4 used) -- collectives are still waited
+		// for with a bound (rccl_wait_stream), only a rank missing at THIS call can hold the others
+		const int rc = g_rccl.CommInitRank(&c, nranks, id, rank);
+		if (rc != ncclSuccess) return g_rccl.GetErrorString(rc);
 	}
 	int n = 0;
 	if (g_rccl.CommCount(c, &n) != ncclSuccess || n != nranks) { g_rccl.CommAbort(c); return "communicator does not span the ranks asked for"; }
@@ -127,7 +164,21 @@ int rccl_version() {
 
 void rccl_comm_abort(void *comm) { if (comm && g_rccl.CommAbort) g_rccl.CommAbort((rccl_comm)comm); }
 
-void rccl_comm_destroy(void *comm) { if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy((rccl_comm)comm); }
+// A non-blocking communicator is finalized first (ncclCommFinalize, settled with the same bound) and destroyed then; one
+// that does not settle is aborted.  Returns an error text for the caller's log, the communicator is gone either way.
+const char *rccl_comm_destroy(void *comm) {
+	if (!comm || !g_rccl.CommDestroy) return nullptr;
+	rccl_comm c = (rccl_comm)comm;
+	if (g_rccl.CommFinalize) {
+		if (const char *e = rccl_settle(c, g_rccl.CommFinalize(c), "ncclCommFinalize")) { g_rccl.CommAbort(c); return e; }
+	}
+	const int rc = g_rccl.CommDestroy(c);
+	if (rc == ncclSuccess) return nullptr;
+	if (rc == ncclInProgress) { if (const char *e = rccl_settle(c, rc, "ncclCommDestroy")) { g_rccl.CommAbort(c); return e; } return nullptr; }
+	return g_rccl.GetErrorString(rc);
+}
+
+bool rccl_available() { return rccl_load() == nullptr; }
 
 // every rank contributes `count` doubles; the root receives nranks*count (rank order)
 const char *rccl_gather_f64(void *comm, int nranks, int rank, int root, const double *send, double *recv,

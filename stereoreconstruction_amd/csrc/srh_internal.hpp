@@ -368,7 +368,10 @@ bool launch_twoview_rows_refill(hipStream_t st, int width, int oth_width, const 
 // RCCL exchange, srh_comm.hip (functions return nullptr or an error string)
 const char *rccl_unique_id_get(void *out128);
 const char *rccl_comm_init(void **comm, int nranks, int rank, const void *id128);
-void rccl_comm_destroy(void *comm);
+const char *rccl_comm_destroy(void *comm);   // finalize (non-blocking communicator) + destroy, bounded; error text or null
+bool rccl_available();                        // librccl can be loaded and has the entry points (else: SRH_E_UNSUPPORTED)
+// bounded wait for everything `st` holds (a collective included): event + ncclCommGetAsyncError polled to the timeout
+const char *rccl_wait_stream(void *comm, hipStream_t st, const char *what);
 void rccl_comm_abort(void *comm);
 void rccl_set_timeout_ms(int ms);      // how long a call into RCCL may stay "in progress" (rendezvous, collectives); default 120 s
 int  rccl_version();                   // NCCL_VERSION_CODE of the loaded librccl, 0 if there is none

@@ -6,6 +6,7 @@
 //                                            LoopbackTransport; every context on device (k mod device count)), and on
 //                                            one context through the RCCL transport (1 rank): all bit-identical.
 //                                            in.bin as host_api_test's "mvs" input; out.bin = per view double depth[w*h]
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <vector>
 
 #include "sharded.hpp"
+#include "../stereoreconstruction_amd/csrc/srh_wait.hpp"   // the bound behind every wait of the exchange (plain C++)
 
 // ---- a deterministic stand-in: "depth maps" are small vectors; crossCheck(v) folds every other view's current map
 // into view v (order dependent, like multiviewstereo.cpp:694-719 reading already-filtered maps)
@@ -123,6 +125,25 @@ static int cpuTest() {
 				if (!sameBits(eng[0].maps[view], ref.maps[view])) { fprintf(stderr, "row bands: height %d world %d view %d differs\n", height, world, view); return 12; }
 			for (int r = 1; r < world; ++r) if (eng[r].checked) return 13;            // the cross-check runs on shard 0 only
 		}
+	}
+	// ---- the wait behind every collective is bounded (csrc/srh_wait.hpp): a transport that never completes
+	// -- a peer that died inside the collective -- ends in an error text after the timeout, one that fails says so at once,
+	// one that completes returns in time
+	{
+		char msg[200];
+		const auto t0 = std::chrono::steady_clock::now();
+		int polls = 0;
+		const char *e = srh::bounded_wait([&] { ++polls; return 1; }, nullptr, 150, "a collective that never completes", msg, sizeof(msg));
+		const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		if (!e || !strstr(e, "still in progress after 150 ms") || ms < 140 || ms > 2000 || polls < 10) { fprintf(stderr, "bounded wait: '%s' after %.1f ms, %d polls\n", e ? e : "(null)", ms, polls); return 14; }
+		polls = 0;
+		e = srh::bounded_wait([&] { return ++polls < 5 ? 1 : 2; }, [] { return "peer gone"; }, 60000, "a failing collective", msg, sizeof(msg));
+		if (!e || strcmp(e, "peer gone") || polls != 5) return 15;
+		polls = 0;
+		e = srh::bounded_wait([&] { return ++polls < 7 ? 1 : 0; }, [] { return "unused"; }, 60000, "a collective", msg, sizeof(msg));
+		if (e || polls != 7) return 16;
+		e = srh::bounded_wait([] { return 3; }, nullptr, 1000, "a call", msg, sizeof(msg));          // failed without a text of its own
+		if (!e || strcmp(e, "a call failed")) return 17;
 	}
 	printf("cpu ok\n");
 	return 0;
