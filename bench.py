@@ -208,7 +208,7 @@ def run_c4(args, rank, world, dev, dev_index, backend):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = ctx.profile()
-    first_call_samples = [first_call() for _ in range(3)] if world == 1 else None
+    first_call_samples = [first_call() for _ in range(3)] if world == 1 and not args.no_first_call else None
     first_call_ms = sorted(first_call_samples)[1] if first_call_samples else None      # (median of three fresh contexts)
     # cost evaluations the reference performs for this rank's views (untimed recount): only masked-in pixels are
     # matched and a curve has as many candidates as its pixel length, so W*H*D*links is neither a bound nor an estimate
@@ -396,7 +396,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         return sorted(v)[len(v) // 2], v
 
     # the process's very first call (C3 in the default run: kernels' code objects not yet resident either)
-    first_call_cold = first_call() if not rows_shard else None
+    first_call_cold = first_call() if not rows_shard and not args.no_first_call else None
 
     ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -481,7 +481,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
 
     prof_timed = ctx.profile()
     stats = ctx.stats()
-    first_call_warm, first_call_samples = first_calls() if not rows_shard else (None, None)
+    first_call_warm, first_call_samples = first_calls() if not rows_shard and not args.no_first_call else (None, None)
     # per-kernel durations (roofline): srh_twoview_compute runs its two passes side by side on two streams, so the HIP
     # events around a kernel of the timed steps also time the other pass's share of the GPU; an extra, untimed run of the
     # same step with the passes one after the other (option tv_overlap 0) gives each kernel's own duration
@@ -823,6 +823,8 @@ def main():
     ap.add_argument("--shard", default="pairs", choices=["pairs", "rows"],
                     help="N > 1, TwoView workloads: 'pairs' (default) = one pair per GPU, weak scaling; 'rows' = ONE pair cut "
                          "into N row bands, bands gathered on rank 0, cross-check there: strong scaling")
+    ap.add_argument("--no-first-call", action="store_true",
+                    help="skip the fresh-context first-call measurements (the rocprofv3 passes: only the steady-state launches are counted)")
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the untimed pass in the reference's arithmetic that counts the depths the chosen arithmetic changes "
                          "(profiling passes: only the kernels of the timed steps are to be traced)")

@@ -259,6 +259,11 @@ int  srh_twoview_wta(srh_context *ctx, int ref_slot, int oth_slot, const srh_par
  * SRH_E_UNSUPPORTED when the pair does not take the dense plan. */
 int  srh_twoview_cost_rows(srh_context *ctx, int ref_slot, int other_slot, const srh_params *p, int y0, int y1, int form, int raw,
                            double *cost_out, size_t cost_doubles, int32_t *range_out, int *cstride_out, int *used_strip_kernel);
+/* DIAGNOSTIC (tests/test_gpu_geodesic_exp.py): the GeodesicWeight kernels evaluate exp(-w/sigma) (geodesicweight.cpp:128-130)
+ * by the device library's exp sequence written out in their source (srh_dense.hip, geo_exp_n: constants of THIS ROCm's
+ * ocml) -- this entry evaluates n arguments by that sequence (kernel_out) and by the library's exp() itself (library_out),
+ * so that a ROCm whose exp has moved shows up as a bit difference here, not as a last-bit drift of the windows. */
+int  srh_debug_exp(srh_context *ctx, const double *x, int n, double *kernel_out, double *library_out);
 int  srh_twoview_cross_check(srh_context *ctx, int left_slot, int right_slot, const srh_params *p);
 /* computeDepthMaps minus colourisation (twoviewstereo.cpp:150-227): both passes +
  * cross-check, progress steps 1,3,5,8; synchronous; host outputs may be NULL.  The two passes

@@ -87,7 +87,7 @@ EXPORTS = [
     "srh_create", "srh_destroy", "srh_set_stream", "srh_set_hooks", "srh_synchronize", "srh_set_option",
     "srh_view_upload", "srh_view_size", "srh_view_depth_download", "srh_view_depth_upload",
     "srh_view_depth_device_ptr", "srh_view_depth_copy_to_device", "srh_view_depth_copy_from_device",
-    "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute", "srh_twoview_cost_rows",
+    "srh_twoview_wta", "srh_twoview_cross_check", "srh_twoview_compute", "srh_twoview_cost_rows", "srh_debug_exp",
     "srh_mvs_initial_estimate", "srh_mvs_cross_check", "srh_view_point_cloud", "srh_epipolar_curves",
     "srh_epipolar_preview", "srh_refraction_error",
     "srh_mrf_params_defaults", "srh_mvs_mrf_estimate", "srh_mvs_mrf_state", "srh_mvs_mrf_dims", "srh_mvs_initial_estimate_mrf",
@@ -170,6 +170,7 @@ def lib():
     L.srh_twoview_cost_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, C.c_size_t,
                                         c_int32_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.srh_twoview_compute.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), c_double_p, c_double_p]
+    L.srh_debug_exp.argtypes = [vp, c_double_p, C.c_int, c_double_p, c_double_p]
     L.srh_mvs_initial_estimate.argtypes = [vp, C.c_int, c_int32_p, C.c_int, C.POINTER(Params), C.c_int, C.c_int, vp]
     L.srh_mvs_cross_check.argtypes = [vp, c_int32_p, C.c_int, C.c_int, C.POINTER(Params)]
     L.srh_epipolar_curves.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, c_int32_p,
@@ -413,6 +414,13 @@ class Context:
         dr = np.empty((h, w), dtype=np.float64)
         _check(lib().srh_twoview_compute(self._h, left_slot, right_slot, C.byref(p), _dptr(dl), _dptr(dr)))
         return dl, dr
+
+    def debug_exp(self, x):
+        """srh_debug_exp -> (the geodesic kernels' exp sequence, the device library's exp) of the arguments x."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        a, b = np.empty_like(x), np.empty_like(x)
+        _check(lib().srh_debug_exp(self._h, _dptr(x), x.size, _dptr(a), _dptr(b)))
+        return a, b
 
     def twoview_compute_device(self, left_slot, right_slot, p):
         """srh_twoview_compute without host outputs: both passes + cross-check, the maps stay in the slots' device memory."""

@@ -1534,6 +1534,23 @@ extern "C" int srh_twoview_cost_rows(srh_context *c, int ref, int oth, const srh
 	return SRH_OK;
 }
 
+extern "C" int srh_debug_exp(srh_context *c, const double *x, int n, double *kernel_out, double *library_out) {
+	if (!c || !x || !kernel_out || !library_out || n < 1) return fail(SRH_E_INVALID, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	double *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, (size_t)n*3*sizeof(double)));
+	hipError_t e = hipMemcpyAsync(d, x, (size_t)n*sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		launch_geo_exp_probe(c->stream, d, n, d + n, d + 2*(size_t)n);
+		e = hipMemcpyAsync(kernel_out, d + n, (size_t)n*sizeof(double), hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(library_out, d + 2*(size_t)n, (size_t)n*sizeof(double), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(SRH_E_DEVICE, "srh_debug_exp: %s", hipGetErrorString(e));
+	return SRH_OK;
+}
+
 extern "C" int srh_twoview_cross_check(srh_context *c, int left, int right, const srh_params *p) {
 	int rc;
 	if ((rc = check_slot(c, left, true)) || (rc = check_slot(c, right, true)) || (rc = check_params(p))) return rc;

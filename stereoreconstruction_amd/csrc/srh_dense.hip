@@ -182,6 +182,20 @@ __device__ __forceinline__ void geo_exp_row(double (&w)[WS], const SharedDivisor
 		geo_exp_row<WS, B0 + N>(w, sg, fast, sigma);
 	}
 }
+
+// srh_debug_exp: geo_exp_n (both forms) beside the device library's exp(), argument by argument
+__global__ void geo_exp_probe_kernel(const double *__restrict__ x, int n, double *__restrict__ kout, double *__restrict__ lout) {
+	const int k = blockIdx.x*blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	double a[1] = { x[k] }, b[1] = { x[k] };
+	geo_exp_n<1, true>(a);
+	if (x[k] <= 0.0 && x[k] >= -0x1p30) { geo_exp_n<1, false>(b); if (__builtin_bit_cast(unsigned long long, a[0]) != __builtin_bit_cast(unsigned long long, b[0])) a[0] = __builtin_nan(""); }   // (the form without range selects, on its range: the same bits or a NaN here)
+	kout[k] = a[0];
+	lout[k] = exp(x[k]);
+}
+void launch_geo_exp_probe(hipStream_t st, const double *x, int n, double *kout, double *lout) {
+	hipLaunchKernelGGL(geo_exp_probe_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, x, n, kout, lout);
+}
 template <int R, int TWD, int PL, int S>
 __device__ __forceinline__ void geo_edges(GeoLds tb, double &e0, double &e1, double &e2, double &e3) {
 	using C = GeoCell<R, S>;

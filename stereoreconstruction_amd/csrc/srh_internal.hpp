@@ -218,6 +218,7 @@ void launch_mvs_cross_check(hipStream_t st, const ViewDev *views, const int32_t 
 // Dense (row-aligned) TwoView path, srh_dense.hip
 void launch_edge_planes(hipStream_t st, const uint32_t *rgba, int w, int h, double *edges);
 // the dense TwoView path's windows kernel with its tiles by LDS-DMA (r = 5; srh_dense.hip): the padded planes it reads
+void launch_geo_exp_probe(hipStream_t st, const double *x, int n, double *kout, double *lout);   // srh_debug_exp
 size_t geo5_doubles(int w, int h);
 void launch_geo5_planes(hipStream_t st, const double *edges, const double *gray_tv, const uint8_t *mask, int w, int h, double *out);
 bool launch_geodesic_dma(hipStream_t st, const ViewDev *views, int ref, int width, const double *geo5, const srh_params &P,
