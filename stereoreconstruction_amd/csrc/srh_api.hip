@@ -48,6 +48,7 @@ struct ViewHost {
 	// strip kernel (srh_strip.hip): NaN-bordered copy of gray_tv, zero-bordered "window fully usable" plane for radius fullp_r
 	double   *tvp = nullptr;   bool tvp_valid = false;
 	double   *geo5 = nullptr;  bool geo5_valid = false;   // edge + tap planes with their borders written out (geodesic_dma_kernel)
+	bool      geo5_denied = false;                        // released by an out-of-memory retry: this upload keeps the register-staged windows kernel
 	uint8_t  *fullp = nullptr; int fullp_r = 0;
 	// how the candidate lists of this view against slot j are best evaluated, learnt from the last run:
 	// 0 unknown, 1 row runs (srh_rows.hip), 2 list order (srh_list.hip: steep curves)
@@ -740,7 +741,7 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	}
 	v.cam = *cam;
 	v.full_r = 0;                                               // recomputed on demand for the new pixels
-	v.tvp_valid = false; v.fullp_r = 0; v.geo5_valid = false;
+	v.tvp_valid = false; v.fullp_r = 0; v.geo5_valid = false; v.geo5_denied = false;
 	v.peaks_k = 0;                                              // the top-K peaks belonged to the previous image
 	if (c->mrf_w == w && c->mrf_h == h) c->mrf_w = c->mrf_h = c->mrf_k = 0;
 	for (int j = 0; j < SRH_MAX_VIEWS; ++j) { v.list_mode[j] = 0; c->views[j].list_mode[slot] = 0; }   // new geometry
@@ -827,6 +828,7 @@ static size_t held_band_bytes(const srh_context *c) {
 	const srh_context::TvSlot &T = c->tv_slot;
 	b += T.wbuf_cap*8 + T.cost_cap*8 + T.pconst_cap*8 + T.prange_cap*sizeof(PixRange) + T.cflag_cap*4 + T.lcand_cap*4 + T.lrowinfo_cap*4
 	   + T.lcount_cap*4 + T.lmeta_cap*4;
+	for (const ViewHost &v : c->views) if (v.geo5) b += geo5_doubles(v.w, v.h)*sizeof(double);   // (released with the band buffers)
 	return b;
 }
 
@@ -865,6 +867,11 @@ static void release_band_buffers(srh_context *c) {
 	drop(T.cflag, T.cflag_cap); drop(T.lcand, T.lcand_cap); drop(T.lrowinfo, T.lrowinfo_cap); drop(T.lcount, T.lcount_cap);
 	drop(T.lmeta, T.lmeta_cap);
 	drop(T.stpl, T.stpl_cap); drop(T.tileflag, T.tileflag_cap);
+	// the geodesic_dma_kernel's second copy of the edge / tap planes (42 B per pixel and view, made on first use): memory an
+	// out-of-memory retry must be able to reclaim -- the register-staged kernel needs no such copy and serves the view until
+	// it is uploaded again
+	for (ViewHost &v : c->views)
+		if (v.geo5) { (void)hipFree(v.geo5); v.geo5 = nullptr; v.geo5_valid = false; v.geo5_denied = true; }
 }
 
 // Run `body`; when it fails because a band buffer could not be allocated, wait for everything in flight, release the
@@ -963,7 +970,7 @@ static int fetch_counters(srh_context *c, int used_dense) {
 // support windows of rows [by, by+nr) of view `ref` into c->wbuf
 static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int by, int nr, size_t wstride,
                         double *pconst = nullptr, bool wimg = false) {
-	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic && wimg && c->geodma && p.window_radius == 5) {
+	if (p.weight_kind == SRH_WEIGHT_GEODESIC && !c->force_generic && wimg && c->geodma && p.window_radius == 5 && !c->views[ref].geo5_denied) {
 		// the dense path's windows: tiles by LDS-DMA from planes with their borders written out (made once per uploaded view)
 		ViewHost &v = c->views[ref];
 		bool ok = true;

@@ -64,13 +64,13 @@ std::vector<Eigen::Vector3d> TwoViewStereo::epipolarCurve(const Ray3d &ray, cons
 // stereo/multiviewstereo.hpp:36-39 / multiviewstereo.cpp:291-315 with the reference's own types
 void outputPLYFile(const std::string &path, const std::vector<PLYPoint> &points) {
 	std::vector<double> xyz(points.size()*3);
-	std::vector<unsigned char> rgb(points.size()*3);
+	std::vector<int> rgb(points.size()*3);
 	for (size_t i = 0; i < points.size(); ++i) {
 		for (int k = 0; k < 3; ++k) xyz[i*3 + k] = points[i].first[k];
-		// (the reference prints static_cast<int>(rgb.r): writePLY prints the byte as an int)
-		rgb[i*3 + 0] = static_cast<unsigned char>(static_cast<int>(points[i].second.r));
-		rgb[i*3 + 1] = static_cast<unsigned char>(static_cast<int>(points[i].second.g));
-		rgb[i*3 + 2] = static_cast<unsigned char>(static_cast<int>(points[i].second.b));
+		// (the reference prints static_cast<int>(rgb.r) of a double: the int goes out as it is, also outside 0 .. 255)
+		rgb[i*3 + 0] = static_cast<int>(points[i].second.r);
+		rgb[i*3 + 1] = static_cast<int>(points[i].second.g);
+		rgb[i*3 + 2] = static_cast<int>(points[i].second.b);
 	}
 	srq::writePLY(path, points.size(), xyz.data(), rgb.data());
 }

@@ -41,6 +41,16 @@ void writePLY(const std::string &path, size_t npoints, const double *xyz, const 
 		     << static_cast<int>(rgb[i*3 + 1]) << ' ' << static_cast<int>(rgb[i*3 + 2]) << '\n';
 }
 
+void writePLY(const std::string &path, size_t npoints, const double *xyz, const int *rgb) {
+	std::ofstream lout(path.c_str());
+	lout << "ply\n" << "format ascii 1.0\n" << "element vertex " << npoints << "\n"
+	     << "property float x\n" << "property float y\n" << "property float z\n"
+	     << "property uchar diffuse_red\n" << "property uchar diffuse_green\n" << "property uchar diffuse_blue\n"
+	     << "end_header\n";
+	for (size_t i = 0; i < npoints; ++i)
+		lout << xyz[i*3] << ' ' << xyz[i*3 + 1] << ' ' << xyz[i*3 + 2] << ' ' << rgb[i*3] << ' ' << rgb[i*3 + 1] << ' ' << rgb[i*3 + 2] << '\n';
+}
+
 std::vector<unsigned char> whiteMask(const Raster &m) {
 	std::vector<unsigned char> out(static_cast<size_t>(m.w)*m.h);
 	for (size_t i = 0; i < out.size(); ++i) {

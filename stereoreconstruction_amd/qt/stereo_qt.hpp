@@ -52,6 +52,9 @@ namespace srq {
 // the text outputPLYFile writes (multiviewstereo.cpp:291-315): ASCII header, then "x y z r g b" per point through
 // operator<< of an ofstream; xyz = 3 doubles per point, rgb = 3 bytes per point (the reference prints static_cast<int>(rgb.r))
 void writePLY(const std::string &path, size_t npoints, const double *xyz, const unsigned char *rgb);
+// the same with the colours as the ints the reference prints: its RGBA holds doubles and static_cast<int>(rgb.r) goes out
+// unchanged -- a component outside 0 .. 255 (or negative) must not wrap modulo 256 on the way (outputPLYFile uses this one)
+void writePLY(const std::string &path, size_t npoints, const double *xyz, const int *rgb);
 
 // VectorImage::fromQImage (util/vectorimage.cpp:48-64): the raw 32-bit scanline words as R,G,B,A bytes.  (A smooth-
 // scaled ARGB32 image is ARGB32_Premultiplied; the reference reads it raw, and so does this.)  Images that are not

@@ -108,6 +108,7 @@ int main(int argc, char **argv) {
 		std::vector<PLYPoint> pts;
 		pts.push_back(PLYPoint(Eigen::Vector3d(1.5, -2.25, 1e-7), RGBA(255, 0, 17)));
 		pts.push_back(PLYPoint(Eigen::Vector3d(123456.789, 0.1, 3.0), RGBA(1.9, 254.2, 128)));
+		pts.push_back(PLYPoint(Eigen::Vector3d(0.0, 1.0, 2.0), RGBA(300.7, -4.2, 256)));   // the reference prints static_cast<int> of the doubles: no wrap
 		outputPLYFile(argv[2], pts);
 		void (TwoViewStereo::*rt)() = &TwoViewStereo::runTask;
 		printf("ply %d\n", rt != nullptr ? 1 : 0);

@@ -66,12 +66,12 @@ std::vector<Eigen::Vector3d> TwoViewStereo::epipolarCurve(const Ray3d &ray, cons
 // stereo/multiviewstereo.hpp:36-39 over the test driver's types (the reference's: qt/glue_reference.cpp)
 void outputPLYFile(const std::string &path, const std::vector<PLYPoint> &points) {
 	std::vector<double> xyz(points.size()*3);
-	std::vector<unsigned char> rgb(points.size()*3);
+	std::vector<int> rgb(points.size()*3);                        // (ints, as the reference prints them: qt/glue_reference.cpp)
 	for (size_t i = 0; i < points.size(); ++i) {
 		for (int k = 0; k < 3; ++k) xyz[i*3 + k] = points[i].first[k];
-		rgb[i*3 + 0] = static_cast<unsigned char>(static_cast<int>(points[i].second.r));
-		rgb[i*3 + 1] = static_cast<unsigned char>(static_cast<int>(points[i].second.g));
-		rgb[i*3 + 2] = static_cast<unsigned char>(static_cast<int>(points[i].second.b));
+		rgb[i*3 + 0] = static_cast<int>(points[i].second.r);
+		rgb[i*3 + 1] = static_cast<int>(points[i].second.g);
+		rgb[i*3 + 2] = static_cast<int>(points[i].second.b);
 	}
 	srq::writePLY(path, points.size(), xyz.data(), rgb.data());
 }

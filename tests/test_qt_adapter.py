@@ -56,9 +56,9 @@ def test_output_ply_file_with_the_reference_signature():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "p.ply")
         assert _run("ply", out)["ply"] == "1"
-        want = ("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
+        want = ("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
                 "property uchar diffuse_red\nproperty uchar diffuse_green\nproperty uchar diffuse_blue\nend_header\n"
-                "1.5 -2.25 1e-07 255 0 17\n123457 0.1 3 1 254 128\n")
+                "1.5 -2.25 1e-07 255 0 17\n123457 0.1 3 1 254 128\n0 1 2 300 -4 256\n")   # (components outside 0 .. 255 go out as the ints they are)
         assert open(out).read() == want
 
 
