@@ -1382,7 +1382,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		if ((rc = ensure(c->wbuf, c->wbuf_cap, strip ? wimg_doubles(W, (int)rows, R) : wbuf_doubles(W, (int)rows, T)))) return rc;
 		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*(size_t)((W + 31)/32)*32*(size_t)cstride))) return rc;   // 32-pixel tiles
 		// (+ one tile of slack: the strip kernel copies whole 32-pixel pieces of these rows)
-		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*4))) return rc;
+		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*SRH_PC))) return rc;
 		int lanes = 8;
 		if (dense && (rc = ensure(c->prange, c->prange_cap, rows*(size_t)W + SRH_WTILE))) return rc;
 		if (tscan && (rc = ensure(c->tileflag, c->tileflag_cap, rows*(size_t)((W + 63)/64) + 1))) return rc;

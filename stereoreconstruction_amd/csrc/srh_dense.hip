@@ -272,9 +272,12 @@ __device__ __forceinline__ void geo_pc1_step(const double (&w)[2*R+1][2*R+1], Ge
 }
 template <int R, int TWD, int KG, int J>
 __device__ __forceinline__ void geo_pc2_step(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double (&pr)[4],
-                                             double mL, double &s2) {
+                                             double mL, double &s2, double (&fa)[2], double &sa) {
 	constexpr int WS = 2*R + 1, NT = WS*WS;
 	if constexpr (J < NT) pr[J % 4] = w[J / WS][J % WS]*g[J % KG];
+	// (SA of the one-pass cost form: the FUSED a_t, one step behind its making; srh_internal.hpp, SRH_PC)
+	if constexpr (J < NT) fa[J % 2] = __builtin_fma(w[J / WS][J % WS], g[J % KG], -mL);
+	if constexpr (J >= 1 && J - 1 < NT) sa += fa[(J - 1) % 2];
 	if constexpr (J >= 1 && J - 1 < NT) pr[(J - 1) % 4] = pr[(J - 1) % 4] - mL;
 	if constexpr (J >= 2 && J - 2 < NT) pr[(J - 2) % 4] = pr[(J - 2) % 4]*pr[(J - 2) % 4];
 	if constexpr (J >= 3) s2 += pr[(J - 3) % 4];
@@ -293,10 +296,10 @@ __device__ __forceinline__ void geo_pc1(const double (&w)[2*R+1][2*R+1], GeoLds 
 	(geo_pc1_step<R, TWD, KG, J>(w, tg, g, pr, mL, tw, wmin), ...);
 }
 template <int R, int TWD, int KG, int... J>
-__device__ __forceinline__ void geo_pc2(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double mL, double &s2,
+__device__ __forceinline__ void geo_pc2(const double (&w)[2*R+1][2*R+1], GeoLds tg, double (&g)[KG], double mL, double &s2, double &sa,
                                         std::integer_sequence<int, J...>) {
-	double pr[4];
-	(geo_pc2_step<R, TWD, KG, J>(w, tg, g, pr, mL, s2), ...);
+	double pr[4], fa[2];
+	(geo_pc2_step<R, TWD, KG, J>(w, tg, g, pr, mL, s2, fa, sa), ...);
 }
 
 template <int R, bool WIMG>
@@ -476,15 +479,16 @@ void geodesic_reg_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 		geo_pc1<R, TWD, KG>(w, tg, g, mL, tw, wmin, std::make_integer_sequence<int, NT + 2>{});
 		bool all = mL == mL && wmin > P.weight_cutoff;
 		GEO_STAMP(5)
-		double s2 = 0;
+		double s2 = 0, sa = 0;
 		if (all && !(tw < 1e-10)) {
 			mL /= tw;
 			geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
-			geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, std::make_integer_sequence<int, NT + 3>{});
+			geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, sa, std::make_integer_sequence<int, NT + 3>{});
 			GEO_STAMP(6)
 		} else all = false;
-		double *pc = pconst + ((size_t)trow*W + cx)*4;
+		double *pc = pconst + ((size_t)trow*W + cx)*SRH_PC;
 		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
+		pc[4] = sa; pc[5] = 0.0;
 	}
 #ifdef SRH_PROFILE_PHASES
 	GEO_STAMP(3)
@@ -677,14 +681,15 @@ void geodesic_dma_kernel(const ViewDev *__restrict__ views, int ref, const doubl
 			geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
 			geo_pc1<R, TWD, KG>(w, tg, g, mL, tw, wmin, std::make_integer_sequence<int, NT + 2>{});
 			bool all = mL == mL && wmin > P.weight_cutoff;
-			double s2 = 0;
+			double s2 = 0, sa = 0;
 			if (all && !(tw < 1e-10)) {
 				mL /= tw;
 				geo_pc_fill<R, TWD, KG>(tg, g, std::make_integer_sequence<int, KG>{});
-				geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, std::make_integer_sequence<int, NT + 3>{});
+				geo_pc2<R, TWD, KG>(w, tg, g, mL, s2, sa, std::make_integer_sequence<int, NT + 3>{});
 			} else all = false;
-			double *pc = pconst + ((size_t)trow*W + cx)*4;
+			double *pc = pconst + ((size_t)trow*W + cx)*SRH_PC;
 			pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
+			pc[4] = sa; pc[5] = 0.0;
 		}
 	}
 }
@@ -770,7 +775,7 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 		}
 	}
 	if (pconst) {
-		double s2 = 0;
+		double s2 = 0, sa = 0;
 		if (all && !(tw < 1e-10)) {
 			mL /= tw;
 #pragma unroll 1
@@ -779,11 +784,12 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 #pragma unroll
 				for (int b = 0; b < WS; ++b) wr[b] = wb[(size_t)(a*WS + b)*wstride];
 #pragma unroll
-				for (int b = 0; b < WS; ++b) { const double t = wr[b]*gt[a][i + b] - mL; s2 += t*t; }
+				for (int b = 0; b < WS; ++b) { const double t = wr[b]*gt[a][i + b] - mL; s2 += t*t; sa += __builtin_fma(wr[b], gt[a][i + b], -mL); }   // (sa: fused terms, SRH_PC)
 			}
 		} else all = false;
-		double *pc = pconst + ((size_t)trow*W + cx)*4;
+		double *pc = pconst + ((size_t)trow*W + cx)*SRH_PC;
 		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
+		pc[4] = sa; pc[5] = 0.0;
 	}
 }
 
@@ -876,7 +882,7 @@ struct DenseSmem {
 	double w[DC_TP][WPIX];                                  // w[pixel][row*WP + col]
 	double rt[WS][RW];
 	double lt[WS][LW];
-	double meanL[DC_TP], totalW[DC_TP], sum2[DC_TP];
+	double meanL[DC_TP], totalW[DC_TP], sum2[DC_TP], sumA[DC_TP];   // (sumA: pconst slot 4, the one-pass form's SA)
 	int lall[DC_TP];
 	int pxmin[DC_TP], pxmax[DC_TP];                         // candidate range of each pixel (empty: max < min)
 	unsigned char rfull[RW];
@@ -1026,10 +1032,10 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		const int gx = x0 - R + tx, gy = y - R + ty;
 		tl_[k] = (idx < WS*Smem::LW && gx >= 0 && gy >= 0 && gx < W && gy < H) ? L.gray_tv[(size_t)gy*W + gx] : nan;
 	}
-	double pc_[4] = { 0.0, 0.0, 0.0, 0.0 };
+	double pc_[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
 	if (g == 0 && x < W) {
-		const double *pc = pconst + ((size_t)trow*W + x)*4;
-		pc_[0] = pc[0]; pc_[1] = pc[1]; pc_[2] = pc[2]; pc_[3] = pc[3];
+		const double *pc = pconst + ((size_t)trow*W + x)*SRH_PC;
+		pc_[0] = pc[0]; pc_[1] = pc[1]; pc_[2] = pc[2]; pc_[3] = pc[3]; pc_[4] = pc[4];
 	}
 	// ---- union of the candidate ranges of the tile (one global load, one LDS reduction)
 	__shared__ int s_cmin, s_cmax, s_need_pix, s_need_col;
@@ -1085,7 +1091,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	SRH_STAMP(1);
 
 	// ---- per-pixel constants of the fast form: computed by the weights kernel while the window was in registers
-	// (geodesic_reg_kernel / weights_kernel, `pconst`), 4 doubles per pixel
+	// (geodesic_reg_kernel / weights_kernel, `pconst`), SRH_PC doubles per pixel
 	if (g == 0) {
 		bool all = (x < W) && (e.xmax >= e.xmin);
 		double mL = 0, tw = 0, s2 = 0;
@@ -1094,6 +1100,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 			all = pc_[3] != 0.0;
 		}
 		S.meanL[i] = mL; S.totalW[i] = (ONEPASS && all) ? pc_[3] : tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0;   // (one-pass form: 1/totalWeight, pconst slot 3)
+		S.sumA[i] = all ? pc_[4] : 0.0;
 		if (!all && x < W && e.xmax >= e.xmin) s_need_pix = 1;      // this pixel needs the general form
 	}
 	SRH_STAMP(2);
@@ -1180,7 +1187,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 					// certified one-pass form (twoview_strip_cost_kernel): P = sum w r, Q = sum ((w l - meanL) w) r, U = sum w^2 r^2
 					const double mL = CS.meanL[i], itw = CS.totalW[i], s2 = CS.sum2[i];   // (this form keeps 1/totalWeight there)
 					const double sig3 = cb.sigma3(s2);
-					double r[NR], q[NR], wv[WS], lv[WS], P_[DC_NCB], Q_[DC_NCB], U_[DC_NCB], SA = 0.0;
+					double r[NR], q[NR], wv[WS], lv[WS], P_[DC_NCB], Q_[DC_NCB], U_[DC_NCB];
 					{
 						const double *rp = &CS.rt[0][rc];
 						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
@@ -1208,7 +1215,6 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 							q[col + DC_NCB - 1] = r[col + DC_NCB - 1]*r[col + DC_NCB - 1];
 							const double a = __builtin_fma(wv[col], lv[col], -mL);
 							const double c = a*wv[col], d = wv[col]*wv[col];
-							SA += a;
 							__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 							for (int j = 0; j < DC_NCB; ++j) P_[j] = __builtin_fma(wv[col], r[col + j], P_[j]);
@@ -1232,7 +1238,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 #pragma unroll
 					for (int j = 0; j < DC_NCB; ++j) {
 						bool okc;                              // (every candidate finished, only the store masked: as in the strip kernel)
-						const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, itw, s2, TT, sig3, cb.zmax2, okc);
+						const double v = onepass_finish(P_[j], Q_[j], U_[j], CS.sumA[i], itw, s2, TT, sig3, cb.zmax2, okc);
 						if ((vm >> j) & 1u) crow[(size_t)(c0 + j - e.xmin)*DC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
 					}
 				} else if (fast) {
@@ -1692,7 +1698,7 @@ void twoview_scan_tile(const int bid, const ViewDev *__restrict__ views, int ref
 		// cost kernel evaluated in the reference's arithmetic throughout (cert_pixel_exact) -- every stored cost is the
 		// reference's own number, every comparison on them is the reference's
 		bool px_sure = false;
-		if (CERT && pexact) { const double *pc = pexact + ((size_t)trow*W + x)*4; px_sure = cert_pixel_exact(cb, pc[2], pc[3]); }
+		if (CERT && pexact) { const double *pc = pexact + ((size_t)trow*W + x)*SRH_PC; px_sure = cert_pixel_exact(cb, pc[2], pc[3]); }
 
 		// consume `count` queued candidates (count == SC_QN except for the final, partial flush)
 		auto flush = [&](int count) {
@@ -2139,7 +2145,7 @@ bool twoview_tscan_tile(const int bid, const ViewDev *__restrict__ views, int re
 		double minCost = __builtin_inf(), secondBest = __builtin_inf();
 		int wcol = -1;
 		bool px_sure = false;
-		if (CERT && pexact) { const double *pc = pexact + ((size_t)trow*W + x)*4; px_sure = cert_pixel_exact(cb, pc[2], pc[3]); }
+		if (CERT && pexact) { const double *pc = pexact + ((size_t)trow*W + x)*SRH_PC; px_sure = cert_pixel_exact(cb, pc[2], pc[3]); }
 		const int xm = tid - smin;                                     // smask index of column x + s: tid + (s - smin)
 		const int xlo = x - lo;                                        // cost-row entry of column x + s: s + xlo
 		int nSe = nS;

@@ -135,7 +135,7 @@ void twoview_dense_cost_f32_kernel(const ViewDev *__restrict__ views, int ref, i
 	}
 	double pc_[4] = { 0.0, 0.0, 0.0, 0.0 };
 	if (g == 0 && x < W) {
-		const double *pc = pconst + ((size_t)trow*W + x)*4;
+		const double *pc = pconst + ((size_t)trow*W + x)*SRH_PC;
 		pc_[0] = pc[0]; pc_[1] = pc[1]; pc_[2] = pc[2]; pc_[3] = pc[3];
 	}
 	__syncthreads();

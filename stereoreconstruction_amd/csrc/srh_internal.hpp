@@ -201,7 +201,11 @@ struct Extent { int32_t xmin, xmax; };
 void launch_prep_view(hipStream_t st, const uint32_t *rgba, const uint8_t *mask, int w, int h,
                       double *gray, double *gray_tv);
 void launch_fill(hipStream_t st, double *p, size_t n, double v);
-// pconst (optional): 4 doubles per pixel of the band -- meanL, totalWeight, sum2, all-taps-usable (0, or 1/totalWeight) -- the per-pixel
+// doubles per pixel of `pconst`: meanL, totalWeight, sum2, [3] 0 / 1/totalWeight, [4] SA = sum of fma(w_t, l_t, -meanL) (the
+// one-pass form's sum1 = Q - m*SA; FUSED terms: an unfused w*l - meanL carries an absolute error u*|w*l| per tap, which at a
+// small sum2 is beyond the certificate's bound), [5] pad (rows of 48 bytes: every tile's piece starts 16-byte aligned)
+#define SRH_PC 6
+// pconst (optional): SRH_PC doubles per pixel of the band -- meanL, totalWeight, sum2, all-taps-usable (0, or 1/totalWeight), SA -- the per-pixel
 // constants of the dense cost kernel's fast form, computed while the window is at hand
 void launch_weights(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P,
                     int y0, int nrows, double *wbuf, size_t wstride, double *pconst = nullptr, bool wimg = false);

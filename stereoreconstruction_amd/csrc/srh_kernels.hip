@@ -155,17 +155,20 @@ __global__ void weights_kernel(const ViewDev *__restrict__ views, int ref, srh_p
 				mL += wt*gl;
 				tw += wt;
 			}
-		double s2 = 0;
+		double s2 = 0, sa = 0;
 		if (all && !(tw < 1e-10)) {
 			mL /= tw;
 			for (int row = -R; row <= R; ++row)
 				for (int col = -R; col <= R; ++col) {
-					const double t = WTAP(row + R, col + R)*V.gray_tv[(size_t)(cy + row)*W + (cx + col)] - mL;
+					const double wt_ = WTAP(row + R, col + R), gl_ = V.gray_tv[(size_t)(cy + row)*W + (cx + col)];
+					const double t = wt_*gl_ - mL;
 					s2 += t*t;
+					sa += __builtin_fma(wt_, gl_, -mL);                      // (fused: srh_internal.hpp, SRH_PC)
 				}
 		} else all = false;
-		double *pc = pconst + ((size_t)(q / W)*W + cx)*4;
+		double *pc = pconst + ((size_t)(q / W)*W + cx)*SRH_PC;
 		pc[0] = mL; pc[1] = tw; pc[2] = s2; pc[3] = all ? 1.0/tw : 0.0;   // all taps usable: != 0, and then 1/totalWeight (the one-pass form multiplies by it)
+		pc[4] = sa; pc[5] = 0.0;
 	}
 #undef WTAP
 }

@@ -117,7 +117,7 @@ int strip_chunk_columns() { return ST_CHUNK; }
 struct StripArgs {
 	int W, H, y0, nrows;                    // reference view size; rows [y0, y0 + nrows) of it
 	const double *wimg;                     // windows of the band, layout B
-	const double *pconst;                   // 4 doubles per pixel of the band: meanL, totalWeight, sum2, all-taps-usable
+	const double *pconst;                   // SRH_PC doubles per pixel of the band: meanL, totalWeight, sum2, 0 | 1/totalWeight, SA, pad
 	const PixRange *prange;                 // candidate column range per pixel of the band
 	const double *ref_tvp, *oth_tvp;        // NaN-bordered gray_tv planes
 	const uint8_t *oth_fullp;               // zero-bordered "window fully usable" plane of the other view
@@ -152,7 +152,7 @@ struct StripSmem {
 	// pad) and a range of 8*16*k columns needs exactly k rounds -- on C3 no column is left to the fill kernel
 	alignas(16) double rto[NBUF == 2 ? NS : 1][RW];
 	alignas(16) double lt[NS][LW];
-	alignas(16) double pc[2][ST_TP][4];
+	alignas(16) double pc[2][ST_TP][SRH_PC];         // meanL, totalWeight, sum2, 0 | 1/totalWeight, SA, pad (srh_internal.hpp)
 	alignas(16) PixRange pr[2][ST_TP];
 	alignas(16) unsigned char full[2][FW];
 	unsigned short glist[GL_CAP];
@@ -420,7 +420,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 		// one tile's own inputs (nothing here depends on the staging origin): constants, ranges, [windows]
 		auto issue_tile_inputs = [&](int r, int buf, int wb, bool consts, bool windows) {
 			const size_t px0 = (size_t)r*W + x0;
-			if (consts && wv == 0) st_dma16(A.pconst + px0*4, &S.pc[buf][0][0], ST_TP*32, lane);
+			if (consts && wv == 0) st_dma16(A.pconst + px0*SRH_PC, &S.pc[buf][0][0], ST_TP*SRH_PC*8, lane);
 			if (consts && wv == 1) st_dma4(A.prange + px0, &S.pr[buf][0], ST_TP*8, lane);
 			if (windows) {
 				const double *wt = A.wimg + ((size_t)r*tiles_per_row + tx)*(size_t)(ST_TP*WPIX);
@@ -715,7 +715,7 @@ void twoview_strip_cost_kernel(const StripArgs A)
 						// ---- certified ONE-PASS form (srh_internal.hpp, CertBound): P = sum w r, Q = sum ((w l - meanL) w) r,
 						// U = sum w^2 r^2 in one sweep over the window; registers are refilled in place a row ahead, as below
 						const double mL = CS.pc[cur][i][0], itw = CS.pc[cur][i][3], s2 = CS.pc[cur][i][2];   // (slot 3 of a pixel with every tap usable: 1/totalWeight)
-						double r_[NR], q_[NR], w_[WS], l_[WS], P_[NCB], Q_[NCB], U_[NCB], SA = 0.0;
+						double r_[NR], q_[NR], w_[WS], l_[WS], P_[NCB], Q_[NCB], U_[NCB];
 						{
 							const double2 *rp = reinterpret_cast<const double2 *>(rbase + s0*RW + rc);
 							const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[wcur][0][i][0]);
@@ -746,7 +746,6 @@ void twoview_strip_cost_kernel(const StripArgs A)
 								q_[col + NCB - 1] = r_[col + NCB - 1]*r_[col + NCB - 1];
 								const double a = __builtin_fma(w_[col], l_[col], -mL);
 								const double c = a*w_[col], d = w_[col]*w_[col];
-								SA += a;
 								__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 								for (int j = 0; j < NCB; ++j) P_[j] = __builtin_fma(w_[col], r_[col + j], P_[j]);
@@ -770,7 +769,9 @@ void twoview_strip_cost_kernel(const StripArgs A)
 						constexpr double TT = (double)(WS*WS);
 						// every candidate of the block is finished (arithmetic on a column outside the range harms nobody); only the
 						// store looks at the candidate's bit -- no LDS read, wait and branch per candidate
-						const double zmax2 = A.cb.zmax2, mhi = A.cb.m_hi, mcd = A.max_color_diff;
+						// (SA = sum of fma(w_t, l_t, -meanL) is the PIXEL's: the weights kernels leave it in pconst slot 4 -- round 5 summed it
+						// again in every block, 121 additions)
+						const double zmax2 = A.cb.zmax2, mhi = A.cb.m_hi, mcd = A.max_color_diff, SA = CS.pc[cur][i][4];
 						const bool redo = A.redo != 0;
 #pragma unroll
 						for (int j = 0; j < NCB; ++j) {
