@@ -180,7 +180,7 @@ def run_c4(args, rank, world, dev, dev_index, backend):
         multiview_sharded(e, C4_VIEWS)
         c.synchronize(); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3
-        c.close()
+        first_held.append(c)                                       # (closed together behind the last sample: see run_twoview's first_call)
         return round(ms, 3)
 
     for _ in range(args.warmup):
@@ -208,7 +208,10 @@ def run_c4(args, rank, world, dev, dev_index, backend):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = ctx.profile()
+    first_held = []
     first_call_samples = [first_call() for _ in range(3)] if world == 1 and not args.no_first_call else None
+    for fc in first_held:
+        fc.close()
     first_call_ms = sorted(first_call_samples)[1] if first_call_samples else None      # (median of three fresh contexts)
     # cost evaluations the reference performs for this rank's views (untimed recount): only masked-in pixels are
     # matched and a curve has as many candidates as its pixel length, so W*H*D*links is neither a bound nor an estimate
@@ -371,11 +374,13 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         sys.exit("--arith fma / f32 apply to the dense row-aligned TwoView path (c2, c3, small)")
     arith_code = {"certified": capi.ARITH_CERTIFIED, "exact": capi.ARITH_EXACT, "fma": capi.ARITH_FMA, "f32": capi.ARITH_F32}[args.arith]
 
-    def first_call():
+    def first_call(keep=None):
         """What a user of the drop-in sees for a NEW pair (TwoViewStereo computes a pair once per object,
         twoviewstereo.cpp:150-227): fresh srh_create + two uploads (untimed, fenced), then ONE srh_twoview_compute timed
         with a fence -- the padded / full / geo5 planes built on first use, every band allocation, the list paths' first
-        sizing of their lists: everything the steady-state steps below no longer pay."""
+        sizing of their lists: everything the steady-state steps below no longer pay.  (keep: the context is handed back
+        open -- a context closed just before the next sample frees tens of GB, and the next multi-GB hipMalloc then waits
+        up to a second for the driver to hand that memory out again: the measurement's own artefact, profiles/r06_first_call.txt)"""
         c = capi.Context(dev_index)
         c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.set_option("arith", arith_code)
@@ -386,13 +391,18 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         c.twoview_compute_device(0, 1, p)
         c.synchronize(); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3
-        c.close()
+        if keep is not None:
+            keep.append(c)
+        else:
+            c.close()
         return round(ms, 3)
 
     def first_calls(n=3):
-        """median of n fresh contexts (a multi-GB hipMalloc now and then waits a second for the driver to hand out VRAM that
-        an earlier process has just released -- profiles/r06_first_call.txt: that is the pool's, not the pair's) + the samples"""
-        v = [first_call() for _ in range(n)]
+        """median of n fresh contexts, all kept open until the last has been measured, + the samples"""
+        held = []
+        v = [first_call(held) for _ in range(n)]
+        for c in held:
+            c.close()
         return sorted(v)[len(v) // 2], v
 
     # the process's very first call (C3 in the default run: kernels' code objects not yet resident either)

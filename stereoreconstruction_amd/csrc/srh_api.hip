@@ -1691,7 +1691,8 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 			c->stats.n_pixels = (int64_t)d1.host->n_pixels;
 			c->stats.n_eval = (int64_t)d1.host->n_eval;
 			c->stats.n_eval_device = (int64_t)d1.host->n_eval_device;
-			c->stats.n_certified = (int64_t)d1.host->n_certified;
+			// (the row-run certified scan counts the pixels it scanned in n_pixels: what the verified list path reports as well)
+			c->stats.n_certified = d1.lists ? (d1.cert ? (int64_t)d1.host->n_pixels : 0) : (int64_t)d1.host->n_certified;
 			c->stats.n_flagged = (int64_t)d1.host->n_flagged;
 			c->stats.used_dense_path = d1.lists ? 0 : 1;
 			c->stats.used_fused_kernel = c->last_fused ? 1 : 0;
