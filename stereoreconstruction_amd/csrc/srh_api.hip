@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <limits>
 #include <vector>
@@ -239,15 +240,85 @@ struct Scope {
 static thread_local bool g_oom = false;
 static thread_local size_t g_alloc_limit = 0;
 
+// ---- the process's pool of band buffers ------------------------------------------------------------------------------
+// A TwoViewStereo / MultiViewStereo object of the reference lives for one computation (twoviewstereo.cpp:150-227; the GUI
+// makes a new one per run), so a drop-in creates and destroys contexts again and again in one process -- and a context's
+// band buffers are gigabytes.  Handing them back to the driver at srh_destroy and asking for them again at the next
+// object's first call is not free on this stack: measured (profiles/r06_first_call.txt, HIP API trace) ONE hipMalloc of 11 GB
+// now and then takes 0.9 ... 1.5 s when tens of GB have just been freed by the same process (its siblings: 0.3 ms).  So band
+// buffers released by srh_destroy (and by a growing buffer) go to a process-wide pool, per device, and the next context's
+// requests are served from it (best fit, at most 1.5x the request); what does not fit the pool's cap is freed.  The pool
+// is emptied before an allocation is declared out of memory, and counts as available memory for the band planner.
+// Option "band_pool_mb" (any context; process-wide): the cap, default 65 536; 0 empties and disables the pool.
+struct PoolBlock { void *p; size_t bytes; int device; };
+static std::mutex g_pool_mu;
+static std::vector<PoolBlock> g_pool;
+static size_t g_pool_bytes = 0, g_pool_cap = (size_t)65536 << 20;
+static const size_t POOL_MIN_BYTES = (size_t)4 << 20;                // smaller buffers are not worth a pool entry
+
+static void pool_flush(int device) {                                 // (device < 0: every device)
+	std::vector<PoolBlock> out;
+	{
+		std::lock_guard<std::mutex> g(g_pool_mu);
+		for (size_t k = 0; k < g_pool.size();)
+			if (device < 0 || g_pool[k].device == device) { out.push_back(g_pool[k]); g_pool_bytes -= g_pool[k].bytes; g_pool[k] = g_pool.back(); g_pool.pop_back(); }
+			else ++k;
+	}
+	int cur = 0;
+	const bool have = hipGetDevice(&cur) == hipSuccess;
+	for (const PoolBlock &b : out) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+	if (have) (void)hipSetDevice(cur);
+}
+static size_t pool_bytes_on(int device) {
+	std::lock_guard<std::mutex> g(g_pool_mu);
+	size_t b = 0;
+	for (const PoolBlock &k : g_pool) if (k.device == device) b += k.bytes;
+	return b;
+}
+// a released band buffer of `bytes` on the current device: into the pool, or back to the driver
+static void pool_give(void *p, size_t bytes) {
+	if (!p) return;
+	int dev = 0;
+	if (bytes >= POOL_MIN_BYTES && hipGetDevice(&dev) == hipSuccess) {
+		std::lock_guard<std::mutex> g(g_pool_mu);
+		if (g_pool_bytes + bytes <= g_pool_cap) { g_pool.push_back({p, bytes, dev}); g_pool_bytes += bytes; return; }
+	}
+	(void)hipFree(p);
+}
+// a block of at least `bytes` (at most 1.5x) from the pool, or null; *got = its size
+static void *pool_take(size_t bytes, size_t *got) {
+	int dev = 0;
+	if (bytes < POOL_MIN_BYTES || hipGetDevice(&dev) != hipSuccess) return nullptr;
+	std::lock_guard<std::mutex> g(g_pool_mu);
+	size_t best = g_pool.size();
+	for (size_t k = 0; k < g_pool.size(); ++k)
+		if (g_pool[k].device == dev && g_pool[k].bytes >= bytes && g_pool[k].bytes <= bytes + bytes/2 &&
+		    (best == g_pool.size() || g_pool[k].bytes < g_pool[best].bytes)) best = k;
+	if (best == g_pool.size()) return nullptr;
+	void *p = g_pool[best].p;
+	*got = g_pool[best].bytes;
+	g_pool_bytes -= g_pool[best].bytes;
+	g_pool[best] = g_pool.back(); g_pool.pop_back();
+	return p;
+}
+
 template <class T>
 static int ensure(T *&ptr, size_t &cap, size_t need) {
 	if (cap >= need) return SRH_OK;
-	if (ptr) { HIP_TRY(hipFree(ptr)); ptr = nullptr; cap = 0; }
+	if (ptr) { pool_give(ptr, cap*sizeof(T)); ptr = nullptr; cap = 0; }   // (nothing in flight reads a buffer that is being outgrown: the callers' streams are ordered)
 	if (g_alloc_limit && need*sizeof(T) > g_alloc_limit) {
 		g_oom = true;
 		return fail(SRH_E_DEVICE, "band buffer of %zu bytes refused (debug_alloc_limit_mb)", need*sizeof(T));
 	}
-	const hipError_t e = hipMalloc((void **)&ptr, need*sizeof(T));
+	size_t got = 0;
+	if (void *q = pool_take(need*sizeof(T), &got)) { ptr = (T *)q; cap = got/sizeof(T); return SRH_OK; }
+	hipError_t e = hipMalloc((void **)&ptr, need*sizeof(T));
+	if (e == hipErrorOutOfMemory) {
+		// the pool's blocks are memory too: give them back and ask once more before the bands get thinner
+		(void)hipGetLastError();
+		int dev = 0;
+		if (hipGetDevice(&dev) == hipSuccess && pool_bytes_on(dev)) { pool_flush(dev); e = hipMalloc((void **)&ptr, need*sizeof(T)); }
+	}
 	if (e != hipSuccess) {
 		ptr = nullptr;
 		(void)hipGetLastError();
@@ -579,11 +650,11 @@ extern "C" void srh_destroy(srh_context *c) {
 		if (S.ev) hipEventDestroy(S.ev);
 		if (S.done) hipEventDestroy(S.done);
 		if (S.h_maxc) hipHostFree(S.h_maxc);
-		if (S.wbuf) hipFree(S.wbuf);
-		if (S.cost) hipFree(S.cost);
+		pool_give(S.wbuf, S.wbuf_cap*sizeof(double));
+		pool_give(S.cost, S.cost_cap*sizeof(double));
 		if (S.tnum) hipFree(S.tnum);
-		if (S.lcount) hipFree(S.lcount);
-		if (S.lcand) hipFree(S.lcand);
+		pool_give(S.lcount, S.lcount_cap*sizeof(int32_t));
+		pool_give(S.lcand, S.lcand_cap*sizeof(uint32_t));
 		if (S.mvs_wdesc) hipFree(S.mvs_wdesc);
 		if (S.mvs_nwin) hipFree(S.mvs_nwin);
 		if (S.d_cnt) hipFree(S.d_cnt);
@@ -594,12 +665,15 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->d_slots) hipFree(c->d_slots);
 	if (c->d_cnt) hipFree(c->d_cnt);
 	if (c->d_span) hipFree(c->d_span);
-	if (c->wbuf) hipFree(c->wbuf);
-	if (c->cost) hipFree(c->cost);
+	// (every stream of the context has been waited for above: its band buffers are idle and go to the process's pool)
+	(void)hipStreamSynchronize(c->stream);
+	if (c->tv_slot.stream) (void)hipStreamSynchronize(c->tv_slot.stream);
+	pool_give(c->wbuf, c->wbuf_cap*sizeof(double));
+	pool_give(c->cost, c->cost_cap*sizeof(double));
 	if (c->tnum) hipFree(c->tnum);
-	if (c->pconst) hipFree(c->pconst);
-	if (c->prange) hipFree(c->prange);
-	if (c->cflag) hipFree(c->cflag);
+	pool_give(c->pconst, c->pconst_cap*sizeof(double));
+	pool_give(c->prange, c->prange_cap*sizeof(PixRange));
+	pool_give(c->cflag, c->cflag_cap*sizeof(uint32_t));
 	if (c->stpl) hipFree(c->stpl);
 	if (c->tileflag) hipFree(c->tileflag);
 	for (auto &d : c->tv_defer) { if (d.host) hipHostFree(d.host); if (d.span) hipHostFree(d.span); }
@@ -611,15 +685,15 @@ extern "C" void srh_destroy(srh_context *c) {
 		if (T.d_cnt) hipFree(T.d_cnt);
 		if (T.d_span) hipFree(T.d_span);
 		if (T.tnum) hipFree(T.tnum);
-		if (T.wbuf) hipFree(T.wbuf);
-		if (T.cost) hipFree(T.cost);
-		if (T.pconst) hipFree(T.pconst);
-		if (T.prange) hipFree(T.prange);
-		if (T.cflag) hipFree(T.cflag);
-		if (T.lcand) hipFree(T.lcand);
-		if (T.lrowinfo) hipFree(T.lrowinfo);
-		if (T.lcount) hipFree(T.lcount);
-		if (T.lmeta) hipFree(T.lmeta);
+		pool_give(T.wbuf, T.wbuf_cap*sizeof(double));
+		pool_give(T.cost, T.cost_cap*sizeof(double));
+		pool_give(T.pconst, T.pconst_cap*sizeof(double));
+		pool_give(T.prange, T.prange_cap*sizeof(PixRange));
+		pool_give(T.cflag, T.cflag_cap*sizeof(uint32_t));
+		pool_give(T.lcand, T.lcand_cap*sizeof(uint32_t));
+		pool_give(T.lrowinfo, T.lrowinfo_cap*sizeof(uint32_t));
+		pool_give(T.lcount, T.lcount_cap*sizeof(int32_t));
+		pool_give(T.lmeta, T.lmeta_cap*sizeof(int32_t));
 		if (T.stpl) hipFree(T.stpl);
 		if (T.tileflag) hipFree(T.tileflag);
 	}
@@ -627,10 +701,10 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->mrf_peaks) hipFree(c->mrf_peaks);
 	for (int i = 0; i < SRH_MAX_VIEWS; ++i) if (c->mrf_stream[i]) hipStreamDestroy(c->mrf_stream[i]);
 	if (c->mrf_host) hipHostFree(c->mrf_host);
-	if (c->lcount) hipFree(c->lcount);
-	if (c->lcand) hipFree(c->lcand);
-	if (c->lrowinfo) hipFree(c->lrowinfo);
-	if (c->lmeta) hipFree(c->lmeta);
+	pool_give(c->lcount, c->lcount_cap*sizeof(int32_t));
+	pool_give(c->lcand, c->lcand_cap*sizeof(uint32_t));
+	pool_give(c->lrowinfo, c->lrowinfo_cap*sizeof(uint32_t));
+	pool_give(c->lmeta, c->lmeta_cap*sizeof(int32_t));
 	if (c->mvs_wdesc) hipFree(c->mvs_wdesc);
 	if (c->mvs_nwin) hipFree(c->mvs_nwin);
 	if (c->comm) (void)rccl_comm_destroy(c->comm);
@@ -684,6 +758,13 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	// tests of the budget logic: pretend the device has only `value` MB to give / refuse band buffers above `value` MB
 	if (!strcmp(name, "mem_limit_mb")) { c->mem_limit = value > 0 ? (size_t)value << 20 : 0; return SRH_OK; }
 	if (!strcmp(name, "debug_trace")) { c->debug_trace = (int)value; return SRH_OK; }
+	if (!strcmp(name, "band_pool_mb")) {
+		// process-wide: how many bytes of released band buffers wait for the next context (0: none, and what waits now is freed)
+		if (value < 0) return fail(SRH_E_INVALID, "band_pool_mb must be >= 0");
+		{ std::lock_guard<std::mutex> g(g_pool_mu); g_pool_cap = (size_t)value << 20; }
+		if (value == 0) pool_flush(-1);
+		return SRH_OK;
+	}
 	if (!strcmp(name, "debug_alloc_limit_mb")) {
 		c->alloc_limit = g_alloc_limit = value > 0 ? (size_t)value << 20 : 0;
 		// the band buffers a bigger run left behind would serve every later request without an allocation: start afresh
@@ -841,7 +922,7 @@ static size_t band_budget(srh_context *c) {
 	if (c->budget_cap && b > c->budget_cap) b = c->budget_cap;
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-		size_t avail = free_b + held_band_bytes(c);
+		size_t avail = free_b + held_band_bytes(c) + pool_bytes_on(c->device);   // (the pool's blocks are this context's to take)
 		if (c->mem_limit && avail > c->mem_limit) avail = c->mem_limit;
 		if (b > avail/4) b = avail/4;
 	} else (void)hipGetLastError();
@@ -851,6 +932,7 @@ static size_t band_budget(srh_context *c) {
 }
 
 static void release_band_buffers(srh_context *c) {
+	pool_flush(c->device);                                        // (out of memory: the pool's blocks go back to the driver first)
 	auto drop = [](auto *&p, size_t &cap) { if (p) (void)hipFree(p); p = nullptr; cap = 0; };
 	drop(c->wbuf, c->wbuf_cap); drop(c->cost, c->cost_cap); drop(c->pconst, c->pconst_cap); drop(c->prange, c->prange_cap);
 	drop(c->lcount, c->lcount_cap); drop(c->lcand, c->lcand_cap); drop(c->lrowinfo, c->lrowinfo_cap); drop(c->lmeta, c->lmeta_cap);
