@@ -1389,7 +1389,10 @@ void mvs_staged_cost_kernel(const ViewDev *__restrict__ views, int ref, NeighLis
 #pragma unroll
 				for (int k = 0; k < MS_CA - 1; ++k) { mR += mRx[k]; mRx[k] = 0; s3x[k] = 0; }
 			}
-			mR = div_by(mR, twd);                                        // mR / tw, the same bits (srh_walk.hpp)
+			// exact form: mR / tw, the same bits (srh_walk.hpp).  Certified form: the product with the refined reciprocal of tw
+			// (within one ulp of 1/tw: one more rounding on meanR, which eps_b = gamma_(T+4)*G has room for -- T for the sum, one
+			// each for the quotient, the product, the subtraction); the unit's tw lies in [1, 25]
+			mR = (CERT && twd.ok) ? mR*twd.r : div_by(mR, twd);
 #pragma unroll
 			for (int row = 0; row < WS; ++row) {
 				if (CERT) {

@@ -98,7 +98,8 @@ def cost_two_fused_sweeps(w, l, r, mL, tw, s2, a_shared, scale, partial=1):
     acc = accs[0]
     for k in range(1, partial):
         acc += accs[k]
-    mR = acc / tw
+    # (MultiViewStereo's certified kernel multiplies by the refined reciprocal of tw -- within an ulp of 1/tw -- instead of dividing)
+    mR = acc / tw if scale == 255 else acc * (1.0 / tw)
     s1 = [0.0] * partial
     s3 = [0.0] * partial
     for t, (wt, lt, rt) in enumerate(zip(w, l, r)):
