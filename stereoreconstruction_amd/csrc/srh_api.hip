@@ -1299,6 +1299,10 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				if ((rc = ensure(c->cost, c->cost_cap, (rows_mode ? px32 : lrows*W)*(size_t)ccap))) return rc;
 				if ((rc = ensure(c->lcand, c->lcand_cap, (rows_mode ? px64 : lrows*W)*(size_t)cmax))) return rc;
 				const bool rows_cert = rows_mode && cert_ok;
+				// the row-run cost kernel takes the pixels' constants (meanL, totalWeight, sum2, 1/totalWeight, SA) from the weights
+				// kernel, which has the window in registers anyway, instead of making them on one lane in eight per tile
+				const bool rows_pc = rows_mode;
+				if (rows_pc && (rc = ensure(c->pconst, c->pconst_cap, (lrows*(size_t)W + SRH_WTILE)*SRH_PC))) return rc;
 				if (rows_mode) {
 					if ((rc = ensure(c->lrowinfo, c->lrowinfo_cap, px64*(size_t)SRH_ROWS_NR))) return rc;
 					if ((rc = ensure(c->lmeta, c->lmeta_cap, lrows*W))) return rc;
@@ -1336,15 +1340,16 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						if (c->side_weights) {
 							HIP_TRY(hipStreamWaitEvent(c->side_stream, c->side_go, 0));
 							std::swap(c->stream, c->side_stream);
-							run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+							run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr);
 							std::swap(c->stream, c->side_stream);
 							HIP_TRY(hipEventRecord(c->side_done, c->side_stream));
 							HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
-						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE);
+						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr);
 						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
-						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? (c->cert_form == 1 ? 5 : 3) : 0); }
+						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? (c->cert_form == 1 ? 5 : 3) : 0,
+						                           rows_pc ? c->pconst : nullptr); }
 						{ Scope s(c, "twoview_rows_scan_kernel");
 						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, rows_cert ? c->cflag : nullptr, -1, c->d_cnt); }

@@ -318,7 +318,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
                               int y0, int nrows, const double *__restrict__ wbuf,
                               const uint8_t *__restrict__ full_oth,
                               const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
-                              double *__restrict__ cost, int smax, Counters *__restrict__ cnt, const CertBound cb)
+                              double *__restrict__ cost, int smax, Counters *__restrict__ cnt, const CertBound cb,
+                              const double *__restrict__ pconst)
 {
 	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;   // 5: the certified ONE-PASS form (srh_internal.hpp, CertBound)
 	constexpr int WS = 2*R + 1;
@@ -395,8 +396,21 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	}
 	__syncthreads();
 
-	// ---- per-pixel constants of the all-taps-usable form (one lane per pixel)
-	if (g == 0) {
+	// ---- per-pixel constants of the all-taps-usable form (one lane per pixel).  pconst (round 6): the weights kernel has made
+	// them while the window was in its registers (the same operations in the same tap order: the same bits; SRH_PC doubles per
+	// pixel) -- computed here they are two 121-tap loops on one lane in eight with the workgroup waiting, 7 % of the kernel on C5
+	if (g == 0 && pconst) {
+		const double *pc = pconst + ((size_t)trow*W + (x < W ? x : W - 1))*SRH_PC;
+		const bool all = (x < W) && (S.meta[i] >> 16) > 0 && pc[3] != 0.0;
+		S.meanL[i] = pc[0]; S.totalW[i] = (ONEPASS && all) ? pc[3] : pc[1]; S.sum2[i] = pc[2]; S.lall[i] = all ? 1 : 0; S.sumA[i] = pc[4];
+		const int nr = S.meta[i] >> 16;
+		int nblk = 0;
+		for (int r = 0; r < nr; ++r) {
+			S.blk0[i][r] = (unsigned short)nblk;
+			nblk += ((int)(S.rowinfo[i][r] >> 16) + RC_NCB - 1)/RC_NCB;
+		}
+		S.blk0[i][nr] = (unsigned short)nblk;
+	} else if (g == 0) {
 		bool all = (x < W) && (S.meta[i] >> 16) > 0;
 		double mL = 0, tw = 0;
 #pragma unroll 1
@@ -775,7 +789,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
-                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith)
+                              const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith,
+                              const double *pconst)
 {
 	const int tiles = (width + RC_TP - 1)/RC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
@@ -786,7 +801,7 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 		(void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR, AA>,                           \
 		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>));            \
 		hipLaunchKernelGGL((twoview_rows_cost_kernel<RR, AA>), grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
-		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb);  \
+		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb, pconst);  \
 		return true;                                                                                        \
 	}
 #define SRH_RC_LAUNCH(RR) { if (arith == 5) SRH_RC_LAUNCH2(RR, 5) else if (arith == 3) SRH_RC_LAUNCH2(RR, 3) else SRH_RC_LAUNCH2(RR, 0) }
