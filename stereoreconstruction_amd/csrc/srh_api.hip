@@ -305,7 +305,9 @@ static void *pool_take(size_t bytes, size_t *got) {
 template <class T>
 static int ensure(T *&ptr, size_t &cap, size_t need) {
 	if (cap >= need) return SRH_OK;
-	if (ptr) { pool_give(ptr, cap*sizeof(T)); ptr = nullptr; cap = 0; }   // (nothing in flight reads a buffer that is being outgrown: the callers' streams are ordered)
+	// (a buffer that is being outgrown: hipFree used to wait for the device before it let go of it; the pool must not hand it to
+	// another context while a kernel queued earlier still reads it -- growth is rare, the wait is kept)
+	if (ptr) { (void)hipDeviceSynchronize(); pool_give(ptr, cap*sizeof(T)); ptr = nullptr; cap = 0; }
 	if (g_alloc_limit && need*sizeof(T) > g_alloc_limit) {
 		g_oom = true;
 		return fail(SRH_E_DEVICE, "band buffer of %zu bytes refused (debug_alloc_limit_mb)", need*sizeof(T));
@@ -616,16 +618,27 @@ extern "C" int srh_create(int device, srh_context **out) {
 	return SRH_OK;
 }
 
+// a view plane: from the process's pool when it holds a block of that size, else from the driver (the planes of a 1920 x 1080
+// view are 230 MB: released and asked for again with every stereo object, like the band buffers)
+static hipError_t plane_alloc(void **p, size_t bytes) {
+	size_t got = 0;
+	if (void *q = pool_take(bytes, &got)) { *p = q; return hipSuccess; }
+	return hipMalloc(p, bytes);
+}
+
+// (hipFree waited for the device before it released a plane; so does this, before a plane can reach another context)
 static void free_view(ViewHost &v) {
-	if (v.rgba) hipFree(v.rgba);
+	const size_t n = (size_t)v.w*v.h;
+	if (v.rgba || v.gray || v.edges || v.tvp || v.geo5) (void)hipDeviceSynchronize();
+	pool_give(v.rgba, n*4);
 	if (v.mask) hipFree(v.mask);
-	if (v.gray) hipFree(v.gray);
-	if (v.gray_tv) hipFree(v.gray_tv);
-	if (v.depth) hipFree(v.depth);
-	if (v.edges) hipFree(v.edges);
+	pool_give(v.gray, n*sizeof(double));
+	pool_give(v.gray_tv, n*sizeof(double));
+	pool_give(v.depth, n*sizeof(double));
+	pool_give(v.edges, 4*n*sizeof(double));
 	if (v.full) hipFree(v.full);
-	if (v.tvp) hipFree(v.tvp);
-	if (v.geo5) hipFree(v.geo5);
+	pool_give(v.tvp, v.tvp ? padded_size(v.w, v.h)*sizeof(double) : 0);
+	pool_give(v.geo5, v.geo5 ? geo5_doubles(v.w, v.h)*sizeof(double) : 0);
 	if (v.fullp) hipFree(v.fullp);
 	if (v.peaks) hipFree(v.peaks);
 	if (v.mrf) hipFree(v.mrf);
@@ -666,6 +679,7 @@ extern "C" void srh_destroy(srh_context *c) {
 	if (c->d_cnt) hipFree(c->d_cnt);
 	if (c->d_span) hipFree(c->d_span);
 	// (every stream of the context has been waited for above: its band buffers are idle and go to the process's pool)
+	(void)hipDeviceSynchronize();
 	(void)hipStreamSynchronize(c->stream);
 	if (c->tv_slot.stream) (void)hipStreamSynchronize(c->tv_slot.stream);
 	pool_give(c->wbuf, c->wbuf_cap*sizeof(double));
@@ -811,12 +825,12 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 	if (!v.present || v.w != w || v.h != h) {
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		free_view(v);
-		HIP_TRY(hipMalloc((void **)&v.rgba, n*4));
+		HIP_TRY(plane_alloc((void **)&v.rgba, n*4));
 		HIP_TRY(hipMalloc((void **)&v.mask, n));
-		HIP_TRY(hipMalloc((void **)&v.gray, n*sizeof(double)));
-		HIP_TRY(hipMalloc((void **)&v.gray_tv, n*sizeof(double)));
-		HIP_TRY(hipMalloc((void **)&v.depth, n*sizeof(double)));
-		HIP_TRY(hipMalloc((void **)&v.edges, 4*n*sizeof(double)));
+		HIP_TRY(plane_alloc((void **)&v.gray, n*sizeof(double)));
+		HIP_TRY(plane_alloc((void **)&v.gray_tv, n*sizeof(double)));
+		HIP_TRY(plane_alloc((void **)&v.depth, n*sizeof(double)));
+		HIP_TRY(plane_alloc((void **)&v.edges, 4*n*sizeof(double)));
 		HIP_TRY(hipMalloc((void **)&v.full, n));
 		v.w = w; v.h = h; v.present = true;
 	}
@@ -1057,7 +1071,7 @@ static void run_weights(srh_context *c, int ref, int W, const srh_params &p, int
 		ViewHost &v = c->views[ref];
 		bool ok = true;
 		if (!v.geo5) {
-			if (hipMalloc((void **)&v.geo5, geo5_doubles(v.w, v.h)*sizeof(double)) != hipSuccess) { (void)hipGetLastError(); v.geo5 = nullptr; ok = false; }   // (no room: the register-staged kernel needs no second copy)
+			if (plane_alloc((void **)&v.geo5, geo5_doubles(v.w, v.h)*sizeof(double)) != hipSuccess) { (void)hipGetLastError(); v.geo5 = nullptr; ok = false; }   // (no room: the register-staged kernel needs no second copy)
 			v.geo5_valid = false;
 		}
 		if (ok && !v.geo5_valid) {
@@ -1311,7 +1325,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						// NaN-bordered planes of both views: the general cost of the certified redo reads them without bound tests
 						for (int k = 0; k < 2; ++k) {
 							ViewHost &v = c->views[k == 0 ? ref : oth];
-							if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
+							if (!v.tvp) HIP_TRY(plane_alloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
 							if (!v.tvp_valid) {
 								Scope s(c, "padded_plane_kernel");
 								launch_padded_plane(c->stream, v.gray_tv, v.w, v.h, v.tvp);
@@ -1484,7 +1498,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 			// certified redo on either dense path)
 			for (int k = 0; k < 2; ++k) {
 				ViewHost &v = c->views[k == 0 ? ref : oth];
-				if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
+				if (!v.tvp) HIP_TRY(plane_alloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
 				if (!v.tvp_valid) {
 					Scope s(c, "padded_plane_kernel");
 					launch_padded_plane(c->stream, v.gray_tv, v.w, v.h, v.tvp);
@@ -1708,7 +1722,7 @@ extern "C" int srh_twoview_compute(srh_context *c, int left, int right, const sr
 		if (p->window_radius == 5 || p->window_radius == 2)
 			for (int k = 0; k < 2; ++k) {
 				ViewHost &v = c->views[k == 0 ? left : right];
-				if (!v.tvp) HIP_TRY(hipMalloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
+				if (!v.tvp) HIP_TRY(plane_alloc((void **)&v.tvp, padded_size(v.w, v.h)*sizeof(double)));
 				if (!v.tvp_valid) {
 					Scope s(c, "padded_plane_kernel");
 					launch_padded_plane(c->stream, v.gray_tv, v.w, v.h, v.tvp);
