@@ -31,6 +31,39 @@ def _setup(ctx, W, H, D, seed, wkind):
     return (L, R, ml, mr), cams3, p, op
 
 
+def test_c2_whole_maps_and_cross_check_against_the_oracle(hip_ctx):
+    """C2 -- a BASELINE configuration (640x480, 64 levels, AdaptiveWeight r = 5) -- IN FULL against the oracle: both WTA maps,
+    every pixel (the oracle's rows on 16 host threads, ~10 s), then srh_twoview_compute (both passes + the ordered
+    cross-check, as TwoViewStereo::computeDepthMaps runs them) against the oracle's cross-check of its own two maps."""
+    from concurrent.futures import ThreadPoolExecutor
+    W, H, D = 640, 480, 64
+    (L, R, ml, mr), cams3, p, op = _setup(hip_ctx, W, H, D, 0x5EED0002, capi.WEIGHT_ADAPTIVE)
+    (Kl, Rl, tl), (Kr, Rr, tr) = cams3
+    oi = [O.OImage(L, ml), O.OImage(R, mr)]
+    oc = [O.camera_set(Kl, Rl, tl), O.camera_set(Kr, Rr, tr)]
+    bands = [(y, min(H, y + 8)) for y in range(0, H, 8)]
+
+    def whole(ref, oth):
+        with ThreadPoolExecutor(max_workers=16) as ex:
+            parts = list(ex.map(lambda b: O.twoview_wta(oi[ref], oi[oth], oc[ref], oc[oth], op, b[0], b[1]), bands))
+        out = np.full((H, W), np.nan)
+        for (a, b), m in zip(bands, parts):
+            out[a:b] = m[a:b]
+        return out
+    want = [whole(0, 1), whole(1, 0)]
+    for ref, oth in ((0, 1), (1, 0)):
+        hip_ctx.twoview_wta(ref, oth, p)
+        assert hip_ctx.stats()["used_dense_path"]
+        ok, msg, _ = cases.compare_depth(hip_ctx.download_depth(ref), want[ref], 1e-9)
+        assert ok, (ref, msg)
+    cl, cr = O.twoview_cross_check(oc[0], oc[1], op, want[0], want[1])
+    dl, dr = hip_ctx.twoview_compute(0, 1, p)
+    for got, w_, tag in ((dl, cl, "left"), (dr, cr, "right")):
+        ok, msg, _ = cases.compare_depth(got, w_, 1e-9)
+        assert ok, ("after the cross-check", tag, msg)
+    assert np.isfinite(cl).mean() > 0.2 and (np.isfinite(want[0]) & ~np.isfinite(cl)).any()
+
+
 def test_c2_full_size_dense_equals_general(hip_ctx):
     """C2: 640x480, 64 levels, AdaptiveWeight r=5, both directions + cross-check."""
     W, H, D = 640, 480, 64
@@ -224,7 +257,7 @@ def test_c4_like_mvs_two_stage_equals_inline_kernel(hip_ctx):
 
 def test_c4_full_size(hip_ctx):
     """C4 at BASELINE size: 8 views 1280x960, 128 uniform levels, r=2, 3 neighbours.  Two-stage kernels ==
-    inline kernel bit for bit (also across a band split); one full-width row PER VIEW against the oracle; the
+    inline kernel bit for bit (also across a band split); 12 stratified full-width rows PER VIEW against the oracle; the
     ordered cross-check chain of all 8 views against the oracle's chain run on the same initial maps."""
     W, H, D, NV = 1280, 960, 128, 8
     cams3 = synthetic.semicircle_rig(NV, W, H, radius=10.0, step_deg=22.5, focal=float(W))
@@ -255,10 +288,15 @@ def test_c4_full_size(hip_ctx):
     ocams = [O.camera_set(K, R, t) for (K, R, t) in cams3]
     op = O.params_mvs(**kw)
     imgs = [O.OImage(rgba[v], masks[v]) for v in range(NV)]
-    for v in range(NV):
-        y = H // 2 + 7 * (v - NV // 2)
-        want, _ = O.mvs_initial_estimate(imgs, ocams, v, neigh[v], op, y, y + 1)
-        ok, msg, _ = _cmp(res["two_stage"][0][v][y], want[y])
+    # 12 stratified full-width rows PER VIEW against the oracle (round 6: one row before): the image's first and last rows
+    # and the rows where the r = 2 window stops crossing them, rows through the sphere's silhouette and its centre
+    from concurrent.futures import ThreadPoolExecutor
+    rows = [0, 1, 2, 3, H // 4 - 3, H // 3 + 1, H // 2 - 40, H // 2 + 7, 2 * H // 3, 3 * H // 4 + 5, H - 3, H - 1]
+    jobs = [(v, y) for v in range(NV) for y in rows]
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        wants = list(ex.map(lambda j: O.mvs_initial_estimate(imgs, ocams, j[0], neigh[j[0]], op, j[1], j[1] + 1)[0][j[1]], jobs))
+    for (v, y), want in zip(jobs, wants):
+        ok, msg, _ = _cmp(res["two_stage"][0][v][y], want)
         assert ok, (v, y, msg)
     # cross-check chain (multiviewstereo.cpp:427-431): the oracle starts from the device's initial maps
     work = [m.copy() for m in res["two_stage"][0]]
