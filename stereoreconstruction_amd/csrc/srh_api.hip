@@ -185,6 +185,7 @@ struct srh_context {
 		       lcount_cap = 0, lmeta_cap = 0, stpl_cap = 0, tileflag_cap = 0;
 	} tv_slot;
 	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
+	int rows_masked = 1;                                // option "rows_masked": 0 = the certified row-run cost kernel evaluates a block in the fast form only when all 8 of its candidates are fast (round 5's rule; A/B and tests)
 	int side_weights = 1;                               // option "side_weights": 0 = the row-run path computes its support windows on the pass's own stream, behind the list kernel (profiling: every kernel's own duration)
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
@@ -791,6 +792,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
 	if (!strcmp(name, "tscan")) { c->tscan = value != 0; return SRH_OK; }
 	if (!strcmp(name, "geodma")) { c->geodma = value != 0; return SRH_OK; }
+	if (!strcmp(name, "rows_masked")) { c->rows_masked = value != 0; return SRH_OK; }
 	if (!strcmp(name, "side_weights")) { c->side_weights = value != 0; return SRH_OK; }
 	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
 	if (!strcmp(name, "debug_mvs_cmax_hint")) { c->mvs_cmax_hint = value > 0 ? (int)((value + 7) & ~7L) : 0; return SRH_OK; }
@@ -1059,6 +1061,11 @@ static int fetch_counters(srh_context *c, int used_dense) {
 		fprintf(stderr, "[srh dbg] rows: tasks %llu fast %llu, rows/pixel %.2f, slots/px %.1f, wave iterations %llu all-fast %llu\n",
 		        h.dbg_phase[6], h.dbg_phase[7], (double)h.dbg_cycles/(double)h.n_pixels, 8.0*h.dbg_phase[6]/(double)h.n_pixels,
 		        h.dbg_blocks, h.dbg_total_cycles);
+	if (h.dbg_phase[6] && !c->last_fused && h.dbg_wave[8])
+		fprintf(stderr, "[srh dbg] rows cost kernel, wave tiles %llu: cycles per tile: staging %.0f  constants %.0f  phase 1 %.0f  p2 blocks %.0f  p2 singles %.0f | tiles with blocks %llu (%llu blocks: %.0f cycles per such tile), with singles %llu (%llu singles: %.0f cycles per such tile); rounds if the tile's tasks were dealt to its 64 lanes: %.2f per tile\n",
+		        h.dbg_wave[8], (double)h.dbg_wave[0]/h.dbg_wave[8], (double)h.dbg_wave[1]/h.dbg_wave[8], (double)h.dbg_wave[2]/h.dbg_wave[8],
+		        (double)h.dbg_wave[3]/h.dbg_wave[8], (double)h.dbg_wave[4]/h.dbg_wave[8], h.dbg_wave[9], h.dbg_wave[10],
+		        h.dbg_wave[9] ? (double)h.dbg_wave[3]/h.dbg_wave[9] : 0.0, h.dbg_wave[11], h.dbg_wave[12], h.dbg_wave[11] ? (double)h.dbg_wave[4]/h.dbg_wave[11] : 0.0, (double)h.dbg_wave[13]/h.dbg_wave[8]);
 #endif
 	return SRH_OK;
 }
@@ -1302,12 +1309,14 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(Counters), c->stream));
 				HIP_TRY(hipMemsetAsync(c->d_span, 0, 4*sizeof(int), c->stream));
 				const int ccap = rows_mode ? smax : cmax;             // cost values per pixel
-				const size_t per_px = (size_t)T*sizeof(double) + (size_t)ccap*sizeof(double) + (size_t)cmax*sizeof(uint32_t)
+				// (row runs: the windows in the LDS-image layout, window rows padded to an even tap count -- the cost kernel's
+				// waves fetch them by LDS-DMA)
+				const size_t per_px = (size_t)(rows_mode ? (2*p->window_radius + 1)*wimg_wp(p->window_radius) : T)*sizeof(double) + (size_t)ccap*sizeof(double) + (size_t)cmax*sizeof(uint32_t)
 				                      + (rows_mode ? (SRH_ROWS_NR + 1)*sizeof(uint32_t) : 0);
 				size_t lrows = budget / (per_px*(size_t)W);
 				if (lrows < 1) lrows = 1;
 				if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
-				if ((rc = ensure(c->wbuf, c->wbuf_cap, wbuf_doubles(W, (int)lrows, T)))) return rc;
+				if ((rc = ensure(c->wbuf, c->wbuf_cap, rows_mode ? wimg_doubles(W, (int)lrows, p->window_radius) : wbuf_doubles(W, (int)lrows, T)))) return rc;
 				// row runs: lists and row tables are tiled per 64 pixels, cost slots per 32-pixel tile of a row
 				const size_t px64 = (lrows*W + 63) & ~(size_t)63, px32 = lrows*(size_t)((W + 31)/32)*32;
 				if ((rc = ensure(c->cost, c->cost_cap, (rows_mode ? px32 : lrows*W)*(size_t)ccap))) return rc;
@@ -1354,16 +1363,17 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						if (c->side_weights) {
 							HIP_TRY(hipStreamWaitEvent(c->side_stream, c->side_go, 0));
 							std::swap(c->stream, c->side_stream);
-							run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr);
+							run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr, true);
 							std::swap(c->stream, c->side_stream);
 							HIP_TRY(hipEventRecord(c->side_done, c->side_stream));
 							HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
-						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr);
+						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr, true);
 						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
+						HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));   // the cost kernel's waves draw their tiles from it
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? (c->cert_form == 1 ? 5 : 3) : 0,
-						                           rows_pc ? c->pconst : nullptr); }
+						                           rows_pc ? c->pconst : nullptr, rows_cert && c->rows_masked ? O.tvp : nullptr, c->num_cus); }
 						{ Scope s(c, "twoview_rows_scan_kernel");
 						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, rows_cert ? c->cflag : nullptr, -1, c->d_cnt); }

@@ -361,7 +361,8 @@ void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
                               const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith = 0,
-                              const double *pconst = nullptr);   // pconst: the band's per-pixel constants from the weights kernel (else made in the kernel)
+                              const double *pconst = nullptr,    // pconst: the band's per-pixel constants from the weights kernel (else made in the kernel)
+                              const double *oth_tvp = nullptr, int num_cus = 256);  // the other view's NaN-bordered plane: masked fast blocks + single candidates (else: a block is fast when all 8 are)
 // cflag == nullptr: exact scan.  cflag, nlist < 0: certified scan (flags into cflag = [count | band pixel indices]).
 // cflag, nlist >= 0: the exact scan of the listed pixels (after launch_twoview_rows_refill)
 void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,

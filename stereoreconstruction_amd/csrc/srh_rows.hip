@@ -283,10 +283,13 @@ void launch_twoview_rows_list(hipStream_t st, const ViewDev *views, int ref, int
 }
 
 // ------------------------------------------------------------------ blocked cost
-#define RC_TP 32
+typedef __attribute__((address_space(3))) void rc_lds_void;
+typedef __attribute__((address_space(1))) const void rc_gbl_void;
+#define RC_TP 32                   // pixels of a tile of the cost-slot / window-buffer layouts
+#define RC_WT 8                    // pixels of a WAVE TILE: what one workgroup (= one wave) works on at a time
 #define RC_G 8
 #define RC_NCB 8
-#define RC_THREADS (RC_TP*RC_G)
+#define RC_THREADS (RC_WT*RC_G)
 
 template <int R>
 struct RowsSmem {
@@ -294,18 +297,23 @@ struct RowsSmem {
 	static constexpr int T = WS*WS;
 	static constexpr int WP = (WS + 1) & ~1;
 	static constexpr int WPIX = WS*WP;
-	static constexpr int LW = RC_TP + 2*R;
-	double w[RC_TP][WPIX];
+	static constexpr int LW = RC_WT + 2*R;
+	double w[WS][RC_WT][WP];                                   // the band buffer's "LDS image" of the wave tile: [window row][pixel][tap, padded]
 	double lt[WS][LW];
-	double meanL[RC_TP], totalW[RC_TP], sum2[RC_TP], sumA[RC_TP];   // sumA: sum of w_t*l_t - meanL, fused (one-pass form only)
-	int lall[RC_TP];
-	int meta[RC_TP];
-	uint32_t rowinfo[RC_TP][RW_NR];
-	unsigned short blk0[RC_TP][RW_NR + 2];                    // first 8-column block (task) of each row; [nr] = total
+	double meanL[RC_WT], totalW[RC_WT], sum2[RC_WT], sumA[RC_WT];   // sumA: sum of w_t*l_t - meanL, fused (one-pass form only)
+	int lall[RC_WT];
+	int meta[RC_WT];
+	uint32_t rowinfo[RC_WT][RW_NR];
+	unsigned short blk0[RC_WT][RW_NR + 2];                    // first 8-column block (task) of each row; [nr] = total
 	// phase 2 work list: blocks that need the select form, (pixel << 16) | task, compacted over the tile
-	static constexpr int GL_CAP = 2048;
+	static constexpr int GL_CAP = 512;
 	unsigned int glist[GL_CAP];
 	int glist_n;
+	// phase 2, single candidates: (pixel << 16) | cost slot -- the few candidates of an otherwise fast block whose window in
+	// the other view is not fully usable (the columns and rows next to its border, masked neighbourhoods)
+	static constexpr int GS_CAP = 256;
+	unsigned int gsingle[GS_CAP];
+	int gsingle_n;
 };
 
 // AR: 0 = the reference's arithmetic; 3 = certified: the two sweeps of the fast form run with fused multiply-adds and
@@ -313,13 +321,13 @@ struct RowsSmem {
 // for a candidate whose error bound is not below e0, the clamp itself above clamp + e0, anything else unclamped.  The
 // per-pixel constants (meanL, totalWeight, sum2) and the select form stay in the reference's arithmetic.
 template <int R, int AR>
-__global__ __launch_bounds__(RC_THREADS, 2)
+__global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                               int y0, int nrows, const double *__restrict__ wbuf,
                               const uint8_t *__restrict__ full_oth,
                               const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
                               double *__restrict__ cost, int smax, Counters *__restrict__ cnt, const CertBound cb,
-                              const double *__restrict__ pconst)
+                              const double *__restrict__ pconst, const double *__restrict__ oth_tvp)
 {
 	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;   // 5: the certified ONE-PASS form (srh_internal.hpp, CertBound)
 	constexpr int WS = 2*R + 1;
@@ -334,31 +342,65 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	const ViewDev &Rv = views[oth];
 	const int W = L.w, H = L.h, OW = Rv.w, OH = Rv.h;
 	const int tiles_per_row = (W + RC_TP - 1)/RC_TP;
-	const int trow = blockIdx.x / tiles_per_row;
-	const int x0 = (blockIdx.x % tiles_per_row)*RC_TP;
-	const int y = y0 + trow;
 	const int tid = threadIdx.x;
-	const int lane = tid & 63;
-	const int i = (tid >> 6)*8 + (lane & 7);
+	const int lane = tid;
+	const int i = lane & 7;
 	const int g = lane >> 3;
+	const double nan = __builtin_nan("");
+	// oth_tvp (round 6): the other view's NaN-bordered plane.  With it a block is fast as soon as ONE of its candidates has a
+	// fully usable window: the row segments are read from the padded plane (a window that leaves the image reads NaN, which
+	// stays inside the sums of the candidates whose window it is), the results of the others are not stored, and those go
+	// candidate by candidate in phase 2 -- as in twoview_strip_cost_kernel.  Without it a block is fast when all 8 are.
+	const bool masked = oth_tvp != nullptr;
+	const int SPR = padded_stride(OW);
+	typedef const __attribute__((address_space(1))) double *gptr;
+	const gptr rplane = masked ? (gptr)(oth_tvp + (size_t)(SRH_PADY - R)*SPR + (SRH_PADL - R)) : (gptr)(Rv.gray_tv - (ptrdiff_t)R*OW - R);
+	const int rs = masked ? SPR : OW;
+
+	// PERSISTENT WAVES (round 6): a workgroup is ONE wave; it draws wave tiles -- 8 adjacent pixels of an image row, a quarter
+	// of a 32-pixel tile of the layouts -- from the launch's ticket counter until none is left.  (Four waves per 32-pixel tile
+	// behind common barriers lost the three that waited while one evaluated the tile's few select-form blocks, and all of them
+	// the difference between the slowest wave's rounds and their own.)
+	const int nitems = tiles_per_row*(RC_TP/RC_WT)*nrows;
+	unsigned n_dev = 0;
+#ifdef SRH_ROWS_DBG
+	unsigned d_task = 0, d_fast = 0, d_rows = 0, d_wavefast = 0, d_waveiter = 0;
+	unsigned long long d_t[6] = { 0, 0, 0, 0, 0, 0 }, d_n[6] = { 0, 0, 0, 0, 0, 0 };   // cycles: ticket+staging, constants, phase 1, p2 blocks, p2 singles; counts
+#define RC_STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); d_t[k] += t_ - d_last; d_last = t_; }
+	unsigned long long d_last = __builtin_readcyclecounter();
+#else
+#define RC_STAMP(k)
+#endif
+	int next_item = 0;
+	if (lane == 0) next_item = (int)atomicAdd(&cnt->strip_ticket, 1u);
+	for (;;) {
+	const int item = __builtin_amdgcn_readfirstlane(next_item);
+	if (item >= nitems) break;
+	const int tile = item/(RC_TP/RC_WT), sub = item % (RC_TP/RC_WT);
+	const int trow = tile / tiles_per_row;
+	const int x0 = (tile % tiles_per_row)*RC_TP + sub*RC_WT;
+	const int y = y0 + trow;
 	const int x = x0 + i;
 	const size_t qbase = (size_t)trow*W + x0;
-	const double nan = __builtin_nan("");
+	double *const ctile = cost + (size_t)tile*smax*RC_TP + sub*RC_WT;      // cost slot s of the wave tile's pixel pi at ctile[s*32 + pi]
 
-	// ---- stage windows, reference rows, row spans (all global loads first)
+	// ---- stage: the windows by LDS-DMA -- the band buffer has the layout of the LDS image ([tile][window row][pixel][WP],
+	// srh_internal.hpp "layout B"), a window row of the wave tile's 8 pixels is 8*WP contiguous doubles: no register, no
+	// ds_write on the way --; reference rows, row spans and the pixels' constants through registers; the NEXT tile's ticket
+	// is drawn here, a tile ahead of its use
+	double pcr[5] = { 0, 0, 0, 0, 0 };
 	{
 		static_assert(RC_TP == SRH_WTILE, "tile = window-buffer tile");
-		constexpr int NBW = (T*RC_TP + RC_THREADS - 1)/RC_THREADS;
 		constexpr int NBL = (WS*Smem::LW + RC_THREADS - 1)/RC_THREADS;
-		constexpr int NBI = (RC_TP*RW_NR + RC_THREADS - 1)/RC_THREADS;
-		const double *wtile = wbuf + wbuf_offset(W, T, trow, x0);
-		double tw_[NBW], tl_[NBL];
-		uint32_t ti_[NBI];
+		constexpr int NBI = (RC_WT*RW_NR + RC_THREADS - 1)/RC_THREADS;
+		const double *wt = wbuf + wimg_offset(W, R, trow, x0);
 #pragma unroll
-		for (int k = 0; k < NBW; ++k) {
-			const int idx = tid + k*RC_THREADS;
-			tw_[k] = (idx < T*RC_TP && x0 + (idx % RC_TP) < W) ? wtile[idx] : 0.0;
-		}
+		for (int a = 0; a < WS; ++a)
+			if (lane*16 < RC_WT*WP*8)
+				__builtin_amdgcn_global_load_lds((rc_gbl_void *)((const char *)(wt + (size_t)a*(RC_TP*WP)) + lane*16),
+				                                 (rc_lds_void *)&S.w[a][0][0], 16, 0, 0);
+		double tl_[NBL];
+		uint32_t ti_[NBI];
 #pragma unroll
 		for (int k = 0; k < NBL; ++k) {
 			const int idx = tid + k*RC_THREADS;
@@ -371,17 +413,15 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			const int idx = tid + k*RC_THREADS;
 			const int pi = idx / RW_NR;
 			const size_t qq = qbase + pi;
-			ti_[k] = (idx < RC_TP*RW_NR && x0 + pi < W) ? rowinfo[((qq >> 6)*RW_NR + idx % RW_NR)*64 + (qq & 63)] : 0u;
+			ti_[k] = (idx < RC_WT*RW_NR && x0 + pi < W) ? rowinfo[((qq >> 6)*RW_NR + idx % RW_NR)*64 + (qq & 63)] : 0u;
 		}
-		const int mt = (tid < RC_TP && x0 + tid < W) ? meta[qbase + tid] : 0;
+		const int mt = (tid < RC_WT && x0 + tid < W) ? meta[qbase + tid] : 0;
+		if (g == 0 && pconst) {
+			const double *pc = pconst + ((size_t)trow*W + (x < W ? x : W - 1))*SRH_PC;
 #pragma unroll
-		for (int k = 0; k < NBW; ++k) {
-			const int idx = tid + k*RC_THREADS;
-			const int t = idx / RC_TP, pi = idx % RC_TP;
-			if (idx < T*RC_TP) S.w[pi][(t / WS)*WP + (t % WS)] = tw_[k];
+			for (int k = 0; k < 5; ++k) pcr[k] = pc[k];
 		}
-		if (WP != WS)
-			for (int idx = tid; idx < WS*RC_TP; idx += RC_THREADS) S.w[idx % RC_TP][(idx / RC_TP)*WP + WS] = 0.0;
+		if (lane == 0) next_item = (int)atomicAdd(&cnt->strip_ticket, 1u);
 #pragma unroll
 		for (int k = 0; k < NBL; ++k) {
 			const int idx = tid + k*RC_THREADS;
@@ -390,19 +430,20 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll
 		for (int k = 0; k < NBI; ++k) {
 			const int idx = tid + k*RC_THREADS;
-			if (idx < RC_TP*RW_NR) S.rowinfo[idx / RW_NR][idx % RW_NR] = ti_[k];
+			if (idx < RC_WT*RW_NR) S.rowinfo[idx / RW_NR][idx % RW_NR] = ti_[k];
 		}
-		if (tid < RC_TP) S.meta[tid] = mt;
+		if (tid < RC_WT) S.meta[tid] = mt;
+		__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the window rows have landed in LDS
 	}
 	__syncthreads();
+	RC_STAMP(0);
 
 	// ---- per-pixel constants of the all-taps-usable form (one lane per pixel).  pconst (round 6): the weights kernel has made
 	// them while the window was in its registers (the same operations in the same tap order: the same bits; SRH_PC doubles per
 	// pixel) -- computed here they are two 121-tap loops on one lane in eight with the workgroup waiting, 7 % of the kernel on C5
 	if (g == 0 && pconst) {
-		const double *pc = pconst + ((size_t)trow*W + (x < W ? x : W - 1))*SRH_PC;
-		const bool all = (x < W) && (S.meta[i] >> 16) > 0 && pc[3] != 0.0;
-		S.meanL[i] = pc[0]; S.totalW[i] = (ONEPASS && all) ? pc[3] : pc[1]; S.sum2[i] = pc[2]; S.lall[i] = all ? 1 : 0; S.sumA[i] = pc[4];
+		const bool all = (x < W) && (S.meta[i] >> 16) > 0 && pcr[3] != 0.0;
+		S.meanL[i] = pcr[0]; S.totalW[i] = (ONEPASS && all) ? pcr[3] : pcr[1]; S.sum2[i] = pcr[2]; S.lall[i] = all ? 1 : 0; S.sumA[i] = pcr[4];
 		const int nr = S.meta[i] >> 16;
 		int nblk = 0;
 		for (int r = 0; r < nr; ++r) {
@@ -418,7 +459,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll
 			for (int col = 0; col < WS; ++col) {
 				const double gl = S.lt[row][i + col];
-				const double wt = S.w[i][row*WP + col];
+				const double wt = S.w[row][i][col];
 				if (!(gl == gl && wt > P.weight_cutoff)) all = false;
 				mL += wt*gl;
 				tw += wt;
@@ -430,9 +471,9 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			for (int row = 0; row < WS; ++row)
 #pragma unroll
 				for (int col = 0; col < WS; ++col) {
-					const double a = S.w[i][row*WP + col]*S.lt[row][i + col] - mL;
+					const double a = S.w[row][i][col]*S.lt[row][i + col] - mL;
 					s2 += a*a;
-					if (ONEPASS) sA += __builtin_fma(S.w[i][row*WP + col], S.lt[row][i + col], -mL);
+					if (ONEPASS) sA += __builtin_fma(S.w[row][i][col], S.lt[row][i + col], -mL);
 				}
 		} else all = false;
 		S.meanL[i] = mL; S.totalW[i] = (ONEPASS && all) ? 1.0/tw : tw; S.sum2[i] = s2; S.lall[i] = all ? 1 : 0; S.sumA[i] = sA;   // (one-pass form: fl(1/totalWeight), onepass_finish)
@@ -444,13 +485,10 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		}
 		S.blk0[i][nr] = (unsigned short)nblk;
 	}
-	if (tid == 0) S.glist_n = 0;
+	if (tid == 0) { S.glist_n = 0; S.gsingle_n = 0; }
 	__syncthreads();
+	RC_STAMP(1);
 
-	unsigned n_dev = 0;
-#ifdef SRH_ROWS_DBG
-	unsigned d_task = 0, d_fast = 0, d_rows = 0, d_wavefast = 0, d_waveiter = 0;
-#endif
 	const Smem &CS = S;
 	// one 8-column block of pixel `pi` (task = index of the block among the pixel's spans) in the blocked select
 	// form: any validity pattern (image border, masked taps, cut-off weights); the same sums as the fast form with
@@ -466,7 +504,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		const int cy = ymin + r;
 		const int c0 = xlo + b*RC_NCB;
 		const int nv = wdt - b*RC_NCB < RC_NCB ? wdt - b*RC_NCB : RC_NCB;
-		double *dst = cost + (size_t)blockIdx.x*smax*RC_TP + pi + (size_t)task*RC_NCB*RC_TP;
+		double *dst = ctile + pi + (size_t)task*RC_NCB*RC_TP;
 			// blocked select form, any validity pattern (image border, masked taps, cut-off weights):
 			// the same sums with every tap guarded; a skipped tap adds +0.0
 			const int gx0 = c0 - R;
@@ -495,7 +533,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				for (int k = 0; k < NR_; ++k) { const bool okr = rr[k] == rr[k]; rv[k] = okr ? 1.0 : 0.0; rr[k] = okr ? rr[k] : 0.0; }
 #pragma unroll
 				for (int col = 0; col < WS; ++col) {
-					const double gl = CS.lt[row][pi + col], wt = CS.w[pi][row*WP + col];
+					const double gl = CS.lt[row][pi + col], wt = CS.w[row][pi][col];
 					const bool okl = gl == gl && wt > P.weight_cutoff;
 					const double w0 = okl ? wt : 0.0, pl0 = okl ? wt*gl : 0.0;
 #pragma unroll
@@ -527,7 +565,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				for (int k = 0; k < NR_; ++k) { const bool okr = rr[k] == rr[k]; rv[k] = okr ? 1.0 : 0.0; rr[k] = okr ? rr[k] : 0.0; }
 #pragma unroll
 				for (int col = 0; col < WS; ++col) {
-					const double gl = CS.lt[row][pi + col], wt = CS.w[pi][row*WP + col];
+					const double gl = CS.lt[row][pi + col], wt = CS.w[row][pi][col];
 					const bool okl = gl == gl && wt > P.weight_cutoff;
 					const double pl = wt*(gl == gl ? gl : 0.0), kl = okl ? 1.0 : 0.0;
 #pragma unroll
@@ -555,7 +593,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	if (x < W) {
 		const int m = CS.meta[i];
 		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
-		double *crow = cost + (size_t)blockIdx.x*smax*RC_TP + i;      // tile-transposed: slot s at crow[s*32]
+		double *crow = ctile + i;                                     // tile-transposed: slot s at crow[s*32]
 		const bool lall = CS.lall[i] != 0;
 		const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
 		const double sig3 = CERT ? cb.sigma3(s2) : 0.0;                // certified: smallest sum3 the bound covers for this pixel
@@ -575,15 +613,20 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				n_dev += nv;
 				// a span's last, partial block is moved left to end on the span's last column, so that the fast
 				// form always works on 8 usable columns (the extra ones are recomputed and dropped)
-				const int sh = RC_NCB - nv;
+				// (a span that starts left of column 8 - nv cannot be moved: its block stays where it is, the extra columns lie
+				// right of the span -- only the masked form takes such a block)
+				const int sh = c0 - (RC_NCB - nv) >= 0 ? RC_NCB - nv : 0;
 				const int c0s = c0 - sh;
-				bool fast = lall && c0s >= 0;
-				if (fast) {
+				const unsigned own = ((1u << nv) - 1u) << sh;             // the block's own candidates
+				unsigned vm = 0;                                          // ... of which the fast form stores
+				bool fast = false;
+				if (lall && (masked || sh == RC_NCB - nv)) {
 					const uint8_t *fp = full_oth + (size_t)cy*OW + c0s;
-					unsigned allfull = 1;
+					unsigned fm = 0;
 #pragma unroll
-					for (int j = 0; j < RC_NCB; ++j) allfull &= fp[j];
-					fast = allfull != 0;
+					for (int j = 0; j < RC_NCB; ++j) fm |= (c0s + j < OW && fp[j]) ? 1u << j : 0u;
+					if (masked) { vm = fm & own; fast = vm != 0; }
+					else { fast = fm == 0xffu; vm = fast ? own : 0u; }
 				}
 				double *dst = crow + (size_t)task*RC_NCB*RC_TP;
 #ifdef SRH_ROWS_DBG
@@ -594,17 +637,16 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				if (fast && ONEPASS) {
 					// certified one-pass form: P = sum w r, Q = sum ((w l - meanL) w) r, U = sum w^2 r^2 in ONE sweep over the window
 					// (twoview_strip_cost_kernel); the other view's row segments come from L1 / L2 once instead of twice
-					typedef const __attribute__((address_space(1))) double *gptr;
-					const gptr rbase = (gptr)(Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R));
+					const gptr rbase = rplane + (size_t)cy*rs + c0s;
 					const double SA = CS.sumA[i];
 					double r[NR_], q[NR_], wv[WS], lv[WS], P_[RC_NCB], Q_[RC_NCB], U_[RC_NCB];
 					{
-						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[0][i][0]);
 #pragma unroll
 						for (int k = 0; k < NR_; ++k) r[k] = rbase[k];
 #pragma unroll
 						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
-						wv[WS - 1] = CS.w[i][WS - 1];
+						wv[WS - 1] = CS.w[0][i][WS - 1];
 #pragma unroll
 						for (int col = 0; col < WS; ++col) lv[col] = CS.lt[0][i + col];
 					}
@@ -613,8 +655,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
 						const int nrow = row + 1 < WS ? row + 1 : 0;          // (the last refill is never used)
-						const gptr rp = rbase + (size_t)nrow*OW;
-						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const gptr rp = rbase + (size_t)nrow*rs;
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[nrow][i][0]);
 						const double *lp = &CS.lt[nrow][i];
 #pragma unroll
 						for (int k = 0; k < RC_NCB - 1; ++k) q[k] = r[k]*r[k];
@@ -640,12 +682,12 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						}
 #pragma unroll
 						for (int k = WS - 1; k < NR_; ++k) r[k] = rp[k];
-						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
+						wv[WS - 1] = CS.w[nrow][i][WS - 1];
 					}
 					constexpr double TT = (double)T;
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
-						if (j >= sh) {
+						if ((vm >> j) & 1u) {
 							bool okc;
 							const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, tw, s2, TT, sig3, cb.zmax2, okc);   // (tw: 1/totalWeight in this form)
 							dst[(j - sh)*RC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
@@ -656,8 +698,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					// read once per window row and shared by the NCB candidates and 2R+1 taps
 					// (a global pointer, not a generic one: flat loads would share the LDS counter, and every wait for a
 					// weight would then also wait for the row segments in flight)
-					typedef const __attribute__((address_space(1))) double *gptr;
-					const gptr rbase = (gptr)(Rv.gray_tv + (size_t)(cy - R)*OW + (c0s - R));
+					const gptr rbase = rplane + (size_t)cy*rs + c0s;
 					// Both sweeps are scheduled by hand like the dense kernel's (srh_dense.hip): r[] / wv[] / av[] hold the
 					// current window row; as soon as a value has had its last use its register is refilled with the next
 					// row's value (the other view's segment from L1/L2, the weights and the reference row from LDS), so the
@@ -665,20 +706,20 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					static_assert(WS % 2 == 1 && WP % 2 == 0, "odd window, window rows padded to 16 bytes");
 					double r[NR_], wv[WS], acc[RC_NCB];
 					{
-						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][0]);
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[0][i][0]);
 #pragma unroll
 						for (int k = 0; k < NR_; ++k) r[k] = rbase[k];
 #pragma unroll
 						for (int m = 0; m < (WS - 1)/2; ++m) { const double2 v = wp[m]; wv[2*m] = v.x; wv[2*m + 1] = v.y; }
-						wv[WS - 1] = CS.w[i][WS - 1];
+						wv[WS - 1] = CS.w[0][i][WS - 1];
 					}
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) acc[j] = 0.0;
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
 						const int nrow = row + 1 < WS ? row + 1 : 0;          // last refill = row 0, for the second sweep
-						const gptr rp = rbase + (size_t)nrow*OW;
-						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const gptr rp = rbase + (size_t)nrow*rs;
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[nrow][i][0]);
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
 							if (FMA) {
@@ -701,7 +742,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						}
 #pragma unroll
 						for (int k = WS - 1; k < NR_; ++k) r[k] = rp[k];
-						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
+						wv[WS - 1] = CS.w[nrow][i][WS - 1];
 					}
 					double mR[RC_NCB], s1[RC_NCB], s3[RC_NCB], av[WS];
 #pragma unroll
@@ -711,8 +752,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 #pragma unroll 1
 					for (int row = 0; row < WS; ++row) {
 						const int nrow = row + 1 < WS ? row + 1 : 0;
-						const gptr rp = rbase + (size_t)nrow*OW;
-						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[i][nrow*WP]);
+						const gptr rp = rbase + (size_t)nrow*rs;
+						const double2 *wp = reinterpret_cast<const double2 *>(&CS.w[nrow][i][0]);
 						const double *lp = &CS.lt[nrow][i];
 #pragma unroll
 						for (int col = 0; col < WS; ++col) {
@@ -751,19 +792,40 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						}
 #pragma unroll
 						for (int k = WS - 1; k < NR_; ++k) r[k] = rp[k];
-						wv[WS - 1] = CS.w[i][nrow*WP + WS - 1];
+						wv[WS - 1] = CS.w[nrow][i][WS - 1];
 					}
 #pragma unroll
 					for (int j = 0; j < RC_NCB; ++j) {
-						if (j >= sh) {
+						if ((vm >> j) & 1u) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
 							if (CERT) dst[(j - sh)*RC_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
 							else dst[(j - sh)*RC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 					}
-				} else {
-					// needs the select form: handed to phase 2, where such blocks of the whole tile are spread
-					// over all lanes (a wave dragged through the select form for a few lanes costs ~3.5 fast blocks)
+				}
+				// what the fast form has left.  Masked form: the candidates of a pixel with a fully usable window of its own whose
+				// window in the OTHER view is not (the columns and rows next to its border, masked neighbourhoods) go one by one in
+				// phase 2 -- a wave tile has a few dozen of them, one iteration of single candidates takes a quarter of the time of
+				// one iteration of blocks in the select form (52 000 against 237 000 cycles per tile that has them:
+				// profiles/r06_c5_rows_phases.txt).  Pixels with unusable taps of their own (the image's border rows and
+				// columns: every block of theirs): the blocked select form, whole iterations of it
+				unsigned need = own & ~vm;
+				if (masked && lall && need) {
+					const int n1 = __builtin_popcount(need);
+					const int at = atomicAdd(&S.gsingle_n, n1);
+					if (at + n1 <= Smem::GS_CAP) {
+						int k = 0;
+#pragma unroll
+						for (int j = 0; j < RC_NCB; ++j)
+							if ((need >> j) & 1u) { S.gsingle[at + k] = ((unsigned)i << 16) | (unsigned)(task*RC_NCB + j - sh); ++k; }
+						need = 0;
+					} else {
+						for (int k = at; k < at + n1 && k < Smem::GS_CAP; ++k) S.gsingle[k] = 0xffffffffu;   // reserved, void
+					}
+				}
+				if (need) {
+					// the blocked select form (which stores all of the block's candidates, the fast ones once more: the
+					// reference's own numbers), in phase 2, where such blocks of the whole tile are spread over all lanes
 					const int slot = atomicAdd(&S.glist_n, 1);
 					if (slot < Smem::GL_CAP) S.glist[slot] = ((unsigned)i << 16) | (unsigned)task;
 					else general_block(i, task);                       // list full (cannot happen below 64 blocks per pixel)
@@ -773,9 +835,34 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	}
 	// ---- phase 2: the listed blocks in the select form, one per lane
 	__syncthreads();
+	RC_STAMP(2);
 	{
 		const int nl = S.glist_n < Smem::GL_CAP ? S.glist_n : Smem::GL_CAP;
 		for (int k = tid; k < nl; k += RC_THREADS) general_block((int)(S.glist[k] >> 16), (int)(S.glist[k] & 0xffffu));
+		RC_STAMP(3);
+#ifdef SRH_ROWS_DBG
+		{ int tot = 0; for (int k = 0; k < RC_WT; ++k) tot += (x0 + k < W) ? (int)CS.blk0[k][CS.meta[k] >> 16] : 0; d_n[5] += (tot + 63)/64; }
+		d_n[0] += 1; d_n[1] += nl > 0; d_n[2] += nl; d_n[3] += S.gsingle_n > 0; d_n[4] += S.gsingle_n;
+#endif
+		// single candidates (masked form only): cost_ncc for any validity pattern, window and reference rows from LDS, the
+		// other view's taps from its NaN-bordered plane
+		const int ns = S.gsingle_n < Smem::GS_CAP ? S.gsingle_n : Smem::GS_CAP;
+		for (int k = tid; k < ns; k += RC_THREADS) {
+			const unsigned e = S.gsingle[k];
+			if (e == 0xffffffffu) continue;
+			const int pi = (int)(e >> 16), slot = (int)(e & 0xffffu), task = slot/RC_NCB;
+			const int m = CS.meta[pi];
+			int r = 0;
+			while (task >= (int)CS.blk0[pi][r + 1]) ++r;
+			const uint32_t info = CS.rowinfo[pi][r];
+			const int cx = (int)(short)(info & 0xffff) + (slot - (int)CS.blk0[pi][r]*RC_NCB), cy = (int)(short)(m & 0xffff) + r;
+			const double *rp = oth_tvp + (size_t)(cy + SRH_PADY - R)*SPR + (cx + SRH_PADL - R);
+			ctile[pi + (size_t)slot*RC_TP] =
+				window_exact_cost<R>(&CS.w[0][pi][0], RC_WT*WP, 1, &CS.lt[0][pi], rp, Smem::LW, SPR, P);
+		}
+	}
+	RC_STAMP(4);
+	__syncthreads();                        // the wave is through with this tile's LDS
 	}
 	block_count_add(&cnt->n_eval_device, n_dev);
 #ifdef SRH_ROWS_DBG
@@ -784,16 +871,20 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	block_count_add(&cnt->dbg_cycles, d_rows);
 	block_count_add(&cnt->dbg_blocks, d_waveiter);
 	block_count_add(&cnt->dbg_total_cycles, d_wavefast);
+	if (lane == 0) for (int k = 0; k < 6; ++k) { atomicAdd(&cnt->dbg_wave[k], d_t[k]); atomicAdd(&cnt->dbg_wave[8 + k], d_n[k]); }
 #endif
+#undef RC_STAMP
 }
 
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
                               const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith,
-                              const double *pconst)
+                              const double *pconst, const double *oth_tvp, int num_cus)
 {
+	// persistent single-wave workgroups, two per SIMD; Counters::strip_ticket is zero at launch (the caller's memset)
 	const int tiles = (width + RC_TP - 1)/RC_TP;
-	const dim3 grid((unsigned)(tiles*nrows));
+	const int items = tiles*(RC_TP/RC_WT)*nrows;
+	const dim3 grid((unsigned)(items < num_cus*8 ? items : num_cus*8));
 	const CertBound cb = cert_bound(P);
 #define SRH_RC_LAUNCH2(RR, AA)                                                                              \
 	{                                                                                                       \
@@ -801,7 +892,7 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 		(void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR, AA>,                           \
 		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>));            \
 		hipLaunchKernelGGL((twoview_rows_cost_kernel<RR, AA>), grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
-		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb, pconst);  \
+		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb, pconst, oth_tvp);  \
 		return true;                                                                                        \
 	}
 #define SRH_RC_LAUNCH(RR) { if (arith == 5) SRH_RC_LAUNCH2(RR, 5) else if (arith == 3) SRH_RC_LAUNCH2(RR, 3) else SRH_RC_LAUNCH2(RR, 0) }
@@ -833,7 +924,7 @@ void twoview_rows_refill_kernel(int W, srh_params P, int y0, const uint32_t *__r
 	for (uint32_t f = blockIdx.x; f < nflag && f < (uint32_t)cap; f += gridDim.x) {      // (a few hundred workgroups share the list)
 	const size_t q = cflag[1 + f];
 	const int x = (int)(q % W), trow = (int)(q / W), y = y0 + trow;
-	const WindowAt wa = window_at<R>(wbuf, 0, W, trow, x);
+	const WindowAt wa = window_at<R>(wbuf, 1, W, trow, x);        // (the row-run path's band buffer has the LDS-image layout)
 	const int SPL = padded_stride(W), SPR = padded_stride(OW);
 	const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SPL + (x + SRH_PADL - R);
 	const int tiles_per_row = (W + 31) >> 5;

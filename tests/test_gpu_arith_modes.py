@@ -314,6 +314,31 @@ def test_certified_equals_exact_on_general_geometry(hip_ctx, name, over):
         assert exact[d][1]["n_eval"] == cert[d][1]["n_eval"]
 
 
+@pytest.mark.parametrize("name,over", ROWS_CASES)
+def test_row_run_masked_blocks_and_single_candidates(hip_ctx, name, over):
+    """Round 6: the certified row-run cost kernel evaluates a block in the fast form as soon as ONE of its candidates has a
+    fully usable window in the other view (row segments from the NaN-bordered plane, results of the others not stored) and
+    the others one by one; option rows_masked = 0 is the earlier rule (fast only when all 8 are, else the blocked select
+    form).  Both give the exact arithmetic's maps, bit for bit, and count the same evaluations."""
+    import cases
+    case = cases.get_twoview(name, **over)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    exact = _rows_both_ways(hip_ctx, p, capi.ARITH_EXACT)
+    try:
+        hip_ctx.set_option("rows_masked", 0)
+        plain = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+        hip_ctx.set_option("rows_masked", 1)
+        masked = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+    finally:
+        hip_ctx.set_option("rows_masked", 1)
+    for d in range(2):
+        assert not masked[d][1]["used_dense_path"]
+        assert np.array_equal(exact[d][0].view(np.uint64), plain[d][0].view(np.uint64)), (name, over, d)
+        assert np.array_equal(exact[d][0].view(np.uint64), masked[d][0].view(np.uint64)), (name, over, d)
+        assert plain[d][1]["n_eval_device"] == masked[d][1]["n_eval_device"] > 0
+
+
 @pytest.mark.parametrize("kind", ["periodic", "flat", "near_flat", "saturated_half", "two_matches"])
 def test_certified_equals_exact_on_adversarial_images_general_geometry(hip_ctx, kind):
     """The adversarial images once more under a slightly verged, distorted rig: row-run lists, curves crossing rows."""
