@@ -185,7 +185,7 @@ struct srh_context {
 		       lcount_cap = 0, lmeta_cap = 0, stpl_cap = 0, tileflag_cap = 0;
 	} tv_slot;
 	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
-	int rows_masked = 1;                                // option "rows_masked": 0 = the certified row-run cost kernel evaluates a block in the fast form only when all 8 of its candidates are fast (round 5's rule; A/B and tests)
+	int rows_masked = 1;                                // option "rows_masked": the certified row-run cost kernel's masked blocks + single candidates: 1 = when at least 90 % of the other view's usable pixels have a fully usable window (decided on the device), 2 = always, 0 = never (a block is fast only when all 8 of its candidates are: round 5's rule)
 	int side_weights = 1;                               // option "side_weights": 0 = the row-run path computes its support windows on the pass's own stream, behind the list kernel (profiling: every kernel's own duration)
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
 	bool force_dense = false;                           // option "force_dense": propose the dense plan for any pinhole pair
@@ -792,7 +792,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
 	if (!strcmp(name, "tscan")) { c->tscan = value != 0; return SRH_OK; }
 	if (!strcmp(name, "geodma")) { c->geodma = value != 0; return SRH_OK; }
-	if (!strcmp(name, "rows_masked")) { c->rows_masked = value != 0; return SRH_OK; }
+	if (!strcmp(name, "rows_masked")) { c->rows_masked = (int)value; return SRH_OK; }   // 0 off, 1 by the other view's share of fully usable windows (default), 2 always
 	if (!strcmp(name, "side_weights")) { c->side_weights = value != 0; return SRH_OK; }
 	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
 	if (!strcmp(name, "debug_mvs_cmax_hint")) { c->mvs_cmax_hint = value > 0 ? (int)((value + 7) & ~7L) : 0; return SRH_OK; }
@@ -833,7 +833,7 @@ extern "C" int srh_view_upload(srh_context *c, int slot, int w, int h,
 		HIP_TRY(plane_alloc((void **)&v.gray_tv, n*sizeof(double)));
 		HIP_TRY(plane_alloc((void **)&v.depth, n*sizeof(double)));
 		HIP_TRY(plane_alloc((void **)&v.edges, 4*n*sizeof(double)));
-		HIP_TRY(hipMalloc((void **)&v.full, n));
+		HIP_TRY(hipMalloc((void **)&v.full, full_stat_offset(n) + 16));      // (+ the map's two counters, full_window_kernel)
 		v.w = w; v.h = h; v.present = true;
 	}
 	v.cam = *cam;
@@ -1276,7 +1276,9 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 			ViewHost &O = c->views[oth];
 			if (O.full_r != R) {
 				Scope s(c, "full_window_kernel");
-				launch_full_window(c->stream, O.gray_tv, O.w, O.h, R, O.full);
+				uint32_t *stat = (uint32_t *)(O.full + full_stat_offset((size_t)O.w*O.h));
+				HIP_TRY(hipMemsetAsync(stat, 0, 2*sizeof(uint32_t), c->stream));
+				launch_full_window(c->stream, O.gray_tv, O.w, O.h, R, O.full, stat);
 				O.full_r = R;
 			}
 			// the label-only part of pointFromDepth, once per pass instead of once per pixel and label
@@ -1318,7 +1320,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 				if (lrows > (size_t)(y1 - y0)) lrows = (size_t)(y1 - y0);
 				if ((rc = ensure(c->wbuf, c->wbuf_cap, rows_mode ? wimg_doubles(W, (int)lrows, p->window_radius) : wbuf_doubles(W, (int)lrows, T)))) return rc;
 				// row runs: lists and row tables are tiled per 64 pixels, cost slots per 32-pixel tile of a row
-				const size_t px64 = (lrows*W + 63) & ~(size_t)63, px32 = lrows*(size_t)((W + 31)/32)*32;
+				const size_t px64 = (lrows*W + 63) & ~(size_t)63, px32 = lrows*(size_t)((W + 7)/8)*8;        /* (cost slots: tiles of 8 pixels) */
 				if ((rc = ensure(c->cost, c->cost_cap, (rows_mode ? px32 : lrows*W)*(size_t)ccap))) return rc;
 				if ((rc = ensure(c->lcand, c->lcand_cap, (rows_mode ? px64 : lrows*W)*(size_t)cmax))) return rc;
 				const bool rows_cert = rows_mode && cert_ok;
@@ -1370,10 +1372,17 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr, true);
 						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 						HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));   // the cost kernel's waves draw their tiles from it
+						if (c->debug_trace && rows_cert) {
+							uint32_t st[2] = { 0, 0 };
+							HIP_TRY(hipMemcpyAsync(st, O.full + full_stat_offset((size_t)O.w*O.h), sizeof(st), hipMemcpyDeviceToHost, c->stream));
+							HIP_TRY(hipStreamSynchronize(c->stream));
+							fprintf(stderr, "[srh trace] row-run cost kernel %d>%d: other view: %u usable pixels, %u with a fully usable window (rows_masked %d)\n", ref, oth, st[0], st[1], c->rows_masked);
+						}
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? (c->cert_form == 1 ? 5 : 3) : 0,
-						                           rows_pc ? c->pconst : nullptr, rows_cert && c->rows_masked ? O.tvp : nullptr, c->num_cus); }
+						                           rows_pc ? c->pconst : nullptr, rows_cert && c->rows_masked ? O.tvp : nullptr, c->num_cus,
+						                           c->rows_masked == 1 ? (const uint32_t *)(O.full + full_stat_offset((size_t)O.w*O.h)) : nullptr); }
 						{ Scope s(c, "twoview_rows_scan_kernel");
 						  launch_twoview_rows_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, cnt_band, c->lcand, cmax,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, rows_cert ? c->cflag : nullptr, -1, c->d_cnt); }

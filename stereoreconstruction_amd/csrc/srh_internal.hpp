@@ -300,7 +300,8 @@ void launch_twoview_count(hipStream_t st, const ViewDev *views, int ref, int oth
 void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                          int y0, int nrows, uint32_t *cand, int cmax, int32_t *count, Counters *cnt, int *max_count,
                          const double *tdist);
-void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full);
+void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full, uint32_t *stat = nullptr);   // stat[2] (zeroed): usable centres, full windows
+inline size_t full_stat_offset(size_t npix) { return (npix + 15) & ~(size_t)15; }   // the two counters live behind the map, 16-byte aligned
 bool launch_twoview_list_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
                               const int32_t *count, const uint32_t *cand, double *cost, int cmax, Counters *cnt);
@@ -362,7 +363,7 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
                               const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith = 0,
                               const double *pconst = nullptr,    // pconst: the band's per-pixel constants from the weights kernel (else made in the kernel)
-                              const double *oth_tvp = nullptr, int num_cus = 256);  // the other view's NaN-bordered plane: masked fast blocks + single candidates (else: a block is fast when all 8 are)
+                              const double *oth_tvp = nullptr, int num_cus = 256, const uint32_t *full_stat = nullptr);  // the other view's NaN-bordered plane: masked fast blocks + single candidates (else: a block is fast when all 8 are)
 // cflag == nullptr: exact scan.  cflag, nlist < 0: certified scan (flags into cflag = [count | band pixel indices]).
 // cflag, nlist >= 0: the exact scan of the listed pixels (after launch_twoview_rows_refill)
 void launch_twoview_rows_scan(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,

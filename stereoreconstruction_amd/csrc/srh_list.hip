@@ -115,9 +115,13 @@ void launch_twoview_list(hipStream_t st, const ViewDev *views, int ref, int oth,
 }
 
 // ------------------------------------------------------------------ fully usable windows of a view
-__global__ void full_window_kernel(const double *__restrict__ gray_tv, int W, int H, int R, uint8_t *__restrict__ full)
+// stat[0] += pixels with a usable centre tap, stat[1] += those whose whole window is usable (zeroed by the caller): how much of
+// a view's candidates the fast forms cover -- the row-run cost kernel picks its treatment of the others by it
+__global__ void full_window_kernel(const double *__restrict__ gray_tv, int W, int H, int R, uint8_t *__restrict__ full,
+                                   uint32_t *__restrict__ stat)
 {
 	const size_t n = (size_t)W*H;
+	unsigned n_centre = 0, n_full = 0;
 	for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x) {
 		const int x = (int)(i % (size_t)W), y = (int)(i / (size_t)W);
 		bool ok = x - R >= 0 && y - R >= 0 && x + R < W && y + R < H;
@@ -127,13 +131,22 @@ __global__ void full_window_kernel(const double *__restrict__ gray_tv, int W, in
 				ok = ok && (v == v);
 			}
 		full[i] = ok ? 1 : 0;
+		const double c0 = gray_tv[i];
+		n_centre += (c0 == c0) ? 1u : 0u; n_full += ok ? 1u : 0u;
 	}
+	__shared__ unsigned s_acc[2];
+	if (threadIdx.x == 0) { s_acc[0] = 0; s_acc[1] = 0; }
+	__syncthreads();
+	if (n_centre) atomicAdd(&s_acc[0], n_centre);
+	if (n_full) atomicAdd(&s_acc[1], n_full);
+	__syncthreads();
+	if (threadIdx.x == 0 && stat) { atomicAdd(&stat[0], s_acc[0]); atomicAdd(&stat[1], s_acc[1]); }
 }
 
-void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full) {
+void launch_full_window(hipStream_t st, const double *gray_tv, int w, int h, int R, uint8_t *full, uint32_t *stat) {
 	size_t n = (size_t)w*h;
 	size_t b = (n + 255)/256; if (b > 4096) b = 4096; if (b < 1) b = 1;
-	hipLaunchKernelGGL(full_window_kernel, dim3((unsigned)b), dim3(256), 0, st, gray_tv, w, h, R, full);
+	hipLaunchKernelGGL(full_window_kernel, dim3((unsigned)b), dim3(256), 0, st, gray_tv, w, h, R, full, stat);
 }
 
 // ------------------------------------------------------------------ list cost

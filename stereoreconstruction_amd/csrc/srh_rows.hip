@@ -216,8 +216,8 @@ __device__ __forceinline__ void walk_curve_rows(const Ray &ray, const srh_camera
 // Per-pixel arrays are wave-tiled so that the 64 pixels of a wave read and write them coalesced:
 //   list entry k of pixel q   at cand   [((q/64)*cmax  + k)*64 + q%64]
 //   row r of pixel q          at rowinfo[((q/64)*RW_NR + r)*64 + q%64]
-//   cost slot s of pixel x of tile t (32 pixels of one image row, the cost kernel's workgroup)
-//                             at cost   [((t*smax) + s)*32 + x%32]
+//   cost slot s of pixel x of tile t (8 pixels of one image row, a wave tile of the cost kernel)
+//                             at cost   [((t*smax) + s)*8 + x%8]
 __global__ __launch_bounds__(RW_LT)
 void twoview_rows_list_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                               int y0, int nrows_band, uint32_t *__restrict__ cand, int cmax,
@@ -327,7 +327,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
                               const uint8_t *__restrict__ full_oth,
                               const uint32_t *__restrict__ rowinfo, const int32_t *__restrict__ meta,
                               double *__restrict__ cost, int smax, Counters *__restrict__ cnt, const CertBound cb,
-                              const double *__restrict__ pconst, const double *__restrict__ oth_tvp)
+                              const double *__restrict__ pconst, const double *__restrict__ oth_tvp, const uint32_t *__restrict__ full_stat)
 {
 	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;   // 5: the certified ONE-PASS form (srh_internal.hpp, CertBound)
 	constexpr int WS = 2*R + 1;
@@ -351,7 +351,10 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	// fully usable window: the row segments are read from the padded plane (a window that leaves the image reads NaN, which
 	// stays inside the sums of the candidates whose window it is), the results of the others are not stored, and those go
 	// candidate by candidate in phase 2 -- as in twoview_strip_cost_kernel.  Without it a block is fast when all 8 are.
-	const bool masked = oth_tvp != nullptr;
+	// (full_stat: pixels of the other view with a usable centre / with a fully usable window.  Single candidates pay when the
+	// candidates they are for are the exception -- image borders, a few masked spots: C5 --; in a view that is mostly
+	// silhouette edge (the bunny pair: C1) they come by the hundred per tile and the blocked select form is the better deal)
+	const bool masked = oth_tvp != nullptr && (!full_stat || (unsigned long long)full_stat[1]*10ull >= (unsigned long long)full_stat[0]*9ull);
 	const int SPR = padded_stride(OW);
 	typedef const __attribute__((address_space(1))) double *gptr;
 	const gptr rplane = masked ? (gptr)(oth_tvp + (size_t)(SRH_PADY - R)*SPR + (SRH_PADL - R)) : (gptr)(Rv.gray_tv - (ptrdiff_t)R*OW - R);
@@ -382,7 +385,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 	const int y = y0 + trow;
 	const int x = x0 + i;
 	const size_t qbase = (size_t)trow*W + x0;
-	double *const ctile = cost + (size_t)tile*smax*RC_TP + sub*RC_WT;      // cost slot s of the wave tile's pixel pi at ctile[s*32 + pi]
+	double *const ctile = cost + ((size_t)trow*((W + RC_WT - 1)/RC_WT) + x0/RC_WT)*(size_t)smax*RC_WT;   // cost slot s of the wave tile's pixel pi at ctile[s*8 + pi]
 
 	// ---- stage: the windows by LDS-DMA -- the band buffer has the layout of the LDS image ([tile][window row][pixel][WP],
 	// srh_internal.hpp "layout B"), a window row of the wave tile's 8 pixels is 8*WP contiguous doubles: no register, no
@@ -504,7 +507,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		const int cy = ymin + r;
 		const int c0 = xlo + b*RC_NCB;
 		const int nv = wdt - b*RC_NCB < RC_NCB ? wdt - b*RC_NCB : RC_NCB;
-		double *dst = ctile + pi + (size_t)task*RC_NCB*RC_TP;
+		double *dst = ctile + pi + (size_t)task*RC_NCB*RC_WT;
 			// blocked select form, any validity pattern (image border, masked taps, cut-off weights):
 			// the same sums with every tap guarded; a skipped tap adds +0.0
 			const int gx0 = c0 - R;
@@ -586,14 +589,14 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2v[j] * s3[j]));
 						result = (v < P.max_color_diff) ? v : P.max_color_diff;
 					}
-					dst[j*RC_TP] = result;
+					dst[j*RC_WT] = result;
 				}
 			}
 	};
 	if (x < W) {
 		const int m = CS.meta[i];
 		const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
-		double *crow = ctile + i;                                     // tile-transposed: slot s at crow[s*32]
+		double *crow = ctile + i;                                     // wave-tile-transposed: slot s at crow[s*8]
 		const bool lall = CS.lall[i] != 0;
 		const double mL = CS.meanL[i], tw = CS.totalW[i], s2 = CS.sum2[i];
 		const double sig3 = CERT ? cb.sigma3(s2) : 0.0;                // certified: smallest sum3 the bound covers for this pixel
@@ -628,7 +631,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					if (masked) { vm = fm & own; fast = vm != 0; }
 					else { fast = fm == 0xffu; vm = fast ? own : 0u; }
 				}
-				double *dst = crow + (size_t)task*RC_NCB*RC_TP;
+				double *dst = crow + (size_t)task*RC_NCB*RC_WT;
 #ifdef SRH_ROWS_DBG
 				++d_task; d_fast += fast ? 1 : 0; if (g == 0 && task == 0) d_rows += nr;
 				if (lane == __ffsll((long long)__ballot(1)) - 1) { ++d_waveiter; }
@@ -690,7 +693,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 						if ((vm >> j) & 1u) {
 							bool okc;
 							const double v = onepass_finish(P_[j], Q_[j], U_[j], SA, tw, s2, TT, sig3, cb.zmax2, okc);   // (tw: 1/totalWeight in this form)
-							dst[(j - sh)*RC_TP] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
+							dst[(j - sh)*RC_WT] = !okc ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
 						}
 					}
 				} else if (fast) {
@@ -798,8 +801,8 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 					for (int j = 0; j < RC_NCB; ++j) {
 						if ((vm >> j) & 1u) {
 							const double v = 255*(1.0 - fabs(s1[j]) / sqrt(s2 * s3[j]));
-							if (CERT) dst[(j - sh)*RC_TP] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
-							else dst[(j - sh)*RC_TP] = (v < P.max_color_diff) ? v : P.max_color_diff;
+							if (CERT) dst[(j - sh)*RC_WT] = !(s3[j] >= sig3) ? __builtin_nan("") : (v > cb.m_hi ? P.max_color_diff : v);
+							else dst[(j - sh)*RC_WT] = (v < P.max_color_diff) ? v : P.max_color_diff;
 						}
 					}
 				}
@@ -857,7 +860,7 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 			const uint32_t info = CS.rowinfo[pi][r];
 			const int cx = (int)(short)(info & 0xffff) + (slot - (int)CS.blk0[pi][r]*RC_NCB), cy = (int)(short)(m & 0xffff) + r;
 			const double *rp = oth_tvp + (size_t)(cy + SRH_PADY - R)*SPR + (cx + SRH_PADL - R);
-			ctile[pi + (size_t)slot*RC_TP] =
+			ctile[pi + (size_t)slot*RC_WT] =
 				window_exact_cost<R>(&CS.w[0][pi][0], RC_WT*WP, 1, &CS.lt[0][pi], rp, Smem::LW, SPR, P);
 		}
 	}
@@ -879,12 +882,14 @@ void twoview_rows_cost_kernel(const ViewDev *__restrict__ views, int ref, int ot
 bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                               int y0, int nrows, const double *wbuf, const uint8_t *full_oth,
                               const uint32_t *rowinfo, const int32_t *meta, double *cost, int smax, Counters *cnt, int arith,
-                              const double *pconst, const double *oth_tvp, int num_cus)
+                              const double *pconst, const double *oth_tvp, int num_cus, const uint32_t *full_stat)
 {
 	// persistent single-wave workgroups, two per SIMD; Counters::strip_ticket is zero at launch (the caller's memset)
 	const int tiles = (width + RC_TP - 1)/RC_TP;
 	const int items = tiles*(RC_TP/RC_WT)*nrows;
-	const dim3 grid((unsigned)(items < num_cus*8 ? items : num_cus*8));
+	// (a small band -- at most four tiles per resident wave --: one wave per tile, so that the other pass's kernels find room
+	// beside this one as its waves retire: C1 2.19 -> 2.0 ms per step with the two passes side by side)
+	const dim3 grid((unsigned)(items <= 4*num_cus*8 ? items : num_cus*8));
 	const CertBound cb = cert_bound(P);
 #define SRH_RC_LAUNCH2(RR, AA)                                                                              \
 	{                                                                                                       \
@@ -892,7 +897,7 @@ bool launch_twoview_rows_cost(hipStream_t st, const ViewDev *views, int ref, int
 		(void)hipFuncSetAttribute((const void *)twoview_rows_cost_kernel<RR, AA>,                           \
 		                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RowsSmem<RR>));            \
 		hipLaunchKernelGGL((twoview_rows_cost_kernel<RR, AA>), grid, dim3(RC_THREADS), sizeof(RowsSmem<RR>), st,  \
-		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb, pconst, oth_tvp);  \
+		                   views, ref, oth, P, y0, nrows, wbuf, full_oth, rowinfo, meta, cost, smax, cnt, cb, pconst, oth_tvp, full_stat);  \
 		return true;                                                                                        \
 	}
 #define SRH_RC_LAUNCH(RR) { if (arith == 5) SRH_RC_LAUNCH2(RR, 5) else if (arith == 3) SRH_RC_LAUNCH2(RR, 3) else SRH_RC_LAUNCH2(RR, 0) }
@@ -927,8 +932,8 @@ void twoview_rows_refill_kernel(int W, srh_params P, int y0, const uint32_t *__r
 	const WindowAt wa = window_at<R>(wbuf, 1, W, trow, x);        // (the row-run path's band buffer has the LDS-image layout)
 	const int SPL = padded_stride(W), SPR = padded_stride(OW);
 	const double *lp = ref_tvp + (size_t)(y + SRH_PADY - R)*SPL + (x + SRH_PADL - R);
-	const int tiles_per_row = (W + 31) >> 5;
-	double *crow = cost + ((size_t)trow*tiles_per_row + (x >> 5))*(size_t)smax*32 + (x & 31);
+	const int tiles_per_row = (W + 7) >> 3;                       // (cost slots: tiles of 8 pixels, the cost kernel's wave tiles)
+	double *crow = cost + ((size_t)trow*tiles_per_row + (x >> 3))*(size_t)smax*8 + (x & 7);
 	const int m = meta[q];
 	const int ymin = (int)(short)(m & 0xffff), nr = m >> 16;
 	int base = 0;
@@ -937,7 +942,7 @@ void twoview_rows_refill_kernel(int W, srh_params P, int y0, const uint32_t *__r
 		const int xlo = (int)(short)(info & 0xffff), wdt = (int)(info >> 16);
 		for (int k = (int)threadIdx.x; k < wdt; k += 256) {
 			const double *rp = oth_tvp + (size_t)(ymin + r + SRH_PADY - R)*SPR + (xlo + k + SRH_PADL - R);
-			crow[(size_t)(base + k)*32] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SPL, SPR, P);
+			crow[(size_t)(base + k)*8] = window_exact_cost<R>(wa.wq, wa.wrow, wa.wcol, lp, rp, SPL, SPR, P);
 			++n;
 		}
 		base += (wdt + 7) & ~7;
@@ -995,8 +1000,8 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 		}
 		const int n = nr > 0 ? (count[q] < cmax ? count[q] : cmax) : 0;
 		const uint32_t *clist = cand + (q >> 6)*(size_t)cmax*64 + (q & 63);
-		const int tiles_per_row = (W + 31) >> 5;
-		const double *crow = cost + ((size_t)(q / W)*tiles_per_row + (x >> 5))*(size_t)smax*32 + (x & 31);
+		const int tiles_per_row = (W + 7) >> 3;
+		const double *crow = cost + ((size_t)(q / W)*tiles_per_row + (x >> 3))*(size_t)smax*8 + (x & 7);
 		double minCost = __builtin_inf(), secondBest = __builtin_inf();
 		uint32_t win = 0xffffffffu;
 		bool flag = false;
@@ -1010,7 +1015,7 @@ void twoview_rows_scan_kernel(const ViewDev *__restrict__ views, int ref, int ot
 				if (k0 + j < n) {
 					const int cx = (int)(e[j] & 0xffffu), r = (int)(e[j] >> 16) - ymin;
 					const uint32_t ri = s_row[r][threadIdx.x];
-					c[j] = crow[(size_t)((int)(ri >> 16) + cx - (int)(short)(ri & 0xffffu))*32];
+					c[j] = crow[(size_t)((int)(ri >> 16) + cx - (int)(short)(ri & 0xffffu))*8];
 				} else c[j] = __builtin_inf();
 			}
 #pragma unroll

@@ -318,8 +318,9 @@ def test_certified_equals_exact_on_general_geometry(hip_ctx, name, over):
 def test_row_run_masked_blocks_and_single_candidates(hip_ctx, name, over):
     """Round 6: the certified row-run cost kernel evaluates a block in the fast form as soon as ONE of its candidates has a
     fully usable window in the other view (row segments from the NaN-bordered plane, results of the others not stored) and
-    the others one by one; option rows_masked = 0 is the earlier rule (fast only when all 8 are, else the blocked select
-    form).  Both give the exact arithmetic's maps, bit for bit, and count the same evaluations."""
+    the others one by one (option rows_masked = 2: always; 1, the default: when at least 90 % of the other view's usable
+    pixels have a fully usable window -- decided on the device); rows_masked = 0 is the earlier rule (fast only when all 8
+    are, else the blocked select form).  All give the exact arithmetic's maps, bit for bit, and count the same evaluations."""
     import cases
     case = cases.get_twoview(name, **over)
     cams, p = cases.hip_inputs(case)
@@ -328,15 +329,17 @@ def test_row_run_masked_blocks_and_single_candidates(hip_ctx, name, over):
     try:
         hip_ctx.set_option("rows_masked", 0)
         plain = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
-        hip_ctx.set_option("rows_masked", 1)
+        hip_ctx.set_option("rows_masked", 2)                      # always
         masked = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+        hip_ctx.set_option("rows_masked", 1)                      # the default: by the other view's share of fully usable windows
+        auto = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
     finally:
         hip_ctx.set_option("rows_masked", 1)
     for d in range(2):
         assert not masked[d][1]["used_dense_path"]
-        assert np.array_equal(exact[d][0].view(np.uint64), plain[d][0].view(np.uint64)), (name, over, d)
-        assert np.array_equal(exact[d][0].view(np.uint64), masked[d][0].view(np.uint64)), (name, over, d)
-        assert plain[d][1]["n_eval_device"] == masked[d][1]["n_eval_device"] > 0
+        for got in (plain, masked, auto):
+            assert np.array_equal(exact[d][0].view(np.uint64), got[d][0].view(np.uint64)), (name, over, d)
+        assert plain[d][1]["n_eval_device"] == masked[d][1]["n_eval_device"] == auto[d][1]["n_eval_device"] > 0
 
 
 @pytest.mark.parametrize("kind", ["periodic", "flat", "near_flat", "saturated_half", "two_matches"])
