@@ -1372,12 +1372,6 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						} else run_weights(c, ref, W, *p, by, nr, SRH_WTILE, rows_pc ? c->pconst : nullptr, true);
 						if (rows_cert) HIP_TRY(hipMemsetAsync(c->cflag, 0, sizeof(uint32_t), c->stream));
 						HIP_TRY(hipMemsetAsync(&c->d_cnt->strip_ticket, 0, 2*sizeof(unsigned int), c->stream));   // the cost kernel's waves draw their tiles from it
-						if (c->debug_trace && rows_cert) {
-							uint32_t st[2] = { 0, 0 };
-							HIP_TRY(hipMemcpyAsync(st, O.full + full_stat_offset((size_t)O.w*O.h), sizeof(st), hipMemcpyDeviceToHost, c->stream));
-							HIP_TRY(hipStreamSynchronize(c->stream));
-							fprintf(stderr, "[srh trace] row-run cost kernel %d>%d: other view: %u usable pixels, %u with a fully usable window (rows_masked %d)\n", ref, oth, st[0], st[1], c->rows_masked);
-						}
 						{ Scope s(c, "twoview_rows_cost_kernel");
 						  launch_twoview_rows_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, O.full,
 						                           c->lrowinfo, c->lmeta, c->cost, smax, c->d_cnt, rows_cert ? (c->cert_form == 1 ? 5 : 3) : 0,
