@@ -404,7 +404,7 @@ def run_twoview(args, workload, rank, world, dev, dev_index, backend):
 
     ctx = capi.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    for opt in ("fused", "exp_repeat", "exp_lds_pad", "exp_scan_mode", "strip", "geodma", "rows_masked"):   # tuning knobs (timing only / path choice; results are identical)
+    for opt in ("fused", "exp_repeat", "exp_lds_pad", "exp_scan_mode", "strip", "geodma", "rows_masked", "f32_form"):   # tuning knobs (timing only / path choice; results are identical)
         if os.environ.get("SRH_BENCH_" + opt.upper()):
             ctx.set_option(opt, int(os.environ["SRH_BENCH_" + opt.upper()]))
     ctx.upload_view(0, L, ml, cl)

@@ -185,6 +185,7 @@ struct srh_context {
 		       lcount_cap = 0, lmeta_cap = 0, stpl_cap = 0, tileflag_cap = 0;
 	} tv_slot;
 	int tv_overlap = 1;                                 // option "tv_overlap": 0 = both passes on the context's stream, one after the other
+	int f32_form = 0;                                   // option "f32_form" (f32 mode only, not a parity mode): 1 = the one-pass sums in single precision (priced in DESIGN.md 9.0'' (i))
 	int rows_masked = 1;                                // option "rows_masked": the certified row-run cost kernel's masked blocks + single candidates: 1 = when at least 90 % of the other view's usable pixels have a fully usable window (decided on the device), 2 = always, 0 = never (a block is fast only when all 8 of its candidates are: round 5's rule)
 	int side_weights = 1;                               // option "side_weights": 0 = the row-run path computes its support windows on the pass's own stream, behind the list kernel (profiling: every kernel's own duration)
 	int cert_form = 1;                                  // option "cert_form": certified strip kernel in 1 = the one-pass form (default), 2 = two fused sweeps
@@ -792,6 +793,7 @@ extern "C" int srh_set_option(srh_context *c, const char *name, long value) {
 	if (!strcmp(name, "tv_overlap")) { c->tv_overlap = value != 0; return SRH_OK; }
 	if (!strcmp(name, "tscan")) { c->tscan = value != 0; return SRH_OK; }
 	if (!strcmp(name, "geodma")) { c->geodma = value != 0; return SRH_OK; }
+	if (!strcmp(name, "f32_form")) { c->f32_form = value != 0; return SRH_OK; }
 	if (!strcmp(name, "rows_masked")) { c->rows_masked = (int)value; return SRH_OK; }   // 0 off, 1 by the other view's share of fully usable windows (default), 2 always
 	if (!strcmp(name, "side_weights")) { c->side_weights = value != 0; return SRH_OK; }
 	// test of the cut-list redo: the capacity the next MultiViewStereo estimate is queued with (0 = forget what was learnt)
@@ -1554,7 +1556,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 						{ Scope s(c, "twoview_dense_cost_kernel");
 						  if (arith == 2)
 							launch_twoview_dense_cost_f32(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-							                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst);
+							                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->f32_form);
 						  else
 							launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
 							                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, arith); }

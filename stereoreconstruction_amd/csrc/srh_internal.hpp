@@ -236,7 +236,7 @@ void launch_label_plane_table(hipStream_t st, const ViewDev *views, int ref, con
 void launch_pinhole_label_table(hipStream_t st, const ViewDev *views, int ref, const srh_params &P, bool mvs, double *tnum);
 bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                    int y0, int nrows, const double *wbuf, size_t wstride,
-                                   const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst);
+                                   const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int form = 0);   // form 1: one-pass sums
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
                                const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);

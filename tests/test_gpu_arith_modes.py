@@ -54,8 +54,9 @@ def test_fma_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed):
                                                       (320, 240, 64, capi.WEIGHT_GEODESIC, 0x5EED0009, 5),
                                                       (333, 201, 40, capi.WEIGHT_GEODESIC, 0x5EED0011, 2)],
                          ids=["C2", "small-geodesic", "odd-size-r2"])
-def test_f32_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed, radius):
-    """Mode 2: the cost loops in single precision (srh_dense_f32.hip).  Costs agree to ~6 digits; the winner changes
+@pytest.mark.parametrize("form", [0, 1], ids=["two-sweeps", "one-pass"])
+def test_f32_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed, radius, form):
+    """Mode 2: the cost loops in single precision (srh_dense_f32.hip; option f32_form 1: its one-pass sums, round 6).  Costs agree to ~6 digits; the winner changes
     where two candidates are that close or the ratio test sits on its threshold.  Measured here, bounded loosely: the
     point of the test is that the mode computes the same thing (same classes, same depths almost everywhere) -- a
     wrong tile offset or a dropped block shows up as tens of percent."""
@@ -67,12 +68,14 @@ def test_f32_mode_mismatch_rate(hip_ctx, W, H, D, wkind, seed, radius):
     st0 = hip_ctx.stats()
     assert st0["used_dense_path"]
     hip_ctx.set_option("arith", 2)
+    hip_ctx.set_option("f32_form", form)
     try:
         hip_ctx.twoview_wta(0, 1, p)
         f32 = hip_ctx.download_depth(0)
         st2 = hip_ctx.stats()
     finally:
         hip_ctx.set_option("arith", capi.ARITH_DEFAULT)
+        hip_ctx.set_option("f32_form", 0)
     assert st2["used_dense_path"] and st2["n_eval"] == st0["n_eval"] and st2["n_pixels"] == st0["n_pixels"]
     differ = exact.view(np.uint64) != f32.view(np.uint64)
     rate = differ.mean()
