@@ -345,6 +345,28 @@ def test_row_run_masked_blocks_and_single_candidates(hip_ctx, name, over):
         assert plain[d][1]["n_eval_device"] == masked[d][1]["n_eval_device"] == auto[d][1]["n_eval_device"] > 0
 
 
+@pytest.mark.parametrize("name,over", [ROWS_CASES[4], ROWS_CASES[5]])
+def test_row_run_path_in_bands_of_a_row_or_two(hip_ctx, name, over):
+    """The row-run path with a band budget of 1 MB (a row or two per band: the cost kernel's waves draw their 8-pixel tiles
+    from a ticket counter that is reset per launch, the band's windows arrive in the LDS-image layout by LDS-DMA, the cost
+    slots are tiled by 8 pixels per band row): the same maps as in one band, certified and exact."""
+    import cases
+    case = cases.get_twoview(name, **over)
+    cams, p = cases.hip_inputs(case)
+    cases.upload_case(hip_ctx, case, cams)
+    whole = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+    try:
+        hip_ctx.set_option("band_budget_mb", 1)
+        cert = _rows_both_ways(hip_ctx, p, capi.ARITH_CERTIFIED)
+        exact = _rows_both_ways(hip_ctx, p, capi.ARITH_EXACT)
+    finally:
+        hip_ctx.set_option("band_budget_mb", 32768)
+    for d in range(2):
+        assert not cert[d][1]["used_dense_path"]
+        assert np.array_equal(whole[d][0].view(np.uint64), cert[d][0].view(np.uint64)), (name, d)
+        assert np.array_equal(whole[d][0].view(np.uint64), exact[d][0].view(np.uint64)), (name, d)
+
+
 @pytest.mark.parametrize("kind", ["periodic", "flat", "near_flat", "saturated_half", "two_matches"])
 def test_certified_equals_exact_on_adversarial_images_general_geometry(hip_ctx, kind):
     """The adversarial images once more under a slightly verged, distorted rig: row-run lists, curves crossing rows."""
