@@ -1494,8 +1494,9 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 			if (strip && c->strip == 1 && (size_t)((W + SRH_WTILE - 1)/SRH_WTILE)*rows < (size_t)48*2*c->num_cus) strip = false;
 			else break;
 		}
+		const bool wimg = strip;                                       // the band's windows in the LDS image's layout
 		const size_t wstride = SRH_WTILE;
-		if ((rc = ensure(c->wbuf, c->wbuf_cap, strip ? wimg_doubles(W, (int)rows, R) : wbuf_doubles(W, (int)rows, T)))) return rc;
+		if ((rc = ensure(c->wbuf, c->wbuf_cap, wimg ? wimg_doubles(W, (int)rows, R) : wbuf_doubles(W, (int)rows, T)))) return rc;
 		if (dense && (rc = ensure(c->cost, c->cost_cap, rows*(size_t)((W + 31)/32)*32*(size_t)cstride))) return rc;   // 32-pixel tiles
 		// (+ one tile of slack: the strip kernel copies whole 32-pixel pieces of these rows)
 		if (dense && (rc = ensure(c->pconst, c->pconst_cap, (rows*(size_t)W + SRH_WTILE)*SRH_PC))) return rc;
@@ -1535,7 +1536,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 		for (int by = y0; by < y1; by += (int)rows) {
 			if (cancelled(c)) return fail(SRH_E_CANCELLED, "cancelled");
 			const int nr = std::min((int)rows, y1 - by);
-			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr, strip);
+			run_weights(c, ref, W, *p, by, nr, wstride, dense ? c->pconst : nullptr, wimg);
 			if (dense) {
 				Scope s(c, "pixel_range_kernel");
 				launch_pixel_range(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, cstride, c->prange);
@@ -1559,7 +1560,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 							                              c->tnum, c->cost, cstride, c->d_cnt, c->pconst, c->f32_form);
 						  else
 							launch_twoview_dense_cost(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->wbuf, wstride,
-							                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, arith); }
+							                          c->tnum, c->cost, cstride, c->d_cnt, c->pconst, arith, c->prange); }
 						Scope s(c, "twoview_lazy_fill_kernel");
 						launch_twoview_lazy_fill(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->prange, c->wbuf, wstride,
 						                         planes ? c->views[ref].tvp : nullptr, planes ? c->views[oth].tvp : nullptr, false, 8,
@@ -1595,7 +1596,7 @@ static int twoview_wta_run(srh_context *c, int ref, int oth, const srh_params *p
 					// refilled and they are scanned again -- launched for a capacity, the count stays on the device
 					const int cap = redo_capacity((size_t)nr*W);
 					{ Scope s(c, "twoview_refill_kernel");
-					  launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, cap, c->wbuf, strip, c->views[ref].tvp,
+					  launch_twoview_refill(c->stream, W, *p, by, c->prange, c->cflag, cap, c->wbuf, wimg, c->views[ref].tvp,
 					                        c->views[oth].tvp, c->cost, cstride, c->d_cnt); }
 					Scope s(c, "twoview_rescan_kernel");
 					launch_twoview_scan(c->stream, c->d_views, ref, oth, W, *p, by, nr, c->tnum, c->cost, cstride, c->d_cnt, c->prange,

@@ -716,7 +716,7 @@ bool launch_geodesic_dma(hipStream_t st, const ViewDev *views, int ref, int widt
 template <int R>
 __global__ __launch_bounds__(AW_TW)
 void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params P, int y0, int nrows,
-                         double *__restrict__ wbuf, size_t wstride, double *__restrict__ pconst)
+                         double *__restrict__ wbuf, size_t wstride, double *__restrict__ pconst, int wimg)
 {
 	constexpr int WS = 2*R + 1, TWD = AW_TW + 2*R;
 	const ViewDev &V = views[ref];
@@ -740,7 +740,9 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 #pragma unroll
 	for (int k = 0; k <= R; ++k) dw[k] = exp(-k / (1.0*R));
 	const uint32_t crgb = ct[R][i + R];
-	double *wb = wbuf + wbuf_offset(W, WS*WS, trow, cx);
+	// (wimg, round 6: the strip / wave-tile paths' LDS-image layout -- tap (a, b) at a*wimg_row_stride + b -- else tile-major)
+	double *wb = wbuf + (wimg ? wimg_offset(W, R, trow, cx) : wbuf_offset(W, WS*WS, trow, cx));
+	const size_t wra = wimg ? (size_t)wimg_row_stride(R) : (size_t)WS*wstride, wcb = wimg ? 1 : wstride;
 	// the window is NOT kept in registers (121 doubles would leave one wave per SIMD alone with the exp / sqrt / division
 	// chains): weights stream out as they are computed, meanL / totalWeight accumulate on the way, and the second sweep of
 	// the constants reads the weights back (the wave's own 256-byte segments, just written)
@@ -765,7 +767,7 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 				weight = w1*w2;
 				if (weight != weight) weight = 0.0;
 			}
-			wb[(size_t)(a*WS + b)*wstride] = weight;
+			wb[(size_t)a*wra + (size_t)b*wcb] = weight;
 			if (pconst) {
 				const double gl = gt[a][i + b];
 				if (!(gl == gl && weight > P.weight_cutoff)) all = false;
@@ -782,7 +784,7 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 			for (int a = 0; a < WS; ++a) {
 				double wr[WS];
 #pragma unroll
-				for (int b = 0; b < WS; ++b) wr[b] = wb[(size_t)(a*WS + b)*wstride];
+				for (int b = 0; b < WS; ++b) wr[b] = wb[(size_t)a*wra + (size_t)b*wcb];
 #pragma unroll
 				for (int b = 0; b < WS; ++b) { const double t = wr[b]*gt[a][i + b] - mL; s2 += t*t; sa += __builtin_fma(wr[b], gt[a][i + b], -mL); }   // (sa: fused terms, SRH_PC)
 			}
@@ -793,14 +795,14 @@ void adaptive_reg_kernel(const ViewDev *__restrict__ views, int ref, srh_params 
 	}
 }
 
-// tile-major windows only (the strip path's LDS-image layout and other radii stay on weights_kernel)
+// radii 5 and 2, either band layout (other radii stay on weights_kernel)
 bool launch_adaptive_reg(hipStream_t st, const ViewDev *views, int ref, int width, const srh_params &P, int y0, int nrows,
                          double *wbuf, size_t wstride, double *pconst, bool wimg)
 {
-	if (wimg || wstride != SRH_WTILE) return false;
+	if (wstride != SRH_WTILE) return false;
 	const dim3 grid((unsigned)(((width + AW_TW - 1)/AW_TW)*nrows)), block(AW_TW);
-	if (P.window_radius == 5) hipLaunchKernelGGL(adaptive_reg_kernel<5>, grid, block, 0, st, views, ref, P, y0, nrows, wbuf, wstride, pconst);
-	else if (P.window_radius == 2) hipLaunchKernelGGL(adaptive_reg_kernel<2>, grid, block, 0, st, views, ref, P, y0, nrows, wbuf, wstride, pconst);
+	if (P.window_radius == 5) hipLaunchKernelGGL(adaptive_reg_kernel<5>, grid, block, 0, st, views, ref, P, y0, nrows, wbuf, wstride, pconst, wimg ? 1 : 0);
+	else if (P.window_radius == 2) hipLaunchKernelGGL(adaptive_reg_kernel<2>, grid, block, 0, st, views, ref, P, y0, nrows, wbuf, wstride, pconst, wimg ? 1 : 0);
 	else return false;
 	return true;
 }
@@ -968,7 +970,8 @@ __global__ __launch_bounds__(DC_THREADS, MINW)
 void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int oth, srh_params P,
                                int y0, int nrows, const double *__restrict__ wbuf, size_t wstride,
                                const double *__restrict__ tnum, double *__restrict__ cost, int cstride,
-                               Counters *__restrict__ cnt, const double *__restrict__ pconst, const CertBound cb)
+                               Counters *__restrict__ cnt, const double *__restrict__ pconst, const CertBound cb,
+                               const PixRange *__restrict__ prange)
 {
 	constexpr bool FMA = AR != 0, CERT = AR == 3 || AR == 5, ONEPASS = AR == 5;   // 5: the certified one-pass form (srh_internal.hpp, CertBound)
 	constexpr int WS = 2*R + 1;
@@ -1037,6 +1040,11 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 		const double *pc = pconst + ((size_t)trow*W + x)*SRH_PC;
 		pc_[0] = pc[0]; pc_[1] = pc[1]; pc_[2] = pc[2]; pc_[3] = pc[3]; pc_[4] = pc[4];
 	}
+	// (prange, round 6: the pixel's column range from pixel_range_kernel -- the same function on the same operands, made once
+	// per band with every lane busy.  Worked out here it was cam_unproject + pinhole_column_range on one lane in eight
+	// with the tile's other lanes waiting: 140 000 of a wave's 355 000 cycles on C2, more than its block loops' 105 000.)
+	PixRange pr_; pr_.lo = 0; pr_.hi = -1;
+	if (prange && g == 0 && x < W) pr_ = prange[(size_t)trow*W + x];
 	// ---- union of the candidate ranges of the tile (one global load, one LDS reduction)
 	__shared__ int s_cmin, s_cmax, s_need_pix, s_need_col;
 	if (tid == 0) { s_cmin = 2147483647; s_cmax = -2147483647; s_need_pix = 0; s_need_col = 0; }
@@ -1044,11 +1052,12 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 	if (g == 0) {
 		// candidate column range of the pixel (verified later by the scan kernel)
 		int lo = 0, hi = -1;
-		if (x < W && L.mask[(size_t)y*W + x] == 1) {
+		if (prange) { lo = pr_.lo; hi = pr_.hi; }
+		else if (x < W && L.mask[(size_t)y*W + x] == 1) {
 			const Ray ray = cam_unproject(L.cam, (x + 0.5) / P.image_scale, (y + 0.5) / P.image_scale);
 			pinhole_column_range(ray, L.cam, Rv, P, tnum, cstride, lo, hi);
-			if (hi >= lo) hi = dense_cover_hi(lo, hi, DC_NCB, DC_G, !ONEPASS);   // columns beyond: evaluated by the fill kernel
 		}
+		if (hi >= lo) hi = dense_cover_hi(lo, hi, DC_NCB, DC_G, !ONEPASS);   // columns beyond: evaluated by the fill kernel
 		S.pxmin[i] = lo; S.pxmax[i] = hi;
 		if (hi >= lo) { atomicMin(&s_cmin, lo); atomicMax(&s_cmax, hi); }
 	}
@@ -1405,7 +1414,7 @@ void twoview_dense_cost_kernel(const ViewDev *__restrict__ views, int ref, int o
 template <int R, int NCB, int CHUNK, int MINW, int AR>
 static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views, int ref, int oth, const srh_params &P,
                                  int y0, int nrows, const double *wbuf, size_t wstride,
-                                 const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst)
+                                 const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, const PixRange *prange)
 {
 	typedef DenseSmem<R, NCB, CHUNK> Smem;
 	// a function attribute belongs to the CURRENT device: set it on every launch (a host-side table update),
@@ -1417,16 +1426,17 @@ static void launch_dense_variant(hipStream_t st, dim3 grid, const ViewDev *views
 	(void)hipFuncSetAttribute((const void *)twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, AR>,
 	                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipLaunchKernelGGL((twoview_dense_cost_kernel<R, NCB, CHUNK, MINW, AR>), grid, dim3(DC_THREADS), lds, st,
-	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst, cert_bound(P));
+	                   views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst, cert_bound(P), prange);
 }
 
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith)
+                               const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith,
+                               const PixRange *prange)
 {
 	const int tiles = (width + DC_TP - 1)/DC_TP;
 	const dim3 grid((unsigned)(tiles*nrows));
-#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst
+#define SRH_ARGS st, grid, views, ref, oth, P, y0, nrows, wbuf, wstride, tnum, cost, cstride, cnt, pconst, prange
 	switch (P.window_radius) {
 	case 5:
 		if (arith == 5) launch_dense_variant<5, 8, 320, 2, 5>(SRH_ARGS);

@@ -239,7 +239,8 @@ bool launch_twoview_dense_cost_f32(hipStream_t st, const ViewDev *views, int ref
                                    const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int form = 0);   // form 1: one-pass sums
 bool launch_twoview_dense_cost(hipStream_t st, const ViewDev *views, int ref, int oth, int width, const srh_params &P,
                                int y0, int nrows, const double *wbuf, size_t wstride,
-                               const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0);
+                               const double *tnum, double *cost, int cstride, Counters *cnt, const double *pconst, int arith = 0,
+                               const PixRange *prange = nullptr);   // the pixels' column ranges from pixel_range_kernel (else worked out per tile)
 // cflag == nullptr: the exact scan (cnt == nullptr: without counting).  cflag, nlist < 0: the certified scan on fused
 // costs, flagged pixels into cflag = [count | band pixel indices].  cflag, nlist >= 0: the exact scan of the listed pixels
 // (launch sized for nlist pixels, the count itself is read on the device)
